@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REAL reference.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+The script imports ``mega_nerf`` from /root/reference (read-only, torch CPU fp32), feeds it the
+seeded scene/weights from ``common.py`` and stores inputs + outputs (+ captured random draws and
+searchsorted indices) as small ``.npz`` files.  Nothing from the reference is copied: only its
+numerical outputs are recorded.
+"""
+import os
+import sys
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(HERE))
+
+from mega_nerf import rendering as R  # noqa: E402  (reference)
+from mega_nerf import ray_utils as RU  # noqa: E402
+from mega_nerf.models import model_utils as MU  # noqa: E402
+from mega_nerf.models.cascade import Cascade  # noqa: E402
+from mega_nerf.models.mega_nerf import MegaNeRF  # noqa: E402
+from mega_nerf.models.nerf import Embedding  # noqa: E402
+from mega_nerf.spherical_harmonics import eval_sh  # noqa: E402
+
+import common  # noqa: E402
+from oracle.nerf_oracle import make_hparams  # noqa: E402  (only the hparams field list)
+
+f32 = np.float32
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+def ref_model(hp, cfg, weights, appearance_count):
+    m = MU._get_single_nerf_inner(hp, appearance_count, cfg.layer_dim, cfg.xyz_dim)
+    m.load_state_dict({k: T(v) for k, v in weights.items()})
+    return m
+
+
+class Recorder:
+    """Records torch.rand / rand_like / searchsorted results in reference call order, tagged by
+    which part of render_rays drew them."""
+
+    def __init__(self, Nc):
+        self.Nc = Nc
+        self.ctx = ['fg', 'coarse']
+        self.rnd = {}
+        self.inds = {}
+        self._orig = {}
+
+    def _add(self, key, val):
+        self.rnd.setdefault(key, []).append(val.detach().numpy().copy())
+
+    def __enter__(self):
+        o = self._orig
+        o['rand'], o['rand_like'], o['ss'] = torch.rand, torch.rand_like, torch.searchsorted
+        o['gr'], o['inf'], o['sc'] = R._get_results, R._inference, R._sample_cdf
+        rec = self
+
+        def rand(*a, **k):
+            v = o['rand'](*a, **k)
+            rec._add('%s_%s' % (rec.ctx[0], rec.ctx[2] if len(rec.ctx) > 2 else 'noise_' + rec.ctx[1]), v)
+            return v
+
+        def rand_like(x, **k):
+            v = o['rand_like'](x, **k)
+            rec._add('bg_perturb' if x.shape[1] == rec.Nc // 2 else 'fg_perturb', v)
+            return v
+
+        def ss(cdf, u, right=False):
+            v = o['ss'](cdf, u, right=right)
+            rec.inds[rec.ctx[0]] = v.numpy().copy()
+            return v
+
+        def gr(*a, **k):
+            rec.ctx = ['bg' if k['flip'] else 'fg', 'coarse']
+            return o['gr'](*a, **k)
+
+        def inf(*a, **k):
+            rec.ctx = [rec.ctx[0], k['typ']]
+            return o['inf'](*a, **k)
+
+        def sc(*a, **k):
+            rec.ctx = [rec.ctx[0], rec.ctx[1], 'u']
+            r = o['sc'](*a, **k)
+            rec.ctx = rec.ctx[:2]
+            return r
+
+        torch.rand, torch.rand_like, torch.searchsorted = rand, rand_like, ss
+        R._get_results, R._inference, R._sample_cdf = gr, inf, sc
+        return self
+
+    def __exit__(self, *exc):
+        o = self._orig
+        torch.rand, torch.rand_like, torch.searchsorted = o['rand'], o['rand_like'], o['ss']
+        R._get_results, R._inference, R._sample_cdf = o['gr'], o['inf'], o['sc']
+
+    def randoms(self):
+        return {k: np.concatenate([x.reshape(x.shape[0], -1) for x in v], 0) if 'noise' in k else v[0]
+                for k, v in self.rnd.items()}
+
+
+def scene_rays():
+    s = common.SCENE
+    d = RU.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, torch.device('cpu'))
+    rays = RU.get_rays(d, T(s['c2w']), s['near'], s['far'], s['ray_altitude_range'])
+    return rays.view(-1, 8).numpy()
+
+
+def save(name, **arrs):
+    np.savez_compressed(HERE / (name + '.npz'), **arrs)
+    print('wrote', name, sum(np.asarray(v).nbytes for v in arrs.values()) // 1024, 'KiB raw')
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_rays():
+    W, H, fx, fy, cx, cy = 40, 30, 30.0, 32.0, 19.5, 15.25
+    out = {}
+    for cp in (True, False):
+        out['dirs_c%d' % cp] = RU.get_ray_directions(W, H, fx, fy, cx, cy, cp, torch.device('cpu')).numpy()
+    d = T(out['dirs_c1'])
+    c2w = common.SCENE['c2w']
+    out['rays_alt'] = RU.get_rays(d, T(c2w), 0.01, 1e5, [-0.5, 0.2]).numpy()
+    out['rays_noalt'] = RU.get_rays(d, T(c2w), 0.05, 2.0, None).numpy()
+    out['rays_alt2'] = RU.get_rays(d, T(c2w), 0.3, 0.9, [-0.35, -0.1]).numpy()   # clamps bite on both ends
+    c2w2 = np.stack([c2w, np.array([[0, 1, 0, -.1], [.6, 0, .8, 0], [.8, 0, -.6, .2]], f32)])
+    pix = d.view(-1, 3)[::7][:64].unsqueeze(0).repeat(2, 1, 1).contiguous()
+    out['batch_dirs'] = pix.numpy()
+    out['batch_c2w'] = c2w2
+    out['rays_batch'] = RU.get_rays_batch(pix, T(c2w2), 0.01, 1e5, [-0.5, 0.2]).numpy()
+    save('rays', W=W, H=H, intr=np.array([fx, fy, cx, cy], f32), c2w=c2w, **out)
+
+
+def gen_stages(all_rays):
+    s = common.SCENE
+    rays, idx = common.pick_rays(all_rays, 64, 7)
+    o, d = T(rays[:, :3]), T(rays[:, 3:6])
+    c, r = T(s['sphere_center']), T(s['sphere_radius'])
+    out = dict(rays=rays)
+    out['fg_far'] = R._intersect_sphere(o, d, c, r).numpy()
+    out['fg_far_nosphere'] = R._intersect_sphere(o * 0.3, d, None, None).numpy()
+    torch.manual_seed(3)
+    depth = torch.rand(64, 32).sort(-1)[0]
+    out['depth'] = depth.numpy()
+    for xr, c2 in ((False, False), (True, False), (True, True)):
+        pts, dr = R._depth2pts_outside(o.view(64, 1, 3), d.view(64, 1, 3), depth, c, r, xr, c2)
+        out['pts_%d%d' % (xr, c2)] = pts.numpy()
+        out['depth_real_%d%d' % (xr, c2)] = dr.numpy()
+    z = torch.linspace(0, 1, 32)
+    pr = torch.rand(64, 32)
+    orig = torch.rand_like
+    torch.rand_like = lambda x: pr
+    out['perturbed'] = R._expand_and_perturb_z_vals(z, 32, 0.7, 64).numpy()
+    torch.rand_like = orig
+    out['perturb_rand'] = pr.numpy()
+    # sample_pdf: peaky weights incl. exact zeros; det and random u
+    for n in (62, 30, 254):
+        w = torch.rand(64, n) ** 6
+        w[:, : n // 3] = 0
+        w[5] = 0
+        bins = (torch.rand(64, n + 1).sort(-1)[0] * 3 + 0.1)
+        for det, nf in ((True, 128), (False, 64)):
+            u = torch.rand(64, nf)
+            orig_r, orig_ss = torch.rand, torch.searchsorted
+            cap = {}
+            torch.rand = lambda *a, **k: u
+
+            def ss(cdf, uu, right=False):
+                cap['cdf'] = cdf.numpy().copy()
+                cap['inds'] = orig_ss(cdf, uu, right=right)
+                return cap['inds']
+            torch.searchsorted = ss
+            smp = R._sample_pdf(bins, w, nf, det)
+            torch.rand, torch.searchsorted = orig_r, orig_ss
+            tag = '%d_%s' % (n, 'det' if det else 'rnd')
+            out['pdf_w_%d' % n] = w.numpy()
+            out['pdf_bins_%d' % n] = bins.numpy()
+            out['pdf_u_' + tag] = u.numpy()
+            out['pdf_cdf_' + tag] = cap['cdf']
+            out['pdf_inds_' + tag] = cap['inds'].numpy().astype(np.int16)
+            out['pdf_samples_' + tag] = smp.numpy()
+    x = (torch.rand(50, 4) * 2 - 1)
+    out['emb_x'] = x.numpy()
+    out['emb_12'] = Embedding(12)(x).numpy()
+    out['emb_4'] = Embedding(4)(x[:, :3]).numpy()
+    for deg in range(5):
+        sh = torch.randn(20, 3, (deg + 1) ** 2)
+        dirs = torch.nn.functional.normalize(torch.randn(20, 3), dim=-1)
+        out['sh_in_%d' % deg] = sh.numpy()
+        out['sh_dirs_%d' % deg] = dirs.numpy()
+        out['sh_out_%d' % deg] = eval_sh(deg, sh, dirs).numpy()
+    for n in (32, 64, 128, 256, 512):
+        out['linspace_%d' % n] = torch.linspace(0, 1, n).numpy()
+    save('stages', **out)
+
+
+def gen_mlp():
+    """NeRF.forward on flat batches: fg (xyz3), bg (xyz4), sigma_only, noise, SH, W=512, relu-sigma."""
+    out = {}
+    rng = np.random.default_rng(11)
+    B = 200
+    variants = dict(
+        fg=dict(xyz_dim=3), bg=dict(xyz_dim=4), w512=dict(xyz_dim=3, layer_dim=512),
+        sh2=dict(xyz_dim=3, sh_deg=2, pos_dir_dim=0), noapp=dict(xyz_dim=3, appearance_dim=0),
+        relu=dict(xyz_dim=3, shifted_softplus=False), w64=dict(xyz_dim=4, layer_dim=64),
+        plain=dict(xyz_dim=3, appearance_dim=0, pos_dir_dim=0),
+        affine=dict(xyz_dim=3, affine_appearance=True))
+    for name, v in variants.items():
+        v = dict(v)
+        xyz_dim = v.pop('xyz_dim')
+        hp = Namespace(**vars(make_hparams(coarse_samples=64, fine_samples=128, **v)))
+        cfg = common.model_cfg(hp, xyz_dim, hp.layer_dim)
+        w = common.make_weights(cfg, 100, 100 + len(name), sharpen=False)
+        m = ref_model(hp, cfg, w, 100).eval()
+        cols = [rng.uniform(-1, 1, (B, xyz_dim))]
+        if cfg.pos_dir_dim > 0:
+            dd = rng.standard_normal((B, 3))
+            cols.append(dd / np.linalg.norm(dd, axis=-1, keepdims=True))
+        if cfg.appearance_dim > 0:
+            cols.append(rng.integers(0, 100, (B, 1)).astype(np.float64))
+        x = np.concatenate(cols, 1).astype(f32)
+        noise = rng.uniform(0, 1, (B, 1)).astype(f32)
+        with torch.no_grad():
+            out[name + '_x'] = x
+            out[name + '_noise'] = noise
+            out[name + '_out'] = m(T(x)).numpy()
+            out[name + '_out_noise'] = m(T(x), sigma_noise=T(noise)).numpy()
+            out[name + '_sigma_only'] = m(T(x[:, :xyz_dim]), sigma_only=True).numpy()
+    save('mlp', **out)
+
+
+def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train=False, cascade=False,
+               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256):
+    s = common.SCENE
+    hp = Namespace(**vars(make_hparams(layer_dim=layer_dim, bg_layer_dim=bg_layer_dim, **hp_kw)))
+    rays, idx = common.pick_rays(all_rays, N, seed)
+    use_idx = hp.appearance_dim > 0
+    fcfg = common.model_cfg(hp, 3, hp.layer_dim)
+    bcfg = common.model_cfg(hp, 4, hp.bg_layer_dim)
+    A = s['appearance_count']
+    extra = {}
+    if container is not None:
+        n_sub = container
+        g = int(np.sqrt(n_sub))
+        ys, zs = np.meshgrid(np.linspace(-.5, .5, g), np.linspace(-.5, .5, g), indexing='ij')
+        cent = np.stack([np.zeros(n_sub), ys.ravel(), zs.ravel()], -1).astype(f32)
+        extra['centroids'] = cent
+        subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
+        bsubs = [ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500 + i), A) for i in range(n_sub)]
+        nerf = MegaNeRF(subs, T(cent), hp.boundary_margin, False, False)
+        bg_nerf = MegaNeRF(bsubs, T(cent), hp.boundary_margin, True, False)
+    elif cascade:
+        nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
+                       ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
+        bg_nerf = Cascade(ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A),
+                          ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 501), A)) if bg else None
+    else:
+        nerf = ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A)
+        bg_nerf = ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A) if bg else None
+    nerf.train(fg_train)
+    if bg_nerf is not None:
+        bg_nerf.train(bg_train)
+    torch.manual_seed(seed)
+    idx_t = (T(idx.astype(np.int32)) if fg_train else T(idx.astype(f32))) if use_idx else None
+    sc = T(s['sphere_center']) if bg else None
+    sr = T(s['sphere_radius']) if bg else None
+    with Recorder(hp.coarse_samples) as rec:
+        if with_grad:
+            res, present = R.render_rays(nerf, bg_nerf, T(rays), idx_t, hp, sc, sr, *flags)
+        else:
+            with torch.inference_mode():
+                res, present = R.render_rays(nerf, bg_nerf, T(rays), idx_t, hp, sc, sr, *flags)
+    out = dict(rays=rays, idx=idx.astype(np.int32), flags=np.array(flags), present=np.array(present), seed=seed,
+               **extra)
+    for k, v in res.items():
+        out['res_' + k] = v.detach().numpy()
+    for k, v in rec.randoms().items():
+        out['rnd_' + k] = v
+    for k, v in rec.inds.items():
+        out['inds_' + k] = v.astype(np.int16)
+    if with_grad:
+        rng = np.random.default_rng(seed + 1)
+        target = rng.uniform(0, 1, (N, 3)).astype(f32)
+        typ = 'fine' if 'rgb_fine' in res else 'coarse'
+        loss = torch.nn.functional.mse_loss(res['rgb_' + typ], T(target))
+        if cascade and typ == 'fine':
+            loss = (loss + torch.nn.functional.mse_loss(res['rgb_coarse'], T(target))) / 2
+        loss.backward()
+        out['target'] = target
+        out['loss'] = loss.detach().numpy()
+        for tag, m in (('fg', nerf), ('bg', bg_nerf)):
+            if m is None:
+                continue
+            for pn, p in m.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                out['gnorm_%s_%s' % (tag, pn)] = g.norm().numpy()
+                if g.numel() <= 2048 or pn.startswith('sigma') or pn.startswith('rgb'):
+                    out['grad_%s_%s' % (tag, pn)] = g.numpy()
+                else:   # big matrices: keep a strided sample (every 37th element of the flat grad)
+                    out['gsub_%s_%s' % (tag, pn)] = g.reshape(-1)[::37].numpy().copy()
+    save(name, **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    all_rays = scene_rays()
+    gen_rays()
+    gen_stages(all_rays)
+    gen_mlp()
+    base = dict(coarse_samples=64, fine_samples=128)
+    E = (True, False, True)      # eval flags (runner.py:569-578)
+    TR = (False, True, False)    # train flags (runner.py:349-358)
+    run_render('render_fgbg_eval', base, 96, 1, E, all_rays=all_rays)
+    run_render('render_fgbg_train', base, 64, 2, TR, fg_train=True, bg_train=True, all_rays=all_rays, with_grad=True)
+    run_render('render_fgonly_eval', base, 48, 3, E, bg=False, all_rays=all_rays)
+    run_render('render_sh2_eval', dict(base, sh_deg=2, pos_dir_dim=0), 48, 4, E, all_rays=all_rays)
+    run_render('render_cascade_eval', dict(base, use_cascade=True, appearance_dim=0), 32, 5, E, bg=False,
+               cascade=True, all_rays=all_rays, layer_dim=64)
+    run_render('render_cascade_bg_train', dict(base, use_cascade=True), 32, 6, TR, cascade=True, fg_train=True,
+               bg_train=True, all_rays=all_rays, layer_dim=64, bg_layer_dim=64, with_grad=True)
+    run_render('render_q13_eval', base, 48, 7, E, bg_train=True, all_rays=all_rays)
+    run_render('render_container_eval', dict(base, container_path='dummy'), 48, 8, E, container=4, all_rays=all_rays)
+    run_render('render_default_samples_eval', dict(), 8, 9, E, all_rays=all_rays)
+    run_render('render_w512_eval', base, 32, 10, E, all_rays=all_rays, layer_dim=512, bg_layer_dim=512)
+    # NB: fine_samples=0 with a bg model and no cascade raises KeyError('bg_lambda_coarse') in the reference
+    # (rendering.py:109 vs :208), so the coarse-only case has no bg model.
+    run_render('render_coarse_only_eval', dict(coarse_samples=64, fine_samples=0), 32, 11, E, bg=False,
+               all_rays=all_rays)
+    run_render('render_relu_noapp_eval', dict(base, shifted_softplus=False, appearance_dim=0), 32, 12, E,
+               all_rays=all_rays)
+
+
+if __name__ == '__main__':
+    os.environ.setdefault('OMP_NUM_THREADS', '8')
+    main()
