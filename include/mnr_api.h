@@ -1,0 +1,230 @@
+/*
+ * mnr_api.h -- C ABI of libmeganerf_hip.so: the MI355X (gfx950) implementation of the Mega-NeRF
+ * hot path  ray_utils.get_rays + rendering.render_rays + models.NeRF forward/backward.
+ *
+ * The reference (cmusatyalab/mega-nerf) has no FFI layer: its "plugin boundary" is a set of Python
+ * call signatures that bottom out in torch ATen ops.  Each entry point below replaces one group of
+ * those ops; the reference location it replaces is cited as  file:line  (relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer marked "dev" is a device (HBM) pointer owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only ENQUEUE work:
+ *     they never synchronise the stream, never allocate device memory, keep no global mutable state;
+ *   - return 0 on success, a negative MNR_E_* code otherwise; mnr_last_error() gives a thread-local
+ *     message.  Entry points are re-entrant and may be called from several host threads on different
+ *     streams (the reference calls ray generation from a prefetch thread: filesystem_dataset.py:70-77);
+ *   - all matrices are row-major fp32; "N" = rays, "S" = samples per ray.
+ */
+#ifndef MNR_API_H
+#define MNR_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNR_VERSION 1
+
+#define MNR_OK 0
+#define MNR_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define MNR_E_LAUNCH (-2)    /* HIP launch failure */
+#define MNR_E_UNSUPPORTED (-3)
+
+#define MNR_MAX_LAYERS 16
+
+int mnr_version(void);
+const char *mnr_last_error(void);
+/* 1 if a HIP device is usable by this process, else 0 (never fails). */
+int mnr_device_available(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray generation -- mega_nerf/ray_utils.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_ray_directions (ray_utils.py:6-18): out[H][W][3] = normalize([(i+c-cx)/fx, -(j+c-cy)/fy, -1]),
+ * c = 0.5 if center_pixels. */
+int mnr_ray_directions(float *out_dev, int W, int H, float fx, float fy, float cx, float cy,
+                       int center_pixels, void *stream);
+
+/* get_rays / get_rays_batch (ray_utils.py:21-41) + _get_rays_inner (:44-62) +
+ * _truncate_with_plane_intersection (:65-84).
+ *   dirs_dev : [n_dirs_sets][P][3]; n_dirs_sets is 1 (get_rays: one direction image shared) or n_poses
+ *   c2w_dev  : [n_poses][3][4]
+ *   out_dev  : [n_poses][P][8] = (origin3, dir3, near, far)
+ *   alt_range: host pointer to 2 floats (already normalised) or NULL. */
+int mnr_get_rays(float *out_dev, const float *dirs_dev, int64_t P, int n_dirs_sets, const float *c2w_dev,
+                 int n_poses, float near, float far, const float *alt_range_host, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NeRF MLP -- mega_nerf/models/nerf.py:45-160
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Architecture + device pointers to the nn.Module parameters (nn.Linear.weight = [out][in] row-major,
+ * y = x W^T + b), i.e. exactly the tensors of the reference state_dict (runner.py:521-536):
+ *   layer_w[i]/layer_b[i] = xyz_encodings.{i}.0.{weight,bias}; final_* = xyz_encoding_final;
+ *   dir_a_* = dir_a_encoding.0; sigma_*; rgb_*; embedding_a = embedding_a.weight. */
+typedef struct mnr_model_desc {
+    int32_t xyz_dim;          /* 3 foreground, 4 background (nerf.py:51,  model_utils.py:12-17) */
+    int32_t pos_xyz_dim;      /* frequency bands for xyz (opts.py:42)  */
+    int32_t pos_dir_dim;      /* frequency bands for direction, 0 = no view dependence (opts.py:44) */
+    int32_t layers;           /* opts.py:46 */
+    int32_t skip_mask;        /* bit i set: layer i consumes cat([embedding, h])  (nerf.py:128-129) */
+    int32_t layer_dim;        /* W (opts.py:48-49) */
+    int32_t appearance_dim;   /* opts.py:50; 0 = none */
+    int32_t appearance_count; /* rows of embedding_a */
+    int32_t rgb_dim;          /* 3, or 3*(sh_deg+1)^2 (model_utils.py:57) */
+    int32_t sigma_activation; /* 0 = ReLU, 1 = ShiftedSoftplus (nerf.py:28-39) */
+    const float *layer_w[MNR_MAX_LAYERS];
+    const float *layer_b[MNR_MAX_LAYERS];
+    const float *final_w, *final_b;   /* NULL when the model has neither dir nor appearance input */
+    const float *dir_a_w, *dir_a_b;
+    const float *sigma_w, *sigma_b;
+    const float *rgb_w, *rgb_b;
+    const float *embedding_a;         /* NULL when appearance_dim == 0 */
+} mnr_model_desc;
+
+/* Bytes of the packed (MFMA-fragment-ordered, chunked) weight image for this architecture. 0 + error
+ * string if the architecture is not supported by the fused kernels. */
+size_t mnr_packed_model_bytes(const mnr_model_desc *desc);
+
+/* Re-pack the module parameters into `packed_dev` (device->device, one launch per layer). Call again
+ * whenever the optimiser has stepped. */
+int mnr_pack_model(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
+
+/* Host-side, no GPU needed: source column of nn.Linear `layer` (0..layers-1 trunk, layers = final,
+ * layers+1 = dir_a) that K-step `step` / lane-part `part` of the packed image multiplies; -1 = zero pad.
+ * Exposed so the layout can be unit-tested without a device. */
+int mnr_layout_src_col(const mnr_model_desc *desc, int layer, int step, int part);
+int mnr_layout_num_steps(const mnr_model_desc *desc, int layer);
+int mnr_layout_parts(const mnr_model_desc *desc);
+
+/* One batched MLP evaluation = NeRF.forward(x, sigma_only, sigma_noise)  (nerf.py:115-160).
+ * Row r of the logical input x is  [ xyz(r) | dir(r / rows_per_ray) | idx(r / rows_per_ray) ]:
+ * with rows_per_ray == 1 and the three pointers aimed into one [B][ncols] matrix this is exactly the
+ * reference's x; with rows_per_ray == S it is the repeat/cat of rendering.py:280-319 without
+ * materialising it. */
+typedef struct mnr_mlp_io {
+    const float *xyz;  int64_t xyz_stride;        /* dev [n_rows][>=xyz_dim], row stride in floats */
+    const float *dir;  int64_t dir_stride;        /* dev, 3 floats per ray (NULL if pos_dir_dim==0 and no SH) */
+    const void  *idx;  int64_t idx_stride;        /* dev, image index per ray: float or int32 */
+    int32_t idx_is_float;
+    int32_t rows_per_ray;
+    const float *sigma_noise;                     /* dev [n_rows] or NULL (rendering.py:294,321; nerf.py:133-134) */
+    float *out;        int64_t out_stride;        /* dev [n_rows][out_stride]; writes rgb_dim+1 (or 1) floats */
+    int64_t n_rows;                               /* upper bound on rows (grid size) */
+    const int32_t *n_units_dev;                   /* optional dev scalar: actual rows = *n_units_dev * rows_per_unit */
+    int32_t rows_per_unit;
+    int32_t sigma_only;
+    int32_t apply_sh_deg;                         /* -1: raw output; >=0: rgb = sigmoid(eval_sh(deg, coeffs, dir))
+                                                     (rendering.py:301-306), output is 4 floats */
+} mnr_mlp_io;
+
+int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volume rendering stages -- mega_nerf/rendering.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* rendering.py:33-45 + _intersect_sphere (:396-417): per ray
+ *   fg_far = max(sphere_exit, near); has_bg = far > fg_far; far_out = min(far, fg_far);
+ *   last_delta = has_bg ? fg_far : 1e10.
+ * Then a stable (ascending ray index) compaction of the has_bg rays:
+ *   bg_list[k] = ray, bg_slot[ray] = k or -1, *n_bg.
+ * err_flag (dev int) is set to 1 if any camera lies outside the unit ellipsoid (the reference raises,
+ * rendering.py:412-414; the host shim raises the same text at its next sync).
+ * sphere_center/radius are host pointers to 3 floats (radius may be NULL: plain unit sphere). */
+int mnr_ray_setup(const float *rays_dev, int64_t N, const float *sphere_center_host,
+                  const float *sphere_radius_host, float *far_out_dev, float *last_delta_dev,
+                  int32_t *bg_list_dev, int32_t *bg_slot_dev, int32_t *n_bg_dev, int32_t *err_flag_dev,
+                  void *stream);
+
+/* rendering.py:82-87 (+ _expand_and_perturb_z_vals :472-483): z = near*(1-t)+far*t, optional
+ * stratified jitter with caller-supplied uniforms, then xyz = o + d*z.
+ *   far_dev  : [N] (from mnr_ray_setup) or NULL to use rays[:,7]
+ *   t_dev    : [S] the torch.linspace(0,1,S) table (values are data)
+ *   rand_dev : [N][S] uniforms or NULL (perturb == 0)
+ *   z_out [N][S], xyz_out [N][S][3] */
+int mnr_fg_samples(const float *rays_dev, const float *far_dev, int64_t N, int S, const float *t_dev,
+                   float perturb, const float *rand_dev, float *z_out_dev, float *xyz_out_dev, void *stream);
+
+/* xyz = o + d*z for caller-provided z [N][S]  (rendering.py:100 xyz_fine_fn). */
+int mnr_fg_points(const float *rays_dev, int64_t N, int S, const float *z_dev, float *xyz_out_dev,
+                  void *stream);
+
+/* Background samples (rendering.py:47-56, 70-75): for k < *n_bg, ray = bg_list[k]:
+ *   z[k][s] = t[s] (+ jitter)  when z_in_dev == NULL, else z_in_dev[k][s] (fine pass)
+ *   pts/depth_real = _depth2pts_outside (rendering.py:420-469); pts has 4 columns, or 7 when
+ *   include_xyz_real (container / train_mega_nerf: :52-53, :457-464). */
+int mnr_bg_samples(const float *rays_dev, const int32_t *bg_list_dev, const int32_t *n_bg_dev, int64_t N_max,
+                   int S, const float *t_dev, float perturb, const float *rand_dev, const float *z_in_dev,
+                   const float *sphere_center_host, const float *sphere_radius_host, int include_xyz_real,
+                   int cluster_2d, float *z_out_dev, float *pts_out_dev, float *depth_real_out_dev,
+                   void *stream);
+
+/* _sample_pdf + _sample_cdf (rendering.py:486-536) on caller-provided bins/weights:
+ *   bins [N][nb+1], weights [N][nb] (row strides given), u: either u_dev [N][nf] (det=0) or the shared
+ *   table t_dev [nf] (det=1).  samples_out [N][nf]; inds_out [N][nf] int32 (optional, for parity).
+ * The normaliser and cdf reproduce the reference CPU association order, so indices are
+ * bit-exact for identical inputs. */
+int mnr_sample_pdf(const float *bins_dev, int64_t bins_stride, const float *weights_dev, int64_t weights_stride,
+                   int64_t N, const int32_t *n_units_dev, int nb, int nf, int det, const float *u_dev,
+                   float *samples_out_dev, int32_t *inds_out_dev, void *stream);
+
+/* The importance-sampling step of _get_results (rendering.py:212-216): bins = mid-points of z [N][S],
+ * weights = w[:,1:-1]  ->  nf samples per ray.  flip is irrelevant here (quirk Q1 is reproduced by the
+ * caller passing the flipped-order weights with ascending z, exactly as the reference does). */
+int mnr_sample_fine(const float *z_dev, const float *weights_dev, int64_t N, const int32_t *n_units_dev, int S,
+                    int nf, int det, const float *u_dev, float *samples_out_dev, int32_t *inds_out_dev,
+                    void *stream);
+
+/* Merge coarse and fine samples (rendering.py:336-350): stable sort of cat([z_fine, z_coarse]) along the
+ * ray (descending when flip) and gather of raw rgb/sigma (and depth_real).
+ *   raw_* are [N][S*][4] MLP outputs; outputs z [N][Sf+Sc], raw [N][Sf+Sc][4], depth_real [N][Sf+Sc]. */
+int mnr_merge_sorted(const float *z_fine_dev, const float *raw_fine_dev, const float *dr_fine_dev, int Sf,
+                     const float *z_coarse_dev, const float *raw_coarse_dev, const float *dr_coarse_dev, int Sc,
+                     int64_t N, const int32_t *n_units_dev, int flip, float *z_out_dev, float *raw_out_dev,
+                     float *dr_out_dev, int32_t *order_out_dev, void *stream);
+
+/* Sort z only (cascade: rendering.py:218-219). */
+int mnr_sort_rows(const float *a_dev, int Sa, const float *b_dev, int Sb, int64_t N, const int32_t *n_units_dev,
+                  float *out_dev, void *stream);
+
+/* Volume compositing (rendering.py:353-393) of one ray per wavefront:
+ *   delta_k = z_{k+1}-z_k (z_k - z_{k+1} when flip), last = last_delta[ray] - (last_delta<1e10 ? zmax_sub[ray] : 0)
+ *   alpha = 1-exp(-delta*sigma); T = cumprod(1-alpha+1e-8); w = alpha * T_shifted
+ * outputs (each optional / NULL): weights [N][S], rgb [N][3], depth [N], depth_var [N], bg_lambda [N].
+ * depth uses depth_real when given (bg), depth_var always uses z (rendering.py:392). */
+typedef struct mnr_composite_io {
+    const float *z;          /* [N][S] */
+    const float *raw;        /* [N][S][4] rgb,sigma */
+    const float *depth_real; /* [N][S] or NULL */
+    const float *last_delta; /* [N] or NULL (=1e10) */
+    const float *zmax_src;   /* [N][zmax_S]: last_delta -= max_s zmax_src[ray][s] where last_delta < 1e10
+                                (rendering.py:192-193, 224-225); NULL = no subtraction */
+    int32_t zmax_S;
+    int32_t flip;
+    int64_t N;
+    const int32_t *n_units_dev;
+    int32_t S;
+    float *weights;
+    float *rgb;
+    float *depth;
+    float *depth_var;
+    float *bg_lambda;
+} mnr_composite_io;
+int mnr_composite(const mnr_composite_io *io, void *stream);
+
+/* fg/bg blend (rendering.py:102-139): for every ray, slot = bg_slot[ray]:
+ *   bg_rgb = slot>=0 ? lambda*bg_rgb_c[slot] : 0;  rgb = fg + bg_rgb  (same for depth).
+ * Optional outputs fg_/bg_ copies (get_bg_fg_rgb). In-place on rgb/depth. */
+int mnr_bg_blend(float *rgb_dev, float *depth_dev, const float *bg_lambda_dev, const int32_t *bg_slot_dev,
+                 const float *bg_rgb_c_dev, const float *bg_depth_c_dev, int64_t N, float *fg_rgb_out,
+                 float *bg_rgb_out, float *fg_depth_out, float *bg_depth_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNR_API_H */

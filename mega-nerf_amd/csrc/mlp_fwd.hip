@@ -1,0 +1,427 @@
+// mlp_fwd.hip -- fused NeRF MLP forward for gfx950 (replaces nerf.py:115-160 + the repeat/cat/
+// chunk loop of rendering.py:275-331).
+//
+// One wavefront = TILE samples x all W features, activations chained layer to layer in registers
+// (mlp_layout.h).  A workgroup is 4 wavefronts (one per SIMD, up to 512 VGPR+AGPR each); they share
+// the weight stream: 32 KiB chunks staged global -> registers -> LDS, double buffered, one barrier
+// per chunk.  Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 (k-ordered fmaf chain), so results
+// agree with the fp32 reference to GEMM-reassociation error (~1e-6 relative).
+//
+// Per-sample work: positional encoding (accurate sincosf, arguments 2^f * x formed exactly),
+// 8 trunk layers (+skip), sigma head (VALU dot + cross-lane add), xyz_encoding_final, dir/appearance
+// layer, rgb head, sigmoid / shifted softplus -- nothing but the inputs (<= 36 B) and the 16 B result
+// touches HBM.
+#include <type_traits>
+
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace mnr {
+
+int layout_from_desc(const mnr_model_desc *d, ModelLayout &m);
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int XYZ_, int LX_, int LD_, int APP_, int W_, int NL_, int SKIP_, int RGB_>
+struct MlpCfg {
+    static constexpr int XYZ = XYZ_, LX = LX_, LD = LD_, APP = APP_, W = W_, NL = NL_, SKIP = SKIP_, RGB = RGB_;
+    static constexpr int TILE = tile_for_width(W_), P = 64 / TILE;
+    static constexpr int RPB = TILE * TILE / 64;                 // accumulator registers per output block
+    static constexpr int H = hid_regs(W_, P);                    // hidden registers per lane
+    static constexpr int NOB = W_ / TILE;
+    static constexpr int EX = emb_regs(XYZ_, LX_, P);
+    static constexpr bool HAS_FINAL = (LD_ > 0 || APP_ > 0);
+    static constexpr int ED = emb_regs(3, LD_, P);
+    static constexpr int AP = app_regs(APP_, P);
+    static constexpr int NOB2 = (W_ / 2) / TILE;
+    static constexpr int H2 = HAS_FINAL ? (W_ / 2) / P : H;      // inputs of the rgb head per lane
+    static constexpr int GPC = CHUNK_F4 / (NOB * 64);
+    static constexpr int GPC2 = HAS_FINAL ? CHUNK_F4 / (NOB2 * 64) : 1;
+    static constexpr int ROWS_PER_WG = 4 * TILE;
+};
+
+struct MlpFwdArgs {
+    const float4 *chunks;
+    const float *aux;
+    const float *emb_a;
+    mnr_mlp_io io;
+    int32_t bias_off[MAX_MFMA_LAYERS];
+    int32_t sigma_off, rgb_off;
+    int32_t sigma_act, app_count;
+};
+
+// ---- weight stream: global -> VGPR (issued one chunk ahead) -> LDS ------------------------------
+struct WStream {
+    const float4 *g;     // this thread's slice of the next chunk to load
+    float4 *lds;         // base of the 2-chunk LDS ring
+    int cur;             // buffer the MFMAs currently read
+    float4 stage[CHUNK_F4 / 256];
+    __device__ __forceinline__ void issue() {
+#pragma unroll
+        for (int i = 0; i < CHUNK_F4 / 256; ++i) stage[i] = g[i * 256];
+        g += CHUNK_F4;
+    }
+    // commit the staged chunk into the idle buffer, make it current, start loading the next one
+    __device__ __forceinline__ void next_chunk() {
+        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < CHUNK_F4 / 256; ++i) dst[i * 256] = stage[i];
+        __syncthreads();
+        cur ^= 1;
+        issue();
+    }
+};
+
+// One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
+// G0 = index of the segment's first group inside the layer (chunk boundaries are static).
+template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB>
+__device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], WStream &st, int lane) {
+    static_assert(NB >= 4 * NG, "B register array too small");
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = G0 + decltype(gi)::value;
+        constexpr int gl = decltype(gi)::value;
+        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
+        const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
+        if constexpr (TILE == 32) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const float4 a = p[ob * 64];
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * gl + 0], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * gl + 1], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * gl + 2], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * gl + 3], acc[ob], 0, 0, 0);
+            }
+        } else {
+            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk all blocks per k step
+            float4 a[NOB];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) a[ob] = p[ob * 64];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[ob], 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[ob], 0, 0, 0);
+        }
+    });
+}
+
+template <int NOB, int RPB, class AccT>
+__device__ __forceinline__ void init_acc(AccT (&acc)[NOB], const float *bias_part) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int q = 0; q < RPB / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(bias_part + ob * RPB + 4 * q);
+            acc[ob][4 * q + 0] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
+        }
+    }
+}
+
+template <int NOB, int RPB, bool RELU, class AccT, int NH>
+__device__ __forceinline__ void acc_to_regs(float (&h)[NH], const AccT (&acc)[NOB]) {
+    static_assert(NH >= NOB * RPB, "register array too small");
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) h[ob * RPB + r] = RELU ? fmaxf(acc[ob][r], 0.f) : acc[ob][r];
+}
+
+// Positional encoding of D coordinates into this lane's registers (layout: mlp_layout.h emb_src).
+template <int D, int L, int P, int NE>
+__device__ __forceinline__ void embed(float (&e)[NE], const float (&x)[D], int part) {
+    constexpr int NP = emb_pairs(D, L, P);
+    static_assert(NE == emb_regs(D, L, P), "embedding register count");
+    float xs[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xs[d] = ldexpf(x[d], part * (L / P));     // exact: power-of-two scale
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float arg = xs[i % D] * (float)(1 << (i / D));              // == fl(2^f * x), nerf.py:22-23
+        float s, c;
+        sincosf(arg, &s, &c);
+        e[2 * i] = s;
+        e[2 * i + 1] = c;
+    }
+#pragma unroll
+    for (int j = 2 * NP; j < NE; ++j) {
+        const int dim = (j - 2 * NP) * P + part;
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) v = (dim == d && (j - 2 * NP) < cdiv(D, P)) ? x[d] : v;
+        e[j] = v;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ float reduce_parts(float v) {
+    v += __shfl_xor(v, 32);
+    if constexpr (P == 4) v += __shfl_xor(v, 16);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_shifted(float x) {   // F.softplus(x - 1, beta=1, threshold=20), nerf.py:38
+    const float y = x - 1.f;
+    return y > 20.f ? y : log1pf(expf(y));
+}
+
+// spherical_harmonics.py:55-107 (deg <= 4), coefficients c[k] for one colour channel
+__device__ __forceinline__ float eval_sh_channel(int deg, const float *c, float x, float y, float z) {
+    float r = 0.28209479177387814f * c[0];
+    if (deg > 0) {
+        r = r - 0.4886025119029199f * y * c[1] + 0.4886025119029199f * z * c[2] - 0.4886025119029199f * x * c[3];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            r = r + 1.0925484305920792f * xy * c[4] + -1.0925484305920792f * yz * c[5] +
+                0.31539156525252005f * (2.0f * zz - xx - yy) * c[6] + -1.0925484305920792f * xz * c[7] +
+                0.5462742152960396f * (xx - yy) * c[8];
+            if (deg > 2) {
+                r = r + -0.5900435899266435f * y * (3 * xx - yy) * c[9] + 2.890611442640554f * xy * z * c[10] +
+                    -0.4570457994644658f * y * (4 * zz - xx - yy) * c[11] +
+                    0.3731763325901154f * z * (2 * zz - 3 * xx - 3 * yy) * c[12] +
+                    -0.4570457994644658f * x * (4 * zz - xx - yy) * c[13] + 1.445305721320277f * z * (xx - yy) * c[14] +
+                    -0.5900435899266435f * x * (xx - 3 * yy) * c[15];
+                if (deg > 3) {
+                    r = r + 2.5033429417967046f * xy * (xx - yy) * c[16] + -1.7701307697799304f * yz * (3 * xx - yy) * c[17] +
+                        0.9461746957575601f * xy * (7 * zz - 1) * c[18] + -0.6690465435572892f * yz * (7 * zz - 3) * c[19] +
+                        0.10578554691520431f * (zz * (35 * zz - 30) + 3) * c[20] +
+                        -0.6690465435572892f * xz * (7 * zz - 3) * c[21] + 0.47308734787878004f * (xx - yy) * (7 * zz - 1) * c[22] +
+                        -1.7701307697799304f * xz * (xx - 3 * yy) * c[23] +
+                        0.6258357354491761f * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)) * c[24];
+                }
+            }
+        }
+    }
+    return r;
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd(MlpFwdArgs a) {
+    constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
+    using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
+    extern __shared__ float4 lds_ring[];
+
+    const mnr_mlp_io &io = a.io;
+    const long n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
+    if ((long)blockIdx.x * C::ROWS_PER_WG >= n_rows) return;   // uniform per workgroup
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane / TILE;
+    const long row = ((long)blockIdx.x * 4 + wave) * TILE + (lane % TILE);
+    const bool valid = row < n_rows;
+    const long rc = valid ? row : n_rows - 1;
+    const long ray = rc / io.rows_per_ray;
+
+    WStream st;
+    st.g = a.chunks + threadIdx.x;
+    st.lds = lds_ring;
+    st.cur = 1;
+    st.issue();                                   // chunk 0 in flight while we encode
+
+    float x[C::XYZ];
+#pragma unroll
+    for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[rc * io.xyz_stride + d];
+    float ex[C::EX];
+    embed<C::XYZ, C::LX, P>(ex, x, part);
+
+    float h[H];
+    AccT acc[NOB];
+    int li = 0;   // MFMA layer counter (compile-time after unrolling)
+
+    // ---- trunk: nerf.py:127-130 ------------------------------------------------------------------
+    static_for<0, C::NL>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        init_acc<NOB, RPB>(acc, a.aux + a.bias_off[l] + part * H);
+        st.next_chunk();
+        if constexpr (l == 0) {
+            run_segment<TILE, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane);
+        } else if constexpr ((C::SKIP >> l) & 1) {
+            run_segment<TILE, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane);
+            run_segment<TILE, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane);
+        } else {
+            run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
+        }
+        acc_to_regs<NOB, RPB, true>(h, acc);
+    });
+    li = C::NL;
+
+    // ---- sigma head: nerf.py:132-136 -------------------------------------------------------------
+    float sigma;
+    {
+        const float *ws = a.aux + a.sigma_off;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(ws + part * H + 4 * q);
+            s = fmaf(h[4 * q + 0], w4.x, s); s = fmaf(h[4 * q + 1], w4.y, s);
+            s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
+        }
+        s = reduce_parts<P>(s) + ws[P * H];
+        if (io.sigma_noise) s += io.sigma_noise[rc];
+        sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
+    }
+    if (io.sigma_only) {
+        if (valid && part == 0) io.out[row * io.out_stride] = sigma;
+        return;
+    }
+
+    // ---- colour branch: nerf.py:141-152 ----------------------------------------------------------
+    float rgbraw[C::RGB];
+    const float *wr = a.aux + a.rgb_off;
+    if constexpr (C::HAS_FINAL) {
+        init_acc<NOB, RPB>(acc, a.aux + a.bias_off[li] + part * H);
+        st.next_chunk();
+        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
+        acc_to_regs<NOB, RPB, false>(h, acc);                    // xyz_encoding_final: no activation
+        ++li;
+
+        constexpr int NOB2 = C::NOB2, H2 = C::H2;
+        AccT acc2[NOB2];
+        init_acc<NOB2, RPB>(acc2, a.aux + a.bias_off[li] + part * H2);
+        st.next_chunk();
+        run_segment<TILE, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane);
+        if constexpr (C::ED > 0) {
+            float dv[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
+            float ed[C::ED];
+            embed<3, C::LD, P>(ed, dv, part);
+            run_segment<TILE, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane);
+        }
+        if constexpr (C::AP > 0) {
+            long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
+                                       : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
+            idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);   // reference would raise; stay in bounds
+            const float *ea = a.emb_a + idx * C::APP + part * (C::APP / P);
+            float ap[C::AP];
+#pragma unroll
+            for (int i = 0; i < C::AP; ++i) ap[i] = (i < C::APP / P) ? ea[i] : 0.f;
+            run_segment<TILE, NOB2, C::AP / 4, C::GPC2, H / 4 + C::ED / 4>(acc2, ap, st, lane);
+        }
+        float dreg[H2];
+        acc_to_regs<NOB2, RPB, true>(dreg, acc2);
+#pragma unroll
+        for (int c = 0; c < C::RGB; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < H2 / 4; ++q) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H2 + 4 * q);
+                s = fmaf(dreg[4 * q + 0], w4.x, s); s = fmaf(dreg[4 * q + 1], w4.y, s);
+                s = fmaf(dreg[4 * q + 2], w4.z, s); s = fmaf(dreg[4 * q + 3], w4.w, s);
+            }
+            rgbraw[c] = reduce_parts<P>(s) + wr[C::RGB * P * H2 + c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C::RGB; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H + 4 * q);
+                s = fmaf(h[4 * q + 0], w4.x, s); s = fmaf(h[4 * q + 1], w4.y, s);
+                s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
+            }
+            rgbraw[c] = reduce_parts<P>(s) + wr[C::RGB * P * H + c];
+        }
+    }
+
+    if (!(valid && part == 0)) return;
+    float *o = io.out + row * io.out_stride;
+    if constexpr (C::RGB == 3) {
+        o[0] = sigmoidf_(rgbraw[0]); o[1] = sigmoidf_(rgbraw[1]); o[2] = sigmoidf_(rgbraw[2]); o[3] = sigma;
+    } else {
+        if (io.apply_sh_deg >= 0) {
+            constexpr int NB = C::RGB / 3;
+            const float dx = io.dir[ray * io.dir_stride], dy = io.dir[ray * io.dir_stride + 1],
+                        dz = io.dir[ray * io.dir_stride + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = sigmoidf_(eval_sh_channel(io.apply_sh_deg, rgbraw + c * NB, dx, dy, dz));
+            o[3] = sigma;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C::RGB; ++c) o[c] = rgbraw[c];
+            o[C::RGB] = sigma;
+        }
+    }
+}
+
+template <class C>
+static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
+                      hipStream_t stream) {
+    // the template's static structure must agree with the runtime layout the packer used
+    if (m.tile != C::TILE || m.layer[0].nsteps != C::EX || m.layer[0].gpc != C::GPC || m.has_final != (int)C::HAS_FINAL ||
+        m.rgb_in_regs != C::H2 || m.n_mfma_layers != C::NL + (C::HAS_FINAL ? 2 : 0))
+        return set_err(MNR_E_INVALID, "internal: kernel template / layout mismatch");
+    if (C::HAS_FINAL && m.layer[C::NL + 1].nsteps != C::H + C::ED + C::AP)
+        return set_err(MNR_E_INVALID, "internal: dir_a layer layout mismatch");
+    MlpFwdArgs a;
+    a.chunks = reinterpret_cast<const float4 *>(packed);
+    a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) + (size_t)m.total_chunks * CHUNK_BYTES);
+    a.emb_a = d->embedding_a;
+    a.io = *io;
+    for (int i = 0; i < MAX_MFMA_LAYERS; ++i) a.bias_off[i] = i < m.n_mfma_layers ? m.layer[i].bias_off : 0;
+    a.sigma_off = m.sigma_off;
+    a.rgb_off = m.rgb_off;
+    a.sigma_act = d->sigma_activation;
+    a.app_count = d->appearance_count;
+    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+    if (nwg <= 0) return MNR_OK;
+    hipLaunchKernelGGL(k_mlp_fwd<C>, dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
+    return check_launch("k_mlp_fwd");
+}
+
+}  // namespace mnr
+
+using namespace mnr;
+
+extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream) {
+    ModelLayout m;
+    int rc = layout_from_desc(d, m);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(packed_dev && io && io->xyz && io->out, "NULL pointer argument");
+    MNR_REQUIRE(io->rows_per_ray >= 1, "rows_per_ray must be >= 1");
+    MNR_REQUIRE(io->n_rows >= 0, "negative n_rows");
+    const bool need_dir = d->pos_dir_dim > 0 || (d->rgb_dim > 3 && io->apply_sh_deg >= 0 && !io->sigma_only);
+    MNR_REQUIRE(!need_dir || io->dir, "dir pointer required");
+    MNR_REQUIRE(d->appearance_dim == 0 || io->sigma_only || (io->idx && d->embedding_a), "idx / embedding_a required");
+    if (io->apply_sh_deg >= 0) MNR_REQUIRE(3 * (io->apply_sh_deg + 1) * (io->apply_sh_deg + 1) == d->rgb_dim,
+                                           "apply_sh_deg does not match rgb_dim");
+    hipStream_t s = as_stream(stream);
+#define MNR_TRY(XYZ, LX, LD, APP, W, NL, SKIP, RGB)                                                            \
+    if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
+        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB)                     \
+        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB>>(m, packed_dev, d, io, s);
+    // configs/mega-nerf/*.yaml (opts.py defaults): fg / bg
+    MNR_TRY(3, 12, 4, 48, 256, 8, 16, 3)
+    MNR_TRY(4, 12, 4, 48, 256, 8, 16, 3)
+#ifdef MNR_ALL_VARIANTS
+    // configs/mega-nerf-sh-3 (sh_deg 2, pos_dir_dim 0)
+    MNR_TRY(3, 12, 0, 48, 256, 8, 16, 27)
+    MNR_TRY(4, 12, 0, 48, 256, 8, 16, 27)
+    // small-width models used by the cascade tests
+    MNR_TRY(3, 12, 4, 0, 64, 8, 16, 3)
+    MNR_TRY(3, 12, 4, 48, 64, 8, 16, 3)
+    MNR_TRY(4, 12, 4, 48, 64, 8, 16, 3)
+    // appearance_dim 0 (configs/mega-nerf-no-embed, configs/npp)
+    MNR_TRY(3, 12, 4, 0, 256, 8, 16, 3)
+    MNR_TRY(4, 12, 4, 0, 256, 8, 16, 3)
+#endif
+#undef MNR_TRY
+    return set_err(MNR_E_UNSUPPORTED,
+                   "no fused MLP kernel for xyz_dim=%d pos_xyz_dim=%d pos_dir_dim=%d appearance_dim=%d layer_dim=%d "
+                   "layers=%d skip_mask=%d rgb_dim=%d",
+                   d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->appearance_dim, d->layer_dim, d->layers,
+                   d->skip_mask, d->rgb_dim);
+}

@@ -1,0 +1,143 @@
+"""ctypes binding of libmeganerf_hip.so (C ABI declared in include/mnr_api.h).
+
+The product path has NO fallback: if the library is missing or no HIP device is present, every
+kernel entry raises.  Only raw pointers, sizes and the current HIP stream cross this boundary --
+torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get('MNR_LIB', _HERE.parent / 'lib' / 'libmeganerf_hip.so'))
+
+MNR_MAX_LAYERS = 16
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    """struct mnr_model_desc"""
+    _fields_ = [
+        ('xyz_dim', C.c_int32), ('pos_xyz_dim', C.c_int32), ('pos_dir_dim', C.c_int32), ('layers', C.c_int32),
+        ('skip_mask', C.c_int32), ('layer_dim', C.c_int32), ('appearance_dim', C.c_int32),
+        ('appearance_count', C.c_int32), ('rgb_dim', C.c_int32), ('sigma_activation', C.c_int32),
+        ('layer_w', C.c_void_p * MNR_MAX_LAYERS), ('layer_b', C.c_void_p * MNR_MAX_LAYERS),
+        ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('dir_a_w', C.c_void_p), ('dir_a_b', C.c_void_p),
+        ('sigma_w', C.c_void_p), ('sigma_b', C.c_void_p), ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p),
+        ('embedding_a', C.c_void_p),
+    ]
+
+
+class MlpIO(C.Structure):
+    """struct mnr_mlp_io"""
+    _fields_ = [
+        ('xyz', C.c_void_p), ('xyz_stride', C.c_int64),
+        ('dir', C.c_void_p), ('dir_stride', C.c_int64),
+        ('idx', C.c_void_p), ('idx_stride', C.c_int64),
+        ('idx_is_float', C.c_int32), ('rows_per_ray', C.c_int32),
+        ('sigma_noise', C.c_void_p),
+        ('out', C.c_void_p), ('out_stride', C.c_int64),
+        ('n_rows', C.c_int64),
+        ('n_units_dev', C.c_void_p), ('rows_per_unit', C.c_int32),
+        ('sigma_only', C.c_int32), ('apply_sh_deg', C.c_int32),
+    ]
+
+
+class CompositeIO(C.Structure):
+    """struct mnr_composite_io"""
+    _fields_ = [
+        ('z', C.c_void_p), ('raw', C.c_void_p), ('depth_real', C.c_void_p), ('last_delta', C.c_void_p),
+        ('zmax_src', C.c_void_p), ('zmax_S', C.c_int32), ('flip', C.c_int32), ('N', C.c_int64),
+        ('n_units_dev', C.c_void_p), ('S', C.c_int32),
+        ('weights', C.c_void_p), ('rgb', C.c_void_p), ('depth', C.c_void_p), ('depth_var', C.c_void_p),
+        ('bg_lambda', C.c_void_p),
+    ]
+
+
+EXPORTS = [
+    'mnr_version', 'mnr_last_error', 'mnr_device_available', 'mnr_ray_directions', 'mnr_get_rays',
+    'mnr_packed_model_bytes', 'mnr_pack_model', 'mnr_layout_src_col', 'mnr_layout_num_steps', 'mnr_layout_parts',
+    'mnr_mlp_forward', 'mnr_ray_setup', 'mnr_fg_samples', 'mnr_fg_points', 'mnr_bg_samples', 'mnr_sample_pdf',
+    'mnr_sample_fine', 'mnr_merge_sorted', 'mnr_sort_rows', 'mnr_composite', 'mnr_bg_blend',
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeError('libmeganerf_hip.so not found at {} -- run `python __graft_entry__.py` (build()) '
+                              'or `make -C mega-nerf_amd/csrc`; there is no CPU fallback'.format(LIB_PATH))
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.mnr_last_error.restype = C.c_char_p
+        _lib.mnr_packed_model_bytes.restype = C.c_size_t
+        _lib.mnr_packed_model_bytes.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_pack_model.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
+        _lib.mnr_layout_src_col.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]
+        _lib.mnr_layout_num_steps.argtypes = [C.POINTER(ModelDesc), C.c_int]
+        _lib.mnr_layout_parts.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_mlp_forward.argtypes = [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(MlpIO), C.c_void_p]
+        _lib.mnr_ray_directions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.c_int, C.c_void_p]
+        _lib.mnr_get_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                      C.c_float, c_float_p, C.c_void_p]
+        _lib.mnr_ray_setup.argtypes = [C.c_void_p, C.c_int64, c_float_p, c_float_p] + [C.c_void_p] * 7
+        _lib.mnr_fg_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_fg_points.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_bg_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_float,
+                                        C.c_void_p, C.c_void_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_sample_pdf.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_sample_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_merge_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_sort_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        _lib.mnr_composite.argtypes = [C.POINTER(CompositeIO), C.c_void_p]
+        _lib.mnr_bg_blend.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 5
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise NativeError('libmeganerf_hip: {} (code {})'.format(lib().mnr_last_error().decode(), rc))
+
+
+def require_device(t: torch.Tensor, name: str = 'tensor') -> None:
+    if not t.is_cuda:
+        raise NativeError('{} must live on the HIP device (got {}); the MI355X kernels have no CPU fallback'.format(
+            name, t.device))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def host3(v) -> Optional[C.Array]:
+    """3 host floats (sphere centre / radius) as a ctypes array; accepts tensors, lists, None."""
+    if v is None:
+        return None
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().tolist()
+    return (C.c_float * 3)(*[float(x) for x in v])

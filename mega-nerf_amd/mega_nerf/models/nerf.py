@@ -1,0 +1,164 @@
+"""NeRF MLP module -- API/state_dict-compatible with the reference (mega_nerf/models/nerf.py:45-160)
+but evaluated by the fused gfx950 kernel (csrc/mlp_fwd.hip) through the C ABI.
+
+Parameter names (``xyz_encodings.{i}.0.*``, ``embedding_a.weight``, ``xyz_encoding_final.*``,
+``dir_a_encoding.0.*``, ``sigma.*``, ``rgb.*``) are those of the reference checkpoints
+(runner.py:521-536), so ``load_state_dict`` of a reference checkpoint works unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from mega_nerf import _native as N
+
+
+class ShiftedSoftplus(nn.Module):
+    """softplus(x - 1) (reference nerf.py:28-39); selects sigma_activation = 1 in the kernel."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # only used by host-side tooling
+        return torch.nn.functional.softplus(x - 1, 1, 20)
+
+
+def _linear_act(fin: int, fout: int) -> nn.Sequential:
+    # the Sequential wrapper only exists to reproduce the checkpoint key "<name>.0.weight"
+    return nn.Sequential(nn.Linear(fin, fout), nn.ReLU(True))
+
+
+class NeRF(nn.Module):
+    def __init__(self, pos_xyz_dim: int, pos_dir_dim: int, layers: int, skip_layers: List[int], layer_dim: int,
+                 appearance_dim: int, affine_appearance: bool, appearance_count: int, rgb_dim: int, xyz_dim: int,
+                 sigma_activation: nn.Module):
+        super().__init__()
+        if rgb_dim > 3:
+            assert pos_dir_dim == 0
+        self.xyz_dim, self.pos_xyz_dim, self.pos_dir_dim = xyz_dim, pos_xyz_dim, pos_dir_dim
+        self.layers, self.skip_layers, self.layer_dim = layers, list(skip_layers), layer_dim
+        self.appearance_dim, self.appearance_count, self.rgb_dim = appearance_dim, appearance_count, rgb_dim
+        in_xyz = xyz_dim * (1 + 2 * pos_xyz_dim)
+        in_dir = 3 * (1 + 2 * pos_dir_dim) if pos_dir_dim > 0 else 0
+        self.xyz_encodings = nn.ModuleList(
+            _linear_act(in_xyz if i == 0 else layer_dim + (in_xyz if i in self.skip_layers else 0), layer_dim)
+            for i in range(layers))
+        self.embedding_a = nn.Embedding(appearance_count, appearance_dim) if appearance_dim > 0 else None
+        if affine_appearance:
+            assert appearance_dim > 0
+            self.affine = nn.Linear(appearance_dim, 12)
+        else:
+            self.affine = None
+        self.has_dir = pos_dir_dim > 0
+        self.has_final = self.has_dir or (appearance_dim > 0 and not affine_appearance)
+        if self.has_final:
+            self.xyz_encoding_final = nn.Linear(layer_dim, layer_dim)
+            self.dir_a_encoding = _linear_act(
+                layer_dim + in_dir + (appearance_dim if not affine_appearance else 0), layer_dim // 2)
+        else:
+            self.xyz_encoding_final = None
+        self.sigma = nn.Linear(layer_dim, 1)
+        self.sigma_activation = sigma_activation
+        self.rgb = nn.Linear(layer_dim // 2 if self.has_final else layer_dim, rgb_dim)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+
+    # ---- native plumbing ---------------------------------------------------------------------
+    def _all_params(self):
+        return [p for p in self.parameters()]
+
+    def model_desc(self) -> N.ModelDesc:
+        if self.affine is not None:
+            raise NotImplementedError('affine_appearance is not supported by the fused MI355X kernels')
+        d = N.ModelDesc()
+        d.xyz_dim, d.pos_xyz_dim, d.pos_dir_dim, d.layers = self.xyz_dim, self.pos_xyz_dim, self.pos_dir_dim, self.layers
+        d.skip_mask = sum(1 << i for i in self.skip_layers)
+        d.layer_dim, d.appearance_dim = self.layer_dim, self.appearance_dim
+        d.appearance_count, d.rgb_dim = self.appearance_count, self.rgb_dim
+        d.sigma_activation = 1 if isinstance(self.sigma_activation, ShiftedSoftplus) else 0
+        for i, enc in enumerate(self.xyz_encodings):
+            d.layer_w[i], d.layer_b[i] = enc[0].weight.data_ptr(), enc[0].bias.data_ptr()
+        if self.has_final:
+            d.final_w, d.final_b = self.xyz_encoding_final.weight.data_ptr(), self.xyz_encoding_final.bias.data_ptr()
+            d.dir_a_w, d.dir_a_b = self.dir_a_encoding[0].weight.data_ptr(), self.dir_a_encoding[0].bias.data_ptr()
+        d.sigma_w, d.sigma_b = self.sigma.weight.data_ptr(), self.sigma.bias.data_ptr()
+        d.rgb_w, d.rgb_b = self.rgb.weight.data_ptr(), self.rgb.bias.data_ptr()
+        if self.embedding_a is not None:
+            d.embedding_a = self.embedding_a.weight.data_ptr()
+        return d
+
+    def packed(self):
+        """(desc, packed device buffer); re-packs when any parameter storage/version changed."""
+        params = self._all_params()
+        for p in params:
+            N.require_device(p, 'NeRF parameter')
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise N.NativeError('NeRF parameters must be contiguous float32')
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        desc = self.model_desc()
+        if self._packed is None or key != self._packed_key:
+            nbytes = N.lib().mnr_packed_model_bytes(C.byref(desc))
+            if nbytes == 0:
+                raise N.NativeError(N.lib().mnr_last_error().decode())
+            if self._packed is None or self._packed.numel() != nbytes or self._packed.device != params[0].device:
+                self._packed = torch.empty(nbytes, dtype=torch.uint8, device=params[0].device)
+            N.check(N.lib().mnr_pack_model(self._packed.data_ptr(), nbytes, C.byref(desc), N.stream_ptr()))
+            self._packed_key = key
+        return desc, self._packed
+
+    def evaluate(self, xyz: torch.Tensor, xyz_stride: int, dirs: Optional[torch.Tensor], dir_stride: int,
+                 idx: Optional[torch.Tensor], idx_stride: int, rows_per_ray: int, n_rows: int, out: torch.Tensor,
+                 sigma_noise: Optional[torch.Tensor] = None, sigma_only: bool = False, apply_sh_deg: int = -1,
+                 n_units_dev: Optional[torch.Tensor] = None, rows_per_unit: int = 0) -> torch.Tensor:
+        """Enqueue one fused MLP launch on the current stream (no host sync).  All tensors are raw device
+        buffers; see ``mnr_mlp_io`` in include/mnr_api.h for the row/ray addressing."""
+        desc, packed = self.packed()
+        io = N.MlpIO()
+        io.xyz, io.xyz_stride = xyz.data_ptr(), xyz_stride
+        io.dir, io.dir_stride = (dirs.data_ptr() if dirs is not None else None), dir_stride
+        if idx is not None:
+            if idx.dtype == torch.float32:
+                io.idx_is_float = 1
+            elif idx.dtype == torch.int32:
+                io.idx_is_float = 0
+            else:
+                raise N.NativeError('image indices must be float32 or int32 (got {})'.format(idx.dtype))
+            io.idx, io.idx_stride = idx.data_ptr(), idx_stride
+        io.rows_per_ray = rows_per_ray
+        io.sigma_noise = sigma_noise.data_ptr() if sigma_noise is not None else None
+        io.out, io.out_stride = out.data_ptr(), out.stride(0) if out.dim() > 1 else 1
+        io.n_rows = n_rows
+        io.n_units_dev = n_units_dev.data_ptr() if n_units_dev is not None else None
+        io.rows_per_unit = rows_per_unit
+        io.sigma_only = 1 if sigma_only else 0
+        io.apply_sh_deg = apply_sh_deg
+        N.check(N.lib().mnr_mlp_forward(packed.data_ptr(), C.byref(desc), C.byref(io), N.stream_ptr()))
+        return out
+
+    # ---- reference API -----------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, sigma_only: bool = False,
+                sigma_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        expected = self.xyz_dim + (0 if (sigma_only or not self.has_dir) else 3) \
+            + (0 if (sigma_only or self.embedding_a is None) else 1)
+        if x.shape[1] != expected:
+            raise Exception(
+                'Unexpected input shape: {} (expected: {}, xyz_dim: {})'.format(x.shape, expected, self.xyz_dim))
+        N.require_device(x, 'x')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from mega_nerf.autograd import mlp_forward_with_grad
+            return mlp_forward_with_grad(self, x, sigma_only, sigma_noise)
+        x = x.contiguous().float()
+        B, ncol = x.shape
+        out_cols = 1 if sigma_only else self.rgb_dim + 1
+        out = torch.empty(B, out_cols, device=x.device, dtype=torch.float32)
+        if B == 0:
+            return out
+        dirs = idx = None
+        if not sigma_only:
+            if self.has_dir:
+                dirs = x[:, ncol - 4:] if ncol >= 4 else None    # x[:, -4:-1] (nerf.py:146, quirk Q8)
+            if self.embedding_a is not None:
+                idx = x[:, ncol - 1:]
+        noise = sigma_noise.contiguous().float().view(-1) if sigma_noise is not None else None
+        self.evaluate(x, ncol, dirs, ncol, idx, ncol, 1, B, out, noise, sigma_only)
+        return out

@@ -1,0 +1,352 @@
+"""render_rays -- drop-in for the reference ``mega_nerf.rendering.render_rays`` (rendering.py:15-173)
+running entirely on MI355X kernels (csrc/render.hip, csrc/mlp_fwd.hip) through the C ABI.
+
+Host code here only sequences kernel launches on the current HIP stream and owns the (torch-allocated)
+device buffers; there is no data-dependent host synchronisation until the very end of
+:func:`render_rays`, where the reference API forces one (it returns a Python bool and raises when a
+camera lies outside the bounding ellipsoid).  :func:`render_rays_async` is the sync-free form used by
+the trainer / benchmark.
+
+Random numbers (training) are drawn with torch on the device in the reference's draw order and can be
+injected (``_randoms``) so that train-mode parity is testable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from argparse import Namespace
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from mega_nerf import _native as N
+
+_ERR_TEXT = ('Not all your cameras are bounded by the unit sphere; please make sure the cameras are normalized '
+             'properly!')
+
+_tables: Dict[Tuple[int, str], torch.Tensor] = {}
+_host_cache: Dict[Tuple[int, int], list] = {}
+
+
+def linspace01(n: int, device: torch.device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) evaluated by the CPU kernel (the parity target: rendering.py:47,82,511),
+    cached on the device.  The device-side linspace kernel differs by 1 ulp in places."""
+    key = (n, str(device))
+    t = _tables.get(key)
+    if t is None:
+        t = torch.linspace(0, 1, n, device='cpu').to(device)
+        _tables[key] = t
+    return t
+
+
+def _host_vec(v) -> Optional[list]:
+    """Host copy of a small device tensor (sphere centre/radius), cached so steady-state calls do not sync."""
+    if v is None:
+        return None
+    if not isinstance(v, torch.Tensor):
+        return [float(x) for x in v]
+    key = (v.data_ptr(), v._version)
+    h = _host_cache.get(key)
+    if h is None:
+        if len(_host_cache) > 64:
+            _host_cache.clear()
+        h = v.detach().float().cpu().tolist()
+        _host_cache[key] = h
+    return h
+
+
+def _f(*shape, device):
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
+class _Part:
+    """Per-branch (foreground / background) geometry handed to :func:`_get_results`."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _model_eval(nerf: nn.Module, typ: str, hparams: Namespace, xyz: torch.Tensor, part: _Part, S: int,
+                noise: Optional[torch.Tensor]) -> torch.Tensor:
+    """The MLP pass of _inference (rendering.py:275-331) for n x S samples -> raw [n, S, 4]."""
+    from mega_nerf.models.cascade import Cascade
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    n = xyz.shape[0]
+    out = _f(n, S, 4, device=xyz.device)
+    model = nerf
+    if isinstance(model, Cascade):
+        model = model.coarse if typ == 'coarse' else model.fine
+    sh_deg = hparams.sh_deg if (hparams.pos_dir_dim == 0 and hparams.sh_deg is not None) else -1
+    if isinstance(model, MegaNeRF):
+        model.evaluate_routed(xyz, part, S, out, noise, sh_deg)
+        return out
+    need_dir = model.has_dir or sh_deg >= 0
+    if model.has_dir and model.embedding_a is None:
+        # quirk Q8 (nerf.py:146): without an appearance column the encoded "direction" is
+        # [last xyz coordinate, d_x, d_y]; materialise that 3-vector per sample.
+        d = part.dirs.view(n, 1, 3).expand(n, S, 3)
+        q = torch.cat([xyz[..., -1:], d[..., :2]], -1).contiguous()
+        model.evaluate(xyz, xyz.shape[-1], q, 3, None, 0, 1, n * S, out.view(-1, 4), noise, False, sh_deg,
+                       part.n_units, S)
+        return out
+    model.evaluate(xyz, xyz.shape[-1], part.dirs if need_dir else None, part.dirs.stride(0) if need_dir else 0,
+                   part.idx, 1, S, n * S, out.view(-1, 4), noise, False, sh_deg, part.n_units, S)
+    return out
+
+
+def _composite(z, raw, n, S, part: _Part, last_delta, zmax_src, flip, depth_real, want, device):
+    io = N.CompositeIO()
+    io.z, io.raw = z.data_ptr(), raw.data_ptr()
+    io.depth_real = depth_real.data_ptr() if depth_real is not None else None
+    io.last_delta = last_delta.data_ptr() if last_delta is not None else None
+    if zmax_src is not None and last_delta is not None:
+        io.zmax_src, io.zmax_S = zmax_src.data_ptr(), zmax_src.shape[1]
+    io.flip, io.N, io.S = int(flip), n, S
+    io.n_units_dev = part.n_units.data_ptr() if part.n_units is not None else None
+    out = {}
+    for k, shape in (('weights', (n, S)), ('rgb', (n, 3)), ('depth', (n,)), ('depth_var', (n,)), ('bg_lambda', (n,))):
+        if k in want:
+            out[k] = _f(*shape, device=device)
+            setattr(io, k, out[k].data_ptr())
+    N.check(N.lib().mnr_composite(C.byref(io), N.stream_ptr()))
+    return out
+
+
+def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bool, get_depth_variance: bool,
+                 get_bg_lambda: bool, flip: bool, rnd: dict, tag: str) -> Dict[str, torch.Tensor]:
+    """rendering.py:176-248 for one branch.  ``part`` carries z_coarse [n,Sc], xyz_coarse, depth_real, last_delta."""
+    lib, st = N.lib(), N.stream_ptr()
+    dev = part.z.device
+    n, Sc = part.z.shape
+    Nf = hparams.fine_samples
+    cascade = hparams.use_cascade
+    results: Dict[str, torch.Tensor] = {}
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+
+    # ---- coarse pass (rendering.py:195-210) ----
+    xyz_c, z_c = part.xyz, part.z
+    if flip:                                   # :271-273 (depth_real is *not* flipped: quirk Q2)
+        xyz_c, z_c = xyz_c.flip(1).contiguous(), z_c.flip(1).contiguous()
+    noise_c = rnd.get(tag + '_noise_coarse') if nerf.training else None
+    if nerf.training and noise_c is None:
+        noise_c = torch.rand(n * Sc, device=dev)
+    raw_c = _model_eval(nerf, 'coarse', hparams, xyz_c, part, Sc, noise_c)
+    want = set()
+    if Nf > 0:
+        want.add('weights')
+    if cascade:
+        want.add('rgb')
+        if get_bg_lambda:
+            want.add('bg_lambda')
+    if Nf == 0 and (get_depth or get_depth_variance):
+        want.add('depth')
+        if get_depth_variance:
+            want.add('depth_var')
+    comp = _composite(z_c, raw_c, n, Sc, part, part.last_delta, part.z, flip, part.depth_real, want, dev)
+    if cascade:
+        results['rgb_coarse'] = comp['rgb']
+        if get_bg_lambda:
+            results['bg_lambda_coarse'] = comp['bg_lambda']
+    else:
+        results['zvals_coarse'] = z_c
+        results['raw_rgb_coarse'] = raw_c[..., :3]
+        results['raw_sigma_coarse'] = raw_c[..., 3]
+        if part.depth_real is not None:
+            results['depth_real_coarse'] = part.depth_real
+    if Nf == 0:
+        if get_depth:
+            results['depth_coarse'] = comp['depth']
+        if get_depth_variance:
+            results['depth_variance_coarse'] = comp['depth_var']
+        return results
+
+    # ---- importance sampling (rendering.py:212-219) ----
+    nf = Nf // 2 if flip else Nf
+    det = (hparams.perturb if nerf.training else 0) == 0
+    if det:
+        u = linspace01(nf, dev)
+    else:
+        u = rnd.get(tag + '_u')
+        if u is None:
+            u = torch.rand(n, nf, device=dev)
+    z_f = _f(n, nf, device=dev)
+    inds = torch.empty(n, nf, device=dev, dtype=torch.int32) if rnd.get('_want_inds') else None
+    N.check(lib.mnr_sample_fine(part.z.data_ptr(), comp['weights'].data_ptr(), n, nunits, Sc, nf, int(det),
+                                u.data_ptr(), z_f.data_ptr(), N.ptr(inds), st))
+    if inds is not None:
+        rnd['_inds_' + tag] = inds
+        rnd['_fine_z_' + tag] = z_f
+    zmax_src = z_f                                           # last_delta uses the fine-only max (quirk Q4)
+    if cascade:
+        z_all = _f(n, Sc + nf, device=dev)
+        N.check(lib.mnr_sort_rows(part.z.data_ptr(), Sc, z_f.data_ptr(), nf, n, nunits, z_all.data_ptr(), st))
+        z_f, nf = z_all, Sc + nf
+        zmax_src = z_f
+    xyz_f, depth_real_f = part.points(z_f)
+
+    # ---- fine pass (rendering.py:227-242) ----
+    if flip and cascade:                                     # 'zvals_coarse' absent -> flip again (:271-273)
+        xyz_f, z_f = xyz_f.flip(1).contiguous(), z_f.flip(1).contiguous()
+    noise_f = rnd.get(tag + '_noise_fine') if nerf.training else None
+    if nerf.training and noise_f is None:
+        noise_f = torch.rand(n * nf, device=dev)
+    raw_f = _model_eval(nerf, 'fine', hparams, xyz_f, part, nf, noise_f)
+    if cascade:
+        z_m, raw_m, dr_m, Sm = z_f, raw_f, depth_real_f, nf
+    else:
+        Sm = nf + Sc
+        z_m, raw_m = _f(n, Sm, device=dev), _f(n, Sm, 4, device=dev)
+        dr_m = _f(n, Sm, device=dev) if depth_real_f is not None else None
+        N.check(lib.mnr_merge_sorted(z_f.data_ptr(), raw_f.data_ptr(), N.ptr(depth_real_f), nf, z_c.data_ptr(),
+                                     raw_c.data_ptr(), N.ptr(part.depth_real), Sc, n, nunits, int(flip),
+                                     z_m.data_ptr(), raw_m.data_ptr(), N.ptr(dr_m), None, st))
+    want = {'rgb'}
+    if get_bg_lambda:
+        want.add('bg_lambda')
+    if get_depth or get_depth_variance:
+        want.add('depth')
+    if get_depth_variance:
+        want.add('depth_var')
+    comp = _composite(z_m, raw_m, n, Sm, part, part.last_delta, zmax_src, flip, dr_m, want, dev)
+    results['rgb_fine'] = comp['rgb']
+    if get_bg_lambda:
+        results['bg_lambda_fine'] = comp['bg_lambda']
+    if get_depth:
+        results['depth_fine'] = comp['depth']
+    if get_depth_variance:
+        results['depth_variance_fine'] = comp['depth_var']
+    for k in ('zvals_coarse', 'raw_rgb_coarse', 'raw_sigma_coarse', 'depth_real_coarse'):
+        results.pop(k, None)
+    return results
+
+
+def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
+                      image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
+                      get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
+    """Enqueue the whole render on the current stream.  Returns (results, n_bg_dev, err_flag_dev); the two
+    device scalars are None without a background model.  No host synchronisation."""
+    N.require_device(rays, 'rays')
+    lib, st = N.lib(), N.stream_ptr()
+    dev = rays.device
+    rnd = _randoms if _randoms is not None else {}
+    rays = rays.contiguous().float()
+    n_rays = rays.shape[0]
+    Nc, Nf = hparams.coarse_samples, hparams.fine_samples
+    if image_indices is not None:
+        N.require_device(image_indices, 'image_indices')
+        if image_indices.dtype not in (torch.float32, torch.int32):
+            image_indices = image_indices.float()
+        image_indices = image_indices.contiguous()
+    perturb = float(hparams.perturb) if nerf.training else 0.0
+    dirs = rays[:, 3:6]
+
+    n_bg = err = bg_slot = None
+    far = None
+    last_delta = None
+    bg_results = None
+    if bg_nerf is not None:
+        c, r = _host_vec(sphere_center), _host_vec(sphere_radius)
+        far, last_delta = _f(n_rays, device=dev), _f(n_rays, device=dev)
+        bg_list = torch.zeros(max(n_rays, 1), device=dev, dtype=torch.int32)
+        bg_slot = torch.empty(max(n_rays, 1), device=dev, dtype=torch.int32)
+        scal = torch.zeros(2, device=dev, dtype=torch.int32)
+        n_bg, err = scal[0:1], scal[1:2]
+        N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
+                                  last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
+                                  err.data_ptr(), st))
+        if n_rays > 0:
+            Sb = Nc // 2
+            include_xyz_real = hparams.container_path is not None or hparams.train_mega_nerf is not None
+            cluster_2d = bool(include_xyz_real and getattr(nerf, 'cluster_dim_start', 0) == 1)
+            ncol = 7 if include_xyz_real else 4
+            rays_bg = rays.index_select(0, bg_list.long())          # compacted rays (rows >= n_bg are padding)
+            idx_bg = image_indices.index_select(0, bg_list.long()) if image_indices is not None else None
+            t_bg = linspace01(Sb, dev)
+            prnd = None
+            if perturb > 0:
+                prnd = rnd.get('bg_perturb')
+                if prnd is None:
+                    prnd = torch.rand(n_rays, Sb, device=dev)
+            bg_z = _f(n_rays, Sb, device=dev)
+            bg_pts, bg_dr = _f(n_rays, Sb, ncol, device=dev), _f(n_rays, Sb, device=dev)
+            N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, Sb, t_bg.data_ptr(), perturb,
+                                       N.ptr(prnd), None, N.host3(c), N.host3(r), int(include_xyz_real),
+                                       int(cluster_2d), bg_z.data_ptr(), bg_pts.data_ptr(), bg_dr.data_ptr(), st))
+
+            def bg_points(zf):
+                s = zf.shape[1]
+                p, d = _f(n_rays, s, ncol, device=dev), _f(n_rays, s, device=dev)
+                N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, s, None, 0.0, None,
+                                           zf.data_ptr(), N.host3(c), N.host3(r), int(include_xyz_real),
+                                           int(cluster_2d), None, p.data_ptr(), d.data_ptr(), st))
+                return p, d
+
+            bg_part = _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg,
+                            dirs=rays_bg[:, 3:6], idx=idx_bg, points=bg_points, rays=rays_bg)
+            bg_results = _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
+
+    # ---- foreground (rendering.py:81-100) ----
+    t_c = linspace01(Nc, dev)
+    prnd = None
+    if perturb > 0:
+        prnd = rnd.get('fg_perturb')
+        if prnd is None:
+            prnd = torch.rand(n_rays, Nc, device=dev)
+    z = _f(n_rays, Nc, device=dev)
+    xyz = _f(n_rays, Nc, 3, device=dev)
+    N.check(lib.mnr_fg_samples(rays.data_ptr(), N.ptr(far), n_rays, Nc, t_c.data_ptr(), perturb, N.ptr(prnd),
+                               z.data_ptr(), xyz.data_ptr(), st))
+
+    def fg_points(zf):
+        p = _f(n_rays, zf.shape[1], 3, device=dev)
+        N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), st))
+        return p, None
+
+    fg_part = _Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=dirs,
+                    idx=image_indices, points=fg_points, rays=rays)
+    results = _get_results(nerf, hparams, fg_part, get_depth, get_depth_variance, bg_nerf is not None, False, rnd, 'fg')
+
+    # ---- fg/bg blend (rendering.py:102-139) ----
+    if bg_nerf is not None and n_rays > 0:
+        types = ['fine' if Nf > 0 else 'coarse']
+        if hparams.use_cascade and Nf > 0:
+            types.append('coarse')
+        for typ in types:
+            lam = results['bg_lambda_%s' % typ]          # KeyError for Nf == 0 without cascade, like the reference
+            rgb, depth = results.get('rgb_%s' % typ), results.get('depth_%s' % typ)
+            outs = {}
+            if get_bg_fg_rgb:
+                for key, val in (('rgb', rgb), ('depth', depth)):
+                    if val is not None:
+                        outs['fg_' + key] = torch.empty_like(val)
+                        outs['bg_' + key] = torch.empty_like(val)
+            N.check(lib.mnr_bg_blend(N.ptr(rgb), N.ptr(depth), lam.data_ptr(), bg_slot.data_ptr(),
+                                     N.ptr(bg_results.get('rgb_%s' % typ)), N.ptr(bg_results.get('depth_%s' % typ)),
+                                     n_rays, N.ptr(outs.get('fg_rgb')), N.ptr(outs.get('bg_rgb')),
+                                     N.ptr(outs.get('fg_depth')), N.ptr(outs.get('bg_depth')), st))
+            for k, v in outs.items():
+                results['%s_%s' % (k, typ)] = v
+    return results, n_bg, err
+
+
+def render_rays(nerf: nn.Module,
+                bg_nerf: Optional[nn.Module],
+                rays: torch.Tensor,
+                image_indices: Optional[torch.Tensor],
+                hparams: Namespace,
+                sphere_center: Optional[torch.Tensor],
+                sphere_radius: Optional[torch.Tensor],
+                get_depth: bool,
+                get_depth_variance: bool,
+                get_bg_fg_rgb: bool,
+                _randoms: Optional[dict] = None) -> Tuple[Dict[str, torch.Tensor], bool]:
+    """Same contract as the reference (rendering.py:15-24): returns ``(results, bg_nerf_rays_present)``."""
+    results, n_bg, err = render_rays_async(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius,
+                                           get_depth, get_depth_variance, get_bg_fg_rgb, _randoms)
+    present = False
+    if n_bg is not None:
+        host = torch.stack([n_bg[0], err[0]]).cpu()      # the one sync the reference API requires
+        if int(host[1]) != 0:
+            raise Exception(_ERR_TEXT)
+        present = int(host[0]) > 0
+    return results, present

@@ -1,0 +1,73 @@
+"""CPU-side checks of the native library: it loads, exports every symbol declared in include/mnr_api.h,
+and the packed-weight K ordering is a permutation of every nn.Linear's input columns (no GPU needed)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from mega_nerf import _native as N
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = (ROOT / 'include' / 'mnr_api.h').read_text()
+    declared = set(re.findall(r'\b(mnr_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    lib = N.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(N.EXPORTS) == declared
+    assert lib.mnr_version() == 1
+
+
+def make_desc(xyz_dim=3, W=256, pos_dir_dim=4, app=48, rgb_dim=3, layers=8, skip=(4,)):
+    d = N.ModelDesc()
+    d.xyz_dim, d.pos_xyz_dim, d.pos_dir_dim, d.layers = xyz_dim, 12, pos_dir_dim, layers
+    d.skip_mask = sum(1 << i for i in skip)
+    d.layer_dim, d.appearance_dim, d.appearance_count, d.rgb_dim, d.sigma_activation = W, app, 10, rgb_dim, 1
+    return d
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(xyz_dim=4), dict(W=512), dict(W=512, xyz_dim=4), dict(W=64),
+                                dict(pos_dir_dim=0, rgb_dim=27), dict(app=0), dict(app=0, pos_dir_dim=0)])
+def test_layout_is_a_column_permutation(kw):
+    d = make_desc(**kw)
+    lib = N.lib()
+    P = lib.mnr_layout_parts(C.byref(d))
+    assert P == (2 if d.layer_dim <= 256 else 4)
+    in_xyz = d.xyz_dim * (1 + 24)
+    in_dir = 3 * (1 + 2 * d.pos_dir_dim) if d.pos_dir_dim else 0
+    has_final = d.pos_dir_dim > 0 or d.appearance_dim > 0
+    widths = [in_xyz if i == 0 else d.layer_dim + (in_xyz if (d.skip_mask >> i) & 1 else 0) for i in range(d.layers)]
+    if has_final:
+        widths += [d.layer_dim, d.layer_dim + in_dir + d.appearance_dim]
+    for layer, width in enumerate(widths):
+        steps = lib.mnr_layout_num_steps(C.byref(d), layer)
+        assert steps > 0 and steps % 4 == 0
+        cols = [lib.mnr_layout_src_col(C.byref(d), layer, s, p) for s in range(steps) for p in range(P)]
+        real = [c for c in cols if c >= 0]
+        assert sorted(real) == list(range(width)), (layer, width)
+        assert all(c >= -1 for c in cols)
+    assert lib.mnr_layout_num_steps(C.byref(d), len(widths)) < 0          # out of range -> error
+    assert lib.mnr_packed_model_bytes(C.byref(d)) > 0
+
+
+def test_unsupported_architecture_reports_error():
+    d = make_desc(W=2048)
+    assert N.lib().mnr_packed_model_bytes(C.byref(d)) == 0
+    assert b'unsupported' in N.lib().mnr_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
+    from mega_nerf import ray_utils
+    m = NeRF(12, 4, 8, [4], 256, 48, False, 10, 3, 3, ShiftedSoftplus())
+    with pytest.raises(N.NativeError):
+        m(torch.zeros(4, 7))
+    with pytest.raises(N.NativeError):
+        ray_utils.get_ray_directions(4, 4, 1., 1., 2., 2., True, torch.device('cpu'))
+    with pytest.raises(Exception, match='Unexpected input shape'):
+        m(torch.zeros(4, 5))
