@@ -393,7 +393,7 @@ extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, 
     MNR_REQUIRE(packed_dev && io && io->xyz && io->out, "NULL pointer argument");
     MNR_REQUIRE(io->rows_per_ray >= 1, "rows_per_ray must be >= 1");
     MNR_REQUIRE(io->n_rows >= 0, "negative n_rows");
-    const bool need_dir = d->pos_dir_dim > 0 || (d->rgb_dim > 3 && io->apply_sh_deg >= 0 && !io->sigma_only);
+    const bool need_dir = !io->sigma_only && (d->pos_dir_dim > 0 || (d->rgb_dim > 3 && io->apply_sh_deg >= 0));
     MNR_REQUIRE(!need_dir || io->dir, "dir pointer required");
     MNR_REQUIRE(d->appearance_dim == 0 || io->sigma_only || (io->idx && d->embedding_a), "idx / embedding_a required");
     if (io->apply_sh_deg >= 0) MNR_REQUIRE(3 * (io->apply_sh_deg + 1) * (io->apply_sh_deg + 1) == d->rgb_dim,

@@ -70,11 +70,12 @@ extern "C" int mnr_ray_directions(float *out_dev, int W, int H, float fx, float 
 
 extern "C" int mnr_get_rays(float *out_dev, const float *dirs_dev, int64_t P, int n_dirs_sets, const float *c2w_dev,
                             int n_poses, float near, float far, const float *alt, void *stream) {
-    MNR_REQUIRE(out_dev && dirs_dev && c2w_dev && P >= 0 && n_poses > 0, "bad arguments to mnr_get_rays");
+    MNR_REQUIRE(P >= 0 && n_poses >= 0, "bad arguments to mnr_get_rays");
+    const long n = (long)P * n_poses;
+    if (n == 0) return MNR_OK;                       // empty input: nothing to enqueue
+    MNR_REQUIRE(out_dev && dirs_dev && c2w_dev, "NULL pointer passed to mnr_get_rays");
     MNR_REQUIRE(n_dirs_sets == 1 || n_dirs_sets == n_poses, "n_dirs_sets must be 1 or n_poses");
     MNR_REQUIRE((reinterpret_cast<uintptr_t>(out_dev) & 15) == 0, "out_dev must be 16-byte aligned");
-    const long n = (long)P * n_poses;
-    if (n == 0) return MNR_OK;
     hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), out_dev, dirs_dev,
                        (long)P, n_dirs_sets == 1 ? 1 : 0, c2w_dev, n_poses, near, far,
                        alt ? 1 : 0, alt ? alt[0] : 0.f, alt ? alt[1] : 0.f);

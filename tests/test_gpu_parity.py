@@ -118,8 +118,9 @@ def test_perturbed_z_bit_exact():
     rays = np.zeros((64, 8), f32)
     rays[:, 6], rays[:, 7] = 0.0, 1.0          # near=0, far=1 -> z = t exactly, then jitter (rendering.py:472-483)
     z = torch.empty(64, 32, device=DEV)
-    N.check(N.lib().mnr_fg_samples(T(rays).data_ptr(), None, 64, 32, T(g['linspace_32']).data_ptr(), 0.7,
-                                   T(g['perturb_rand']).data_ptr(), z.data_ptr(), None, None))
+    rays_t, t_t, r_t = T(rays), T(g['linspace_32']), T(g['perturb_rand'])   # keep alive across the launch
+    N.check(N.lib().mnr_fg_samples(rays_t.data_ptr(), None, 64, 32, t_t.data_ptr(), 0.7, r_t.data_ptr(), z.data_ptr(),
+                                   None, None))
     assert np.array_equal(z.cpu().numpy(), g['perturbed'])
 
 
@@ -163,8 +164,9 @@ def test_merge_and_composite_against_oracle():
         z_m, raw_m, dr_m = (torch.empty(n, St, device=DEV), torch.empty(n, St, 4, device=DEV),
                             torch.empty(n, St, device=DEV))
         ordr = torch.empty(n, St, device=DEV, dtype=torch.int32)
-        N.check(N.lib().mnr_merge_sorted(T(zf).data_ptr(), T(rawf).data_ptr(), T(drf).data_ptr(), Sf, T(zc).data_ptr(),
-                                         T(rawc).data_ptr(), T(drc).data_ptr(), Sc, n, None, flip, z_m.data_ptr(),
+        ins = [T(a) for a in (zf, rawf, drf, zc, rawc, drc)]                 # keep alive across the launch
+        N.check(N.lib().mnr_merge_sorted(ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), Sf, ins[3].data_ptr(),
+                                         ins[4].data_ptr(), ins[5].data_ptr(), Sc, n, None, flip, z_m.data_ptr(),
                                          raw_m.data_ptr(), dr_m.data_ptr(), ordr.data_ptr(), None))
         assert np.array_equal(ordr.cpu().numpy(), order.astype(np.int32))
         assert np.array_equal(z_m.cpu().numpy(), z_o)
@@ -181,7 +183,9 @@ def test_merge_and_composite_against_oracle():
             def __call__(self, x, sigma_noise=None, use_coarse=None):
                 return raw_o.reshape(-1, 4)
         hp = O.make_hparams(coarse_samples=Sc, fine_samples=Sf, appearance_dim=0)
-        O.inference(res, 'fine', Fake(), np.zeros((n, 1, 3), f32), None, hp, np.zeros((n, St, 3), f32), z_o,
+        # inference() re-flips z when flip is set and no coarse z is stored (rendering.py:271-273): pre-flip it
+        O.inference(res, 'fine', Fake(), np.zeros((n, 1, 3), f32), None, hp, np.zeros((n, St, 3), f32),
+                    z_o[:, ::-1] if flip else z_o,
                     (last - diff)[:, None].astype(f32), True, True, True, True, True, bool(flip), dr_o)
         io = N.CompositeIO()
         io.z, io.raw, io.depth_real = z_m.data_ptr(), raw_m.data_ptr(), dr_m.data_ptr()
