@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/s of the Mega-NeRF hot path (get_rays + render_rays + NeRF MLP) on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` with one rank per GPU (RCCL).  Rank 0 prints ONE
+JSON line.
+
+Workload (BASELINE.json configs[1]/[2]): "configs/mega-nerf Rubble"-shaped model -- foreground + background
+NeRF, 8 layers x 256 channels, 12/4 frequency bands, 48-d appearance embedding -- on synthetic
+1024-ray x (64 coarse + 128 fine)-sample batches; one spatial submodule per GPU (weak scaling: every rank
+owns a private submodule and its own ray batch; no collective in the data path, one RCCL all-reduce of the
+packed metric vector after the timed region, replacing the reference's file-based gather runner.py:495-510).
+A "step" is one pass of the hot path over one batch: ``--mode eval`` = render_rays forward with the
+validation flags (runner.py:569-578); ``--mode train`` = render_rays + MSE loss + backward + 2x Adam
+(runner.py:246-277).  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / 'mega-nerf_amd', ROOT / 'tests', ROOT / 'tests' / 'golden'):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+FG_FLOP_PER_SAMPLE = 1211392      # 2 x 605 696 MAC
+BG_FLOP_PER_SAMPLE = 1236992
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_models(hp, dev, seed):
+    import common
+    from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
+    A = common.SCENE['appearance_count']
+    out = []
+    for xyz_dim, s in ((3, seed), (4, seed + 500)):
+        cfg = common.model_cfg(hp, xyz_dim, 256)
+        w = common.make_weights(cfg, A, s)
+        m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim,
+                 False, A, 3, xyz_dim, ShiftedSoftplus())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        out.append((m.to(dev), cfg, w))
+    return out
+
+
+def cpu_baseline(hp, rays_np, idx_np, fw, bw, fcfg, bcfg, n_sample):
+    """The numpy oracle (port of the reference CPU path) timed on this box's host cores, bounded sample."""
+    import common
+    from oracle import nerf_oracle as O
+    s = common.SCENE
+    r, i = rays_np[:n_sample], idx_np[:n_sample].astype(np.float32)
+    fn = lambda: O.render_rays(O.Model(fcfg, fw), O.Model(bcfg, bw), r, i, hp, s['sphere_center'], s['sphere_radius'],  # noqa: E731
+                               True, False, True)
+    fn()
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {'value': n_sample / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
+            'sample': 'numpy oracle render_rays (eval flags), %d rays x (64+128) samples, best of 3' % n_sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--mode', choices=['eval', 'train'], default='eval')
+    ap.add_argument('--rays', type=int, default=1024, help='rays per batch (BASELINE: 1024)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')            # RCCL on ROCm
+    assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
+
+    import common
+    from oracle import nerf_oracle as O
+    from mega_nerf import ray_utils, rendering
+    from mega_nerf.rendering import render_rays_async
+
+    hp_o = O.make_hparams(coarse_samples=64, fine_samples=128)
+    hp = Namespace(**vars(hp_o))
+    s = common.SCENE
+    (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp_o, dev, 1000 * (rank + 1))   # one submodule per rank
+    sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
+
+    # synthetic batch: rays of the 400x400 camera, seeded permutation, ~13 % bg rays
+    d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
+    all_rays = ray_utils.get_rays(d, torch.from_numpy(s['c2w']).to(dev), s['near'], s['far'],
+                                  s['ray_altitude_range']).view(-1, 8)
+    g = torch.Generator(device='cpu').manual_seed(42 + rank)
+    sel = torch.randperm(all_rays.shape[0], generator=g)[:args.rays].to(dev)
+    rays = all_rays[sel].contiguous()
+    idx = torch.randint(0, s['appearance_count'], (args.rays,), generator=g).float().to(dev)
+    target = torch.rand(args.rays, 3, generator=g).to(dev)
+
+    if args.mode == 'train':
+        from mega_nerf.training import TrainStep
+        fg.train(), bg.train()
+        stepper = TrainStep(fg, bg, hp, sc, sr)
+        step = lambda: stepper(rays, idx, target)                       # noqa: E731
+    else:
+        fg.eval(), bg.eval()
+
+        def step():
+            with torch.no_grad():
+                return render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
+
+    for _ in range(args.warmup):
+        step()
+    # kernel-level timing of the dominant launch (fg fine MLP: rays x 128 rows) with HIP events recorded on the
+    # launch stream inside the timed region
+    rendering.KERNEL_EVENTS = ev = []
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    rendering.KERNEL_EVENTS = None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    n_bg = int(out[1]) if (args.mode == 'eval' and out[1] is not None) else -1
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    # eval metric all-reduce (packed [sum_psnr, count]) -- the only collective of the path
+    with torch.no_grad():
+        res = render_rays_async(fg.eval(), bg.eval(), rays, idx, hp, sc, sr, True, False, True)[0]
+        mse = torch.mean((res['rgb_fine'] - target) ** 2)
+        packed = torch.stack([-10 * torch.log10(mse), torch.ones((), device=dev)]).double()
+    if dist is not None:
+        dist.all_reduce(packed)
+    psnr = float(packed[0] / packed[1])
+
+    if rank == 0:
+        total_rays = args.rays * args.steps * world
+        fine_ms = [a.elapsed_time(b) for tag, a, b in ev if tag == 'fg_fine']
+        roof = None
+        if fine_ms:
+            avg = sum(fine_ms) / len(fine_ms) * 1e-3
+            flops = args.rays * 128 * FG_FLOP_PER_SAMPLE * (3.0 if args.mode == 'train' and False else 1.0)
+            ach = flops / avg / 1e12
+            traffic = None
+            tf = ROOT / 'profiles' / 'hbm_traffic.json'
+            if tf.exists():
+                traffic = json.loads(tf.read_text()).get('k_mlp_fwd_fg_fine_bytes_per_launch')
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'kernel': 'k_mlp_fwd<fg> (fine pass, %d rows)' % (args.rays * 128),
+                    'avg_launch_ms': round(avg * 1e3, 4)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), fw, bw, fcfg, bcfg, min(256, args.rays))
+        line = {
+            'metric': 'rays_per_sec (%s)' % ('train step: fwd+bwd+Adam' if args.mode == 'train' else 'eval render_rays fwd'),
+            'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs/mega-nerf Rubble-shaped fg+bg NeRF (8x256, 12/4 freqs, 48-d appearance), '
+                                   '%d rays x (64+128) samples per step, one submodule per GPU' % args.rays,
+                       'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg,
+                       'parallelism': 'submodule-per-gpu x%d' % world},
+            'eval_psnr_vs_random_target_db': round(psnr, 4),
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

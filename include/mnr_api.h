@@ -77,6 +77,7 @@ typedef struct mnr_model_desc {
     int32_t appearance_count; /* rows of embedding_a */
     int32_t rgb_dim;          /* 3, or 3*(sh_deg+1)^2 (model_utils.py:57) */
     int32_t sigma_activation; /* 0 = ReLU, 1 = ShiftedSoftplus (nerf.py:28-39) */
+    int32_t mfma_tile;        /* samples per wavefront: 0 = auto (32 for W<=256 else 16), 32 or 16 */
     const float *layer_w[MNR_MAX_LAYERS];
     const float *layer_b[MNR_MAX_LAYERS];
     const float *final_w, *final_b;   /* NULL when the model has neither dir nor appearance input */

@@ -31,10 +31,10 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <int XYZ_, int LX_, int LD_, int APP_, int W_, int NL_, int SKIP_, int RGB_>
+template <int XYZ_, int LX_, int LD_, int APP_, int W_, int NL_, int SKIP_, int RGB_, int TILE_ = tile_for_width(W_)>
 struct MlpCfg {
     static constexpr int XYZ = XYZ_, LX = LX_, LD = LD_, APP = APP_, W = W_, NL = NL_, SKIP = SKIP_, RGB = RGB_;
-    static constexpr int TILE = tile_for_width(W_), P = 64 / TILE;
+    static constexpr int TILE = TILE_, P = 64 / TILE;
     static constexpr int RPB = TILE * TILE / 64;                 // accumulator registers per output block
     static constexpr int H = hid_regs(W_, P);                    // hidden registers per lane
     static constexpr int NOB = W_ / TILE;
@@ -59,22 +59,28 @@ struct MlpFwdArgs {
     int32_t sigma_act, app_count;
 };
 
-// ---- weight stream: global -> VGPR (issued one chunk ahead) -> LDS ------------------------------
+// ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
+// `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at
+// (wave-uniform LDS base) + lane*16 -- the packed image is lane-linear, so no staging registers and no
+// ds_write pass are needed.  The barrier that publishes chunk c also proves every wave has finished
+// reading the buffer chunk c+1 is then loaded into (2-deep ring).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+
 struct WStream {
     const float4 *g;     // this thread's slice of the next chunk to load
     float4 *lds;         // base of the 2-chunk LDS ring
     int cur;             // buffer the MFMAs currently read
-    float4 stage[CHUNK_F4 / 256];
     __device__ __forceinline__ void issue() {
+        const int wave = threadIdx.x >> 6;
+        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;      // wave-uniform base; HW adds lane*16
 #pragma unroll
-        for (int i = 0; i < CHUNK_F4 / 256; ++i) stage[i] = g[i * 256];
+        for (int i = 0; i < CHUNK_F4 / 256; ++i)
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * 256), (lds_void_t *)(dst + i * 256), 16, 0, 0);
         g += CHUNK_F4;
     }
-    // commit the staged chunk into the idle buffer, make it current, start loading the next one
+    // publish the chunk in flight (hipcc drains vmcnt before the barrier), make it current, start the next one
     __device__ __forceinline__ void next_chunk() {
-        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < CHUNK_F4 / 256; ++i) dst[i * 256] = stage[i];
         __syncthreads();
         cur ^= 1;
         issue();
@@ -102,17 +108,23 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
             }
         } else {
             // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk all blocks per k step
-            float4 a[NOB];
+            // (in batches of OBB blocks so that the A fragments stay within OBB*4 registers)
+            constexpr int OBB = NOB < 4 ? NOB : 4;
+            static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) a[ob] = p[ob * 64];
+            for (int o0 = 0; o0 < NOB; o0 += OBB) {
+                float4 a[OBB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[ob], 0, 0, 0);
+                for (int ob = 0; ob < OBB; ++ob) a[ob] = p[(o0 + ob) * 64];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[ob], 0, 0, 0);
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[o0 + ob], 0, 0, 0);
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[ob], 0, 0, 0);
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[o0 + ob], 0, 0, 0);
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[ob], 0, 0, 0);
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[o0 + ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[o0 + ob], 0, 0, 0);
+            }
         }
     });
 }
@@ -208,7 +220,7 @@ __device__ __forceinline__ float eval_sh_channel(int deg, const float *c, float 
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void k_mlp_fwd(MlpFwdArgs a) {
+__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
     extern __shared__ float4 lds_ring[];
@@ -399,13 +411,20 @@ extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, 
     if (io->apply_sh_deg >= 0) MNR_REQUIRE(3 * (io->apply_sh_deg + 1) * (io->apply_sh_deg + 1) == d->rgb_dim,
                                            "apply_sh_deg does not match rgb_dim");
     hipStream_t s = as_stream(stream);
-#define MNR_TRY(XYZ, LX, LD, APP, W, NL, SKIP, RGB)                                                            \
+#define MNR_TRY_T(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                     \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
-        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB)                     \
-        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB>>(m, packed_dev, d, io, s);
+        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL)     \
+        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(m, packed_dev, d, io, s);
+#define MNR_TRY(XYZ, LX, LD, APP, W, NL, SKIP, RGB) MNR_TRY_T(XYZ, LX, LD, APP, W, NL, SKIP, RGB, tile_for_width(W))
     // configs/mega-nerf/*.yaml (opts.py defaults): fg / bg
     MNR_TRY(3, 12, 4, 48, 256, 8, 16, 3)
     MNR_TRY(4, 12, 4, 48, 256, 8, 16, 3)
+    // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
+    MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)
+    MNR_TRY_T(4, 12, 4, 48, 256, 8, 16, 3, 32)
+    // configs/mega-nerf Building: 512 channels
+    MNR_TRY(3, 12, 4, 48, 512, 8, 16, 3)
+    MNR_TRY(4, 12, 4, 48, 512, 8, 16, 3)
 #ifdef MNR_ALL_VARIANTS
     // configs/mega-nerf-sh-3 (sh_deg 2, pos_dir_dim 0)
     MNR_TRY(3, 12, 0, 48, 256, 8, 16, 27)
@@ -419,6 +438,7 @@ extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, 
     MNR_TRY(4, 12, 4, 0, 256, 8, 16, 3)
 #endif
 #undef MNR_TRY
+#undef MNR_TRY_T
     return set_err(MNR_E_UNSUPPORTED,
                    "no fused MLP kernel for xyz_dim=%d pos_xyz_dim=%d pos_dir_dim=%d appearance_dim=%d layer_dim=%d "
                    "layers=%d skip_mask=%d rgb_dim=%d",

@@ -97,18 +97,21 @@ MNR_HD int layer_src_col(const LayerLayout &l, int P, int s, int p) {
     return -1;
 }
 
-// Which MFMA tile a given width uses.  32x32x2 keeps 2*W/2 = W accumulator+input registers per lane
-// (W=256 -> 256 of the 512-register budget); wider models use 16x16x4 with 16 samples per wave.
-MNR_HD constexpr int tile_for_width(int W) { return W <= 256 ? 32 : 16; }
+// Default MFMA tile.  16x16x4 (16 samples per wave) keeps W/4 input + W/4 accumulator registers per lane:
+// two workgroups fit per CU for W <= 256 (better latency hiding, finer scheduling quantum; measured
+// 133 vs 127 TFLOP/s, round 1) and W = 512 fits at one.  32x32x2 (mfma_tile = 32) stays selectable for W <= 256.
+MNR_HD constexpr int tile_for_width(int W) { return (void)W, 16; }
 
 struct ArchDims {   // the subset of mnr_model_desc the layout depends on
-    int xyz_dim, pos_xyz_dim, pos_dir_dim, layers, skip_mask, W, app_dim, rgb_dim;
+    int xyz_dim, pos_xyz_dim, pos_dir_dim, layers, skip_mask, W, app_dim, rgb_dim, tile;
 };
 
 // Returns 0 on success, else a static error string is stored in *err.
 inline int build_layout(const ArchDims &a, ModelLayout &m, const char **err) {
     *err = nullptr;
-    const int tile = tile_for_width(a.W), P = 64 / tile;
+    const int tile = a.tile ? a.tile : tile_for_width(a.W), P = 64 / tile;
+    if (tile != 16 && tile != 32) { *err = "mfma_tile must be 0, 16 or 32"; return -1; }
+    if (tile == 32 && a.W > 256) { *err = "mfma_tile 32 needs layer_dim <= 256 (register budget)"; return -1; }
     if (a.W % tile || a.W < tile || a.W > 512) { *err = "layer_dim must be a multiple of the MFMA tile and <= 512"; return -1; }
     if ((a.W / 2) % tile && (a.pos_dir_dim > 0 || a.app_dim > 0)) { *err = "layer_dim/2 must be a multiple of the MFMA tile"; return -1; }
     if (a.layers < 1 || a.layers > 16) { *err = "layers must be in 1..16"; return -1; }

@@ -20,7 +20,7 @@ int set_err(int code, const char *fmt, ...) {
 int layout_from_desc(const mnr_model_desc *d, ModelLayout &m) {
     if (!d) return set_err(MNR_E_INVALID, "model desc is NULL");
     ArchDims a{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim, d->appearance_dim,
-               d->rgb_dim};
+               d->rgb_dim, d->mfma_tile};
     if (d->xyz_dim != 3 && d->xyz_dim != 4) return set_err(MNR_E_UNSUPPORTED, "xyz_dim must be 3 or 4 (got %d)", d->xyz_dim);
     if (d->rgb_dim < 1 || d->rgb_dim > 75) return set_err(MNR_E_UNSUPPORTED, "rgb_dim out of range: %d", d->rgb_dim);
     const char *err = nullptr;

@@ -27,6 +27,7 @@ class ModelDesc(C.Structure):
         ('xyz_dim', C.c_int32), ('pos_xyz_dim', C.c_int32), ('pos_dir_dim', C.c_int32), ('layers', C.c_int32),
         ('skip_mask', C.c_int32), ('layer_dim', C.c_int32), ('appearance_dim', C.c_int32),
         ('appearance_count', C.c_int32), ('rgb_dim', C.c_int32), ('sigma_activation', C.c_int32),
+        ('mfma_tile', C.c_int32),
         ('layer_w', C.c_void_p * MNR_MAX_LAYERS), ('layer_b', C.c_void_p * MNR_MAX_LAYERS),
         ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('dir_a_w', C.c_void_p), ('dir_a_b', C.c_void_p),
         ('sigma_w', C.c_void_p), ('sigma_b', C.c_void_p), ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p),

@@ -60,6 +60,7 @@ class NeRF(nn.Module):
         self.sigma = nn.Linear(layer_dim, 1)
         self.sigma_activation = sigma_activation
         self.rgb = nn.Linear(layer_dim // 2 if self.has_final else layer_dim, rgb_dim)
+        self.mfma_tile = 0          # 0 = auto; 16 / 32 samples per wavefront (see include/mnr_api.h)
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
 
@@ -76,6 +77,7 @@ class NeRF(nn.Module):
         d.layer_dim, d.appearance_dim = self.layer_dim, self.appearance_dim
         d.appearance_count, d.rgb_dim = self.appearance_count, self.rgb_dim
         d.sigma_activation = 1 if isinstance(self.sigma_activation, ShiftedSoftplus) else 0
+        d.mfma_tile = self.mfma_tile
         for i, enc in enumerate(self.xyz_encodings):
             d.layer_w[i], d.layer_b[i] = enc[0].weight.data_ptr(), enc[0].bias.data_ptr()
         if self.has_final:
@@ -94,7 +96,7 @@ class NeRF(nn.Module):
             N.require_device(p, 'NeRF parameter')
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise N.NativeError('NeRF parameters must be contiguous float32')
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (self.mfma_tile,)
         desc = self.model_desc()
         if self._packed is None or key != self._packed_key:
             nbytes = N.lib().mnr_packed_model_bytes(C.byref(desc))

@@ -24,6 +24,10 @@ from mega_nerf import _native as N
 _ERR_TEXT = ('Not all your cameras are bounded by the unit sphere; please make sure the cameras are normalized '
              'properly!')
 
+# bench.py sets this to a list to get (tag, start_event, end_event) around every MLP launch, recorded on
+# the launch stream (kernel-level timing without a profiler); None = no events.
+KERNEL_EVENTS = None
+
 _tables: Dict[Tuple[int, str], torch.Tensor] = {}
 _host_cache: Dict[Tuple[int, int], list] = {}
 
@@ -66,8 +70,19 @@ class _Part:
         self.__dict__.update(kw)
 
 
-def _model_eval(nerf: nn.Module, typ: str, hparams: Namespace, xyz: torch.Tensor, part: _Part, S: int,
-                noise: Optional[torch.Tensor]) -> torch.Tensor:
+def _model_eval(nerf, typ, hparams, xyz, part, S, noise):
+    if KERNEL_EVENTS is None:
+        return _model_eval_inner(nerf, typ, hparams, xyz, part, S, noise)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = _model_eval_inner(nerf, typ, hparams, xyz, part, S, noise)
+    b.record()
+    KERNEL_EVENTS.append(('%s_%s' % (part.tag, typ), a, b))
+    return out
+
+
+def _model_eval_inner(nerf: nn.Module, typ: str, hparams: Namespace, xyz: torch.Tensor, part: _Part, S: int,
+                      noise: Optional[torch.Tensor]) -> torch.Tensor:
     """The MLP pass of _inference (rendering.py:275-331) for n x S samples -> raw [n, S, 4]."""
     from mega_nerf.models.cascade import Cascade
     from mega_nerf.models.mega_nerf import MegaNeRF
@@ -115,7 +130,7 @@ def _composite(z, raw, n, S, part: _Part, last_delta, zmax_src, flip, depth_real
 def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bool, get_depth_variance: bool,
                  get_bg_lambda: bool, flip: bool, rnd: dict, tag: str) -> Dict[str, torch.Tensor]:
     """rendering.py:176-248 for one branch.  ``part`` carries z_coarse [n,Sc], xyz_coarse, depth_real, last_delta."""
-    lib, st = N.lib(), N.stream_ptr()
+    lib = N.lib()
     dev = part.z.device
     n, Sc = part.z.shape
     Nf = hparams.fine_samples
@@ -130,6 +145,8 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     noise_c = rnd.get(tag + '_noise_coarse') if nerf.training else None
     if nerf.training and noise_c is None:
         noise_c = torch.rand(n * Sc, device=dev)
+    if getattr(part, 'before_coarse', None) is not None:
+        part.before_coarse()
     raw_c = _model_eval(nerf, 'coarse', hparams, xyz_c, part, Sc, noise_c)
     want = set()
     if Nf > 0:
@@ -172,14 +189,14 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     z_f = _f(n, nf, device=dev)
     inds = torch.empty(n, nf, device=dev, dtype=torch.int32) if rnd.get('_want_inds') else None
     N.check(lib.mnr_sample_fine(part.z.data_ptr(), comp['weights'].data_ptr(), n, nunits, Sc, nf, int(det),
-                                u.data_ptr(), z_f.data_ptr(), N.ptr(inds), st))
+                                u.data_ptr(), z_f.data_ptr(), N.ptr(inds), N.stream_ptr()))
     if inds is not None:
         rnd['_inds_' + tag] = inds
         rnd['_fine_z_' + tag] = z_f
     zmax_src = z_f                                           # last_delta uses the fine-only max (quirk Q4)
     if cascade:
         z_all = _f(n, Sc + nf, device=dev)
-        N.check(lib.mnr_sort_rows(part.z.data_ptr(), Sc, z_f.data_ptr(), nf, n, nunits, z_all.data_ptr(), st))
+        N.check(lib.mnr_sort_rows(part.z.data_ptr(), Sc, z_f.data_ptr(), nf, n, nunits, z_all.data_ptr(), N.stream_ptr()))
         z_f, nf = z_all, Sc + nf
         zmax_src = z_f
     xyz_f, depth_real_f = part.points(z_f)
@@ -190,6 +207,8 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     noise_f = rnd.get(tag + '_noise_fine') if nerf.training else None
     if nerf.training and noise_f is None:
         noise_f = torch.rand(n * nf, device=dev)
+    if getattr(part, 'before_fine', None) is not None:
+        part.before_fine()
     raw_f = _model_eval(nerf, 'fine', hparams, xyz_f, part, nf, noise_f)
     if cascade:
         z_m, raw_m, dr_m, Sm = z_f, raw_f, depth_real_f, nf
@@ -199,7 +218,7 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
         dr_m = _f(n, Sm, device=dev) if depth_real_f is not None else None
         N.check(lib.mnr_merge_sorted(z_f.data_ptr(), raw_f.data_ptr(), N.ptr(depth_real_f), nf, z_c.data_ptr(),
                                      raw_c.data_ptr(), N.ptr(part.depth_real), Sc, n, nunits, int(flip),
-                                     z_m.data_ptr(), raw_m.data_ptr(), N.ptr(dr_m), None, st))
+                                     z_m.data_ptr(), raw_m.data_ptr(), N.ptr(dr_m), None, N.stream_ptr()))
     want = {'rgb'}
     if get_bg_lambda:
         want.add('bg_lambda')
@@ -220,13 +239,63 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     return results
 
 
+OVERLAP_BG = True          # run the background branch on a side stream (see render_rays_async)
+_side_streams: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    s = _side_streams.get(str(dev))
+    if s is None:
+        # high priority: the few background workgroups are dispatched ahead of the queued foreground ones, so the
+        # branch finishes inside the foreground coarse pass instead of trailing into the fine pass
+        s = torch.cuda.Stream(device=dev, priority=-1)
+        _side_streams[str(dev)] = s
+    return s
+
+
+def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, get_depth,
+                get_depth_variance, rnd, dev, before_coarse=None):
+    """Background branch of render_rays (rendering.py:47-75) on the current stream."""
+    lib = N.lib()
+    Sb = hparams.coarse_samples // 2
+    include_xyz_real = hparams.container_path is not None or hparams.train_mega_nerf is not None
+    cluster_2d = bool(include_xyz_real and getattr(nerf, 'cluster_dim_start', 0) == 1)
+    ncol = 7 if include_xyz_real else 4
+    rays_bg = rays.index_select(0, bg_list.long())          # compacted rays (rows >= n_bg are padding)
+    idx_bg = image_indices.index_select(0, bg_list.long()) if image_indices is not None else None
+    t_bg = linspace01(Sb, dev)
+    prnd = None
+    if perturb > 0:
+        prnd = rnd.get('bg_perturb')
+        if prnd is None:
+            prnd = torch.rand(n_rays, Sb, device=dev)
+    bg_z = _f(n_rays, Sb, device=dev)
+    bg_pts, bg_dr = _f(n_rays, Sb, ncol, device=dev), _f(n_rays, Sb, device=dev)
+    N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, Sb, t_bg.data_ptr(), perturb,
+                               N.ptr(prnd), None, N.host3(c), N.host3(r), int(include_xyz_real),
+                               int(cluster_2d), bg_z.data_ptr(), bg_pts.data_ptr(), bg_dr.data_ptr(), N.stream_ptr()))
+
+    def bg_points(zf):
+        s = zf.shape[1]
+        p, d = _f(n_rays, s, ncol, device=dev), _f(n_rays, s, device=dev)
+        N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, s, None, 0.0, None,
+                                   zf.data_ptr(), N.host3(c), N.host3(r), int(include_xyz_real),
+                                   int(cluster_2d), None, p.data_ptr(), d.data_ptr(), N.stream_ptr()))
+        return p, d
+
+    bg_part = _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg,
+                    dirs=rays_bg[:, 3:6], idx=idx_bg, points=bg_points, rays=rays_bg, tag='bg',
+                    before_coarse=before_coarse)
+    return _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
+
+
 def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
                       image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
                       get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
     """Enqueue the whole render on the current stream.  Returns (results, n_bg_dev, err_flag_dev); the two
     device scalars are None without a background model.  No host synchronisation."""
     N.require_device(rays, 'rays')
-    lib, st = N.lib(), N.stream_ptr()
+    lib = N.lib()
     dev = rays.device
     rnd = _randoms if _randoms is not None else {}
     rays = rays.contiguous().float()
@@ -240,7 +309,7 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     perturb = float(hparams.perturb) if nerf.training else 0.0
     dirs = rays[:, 3:6]
 
-    n_bg = err = bg_slot = None
+    n_bg = err = bg_slot = bg_join = bg_prologue_done = None
     far = None
     last_delta = None
     bg_results = None
@@ -253,37 +322,20 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
         n_bg, err = scal[0:1], scal[1:2]
         N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
                                   last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
-                                  err.data_ptr(), st))
+                                  err.data_ptr(), N.stream_ptr()))
         if n_rays > 0:
-            Sb = Nc // 2
-            include_xyz_real = hparams.container_path is not None or hparams.train_mega_nerf is not None
-            cluster_2d = bool(include_xyz_real and getattr(nerf, 'cluster_dim_start', 0) == 1)
-            ncol = 7 if include_xyz_real else 4
-            rays_bg = rays.index_select(0, bg_list.long())          # compacted rays (rows >= n_bg are padding)
-            idx_bg = image_indices.index_select(0, bg_list.long()) if image_indices is not None else None
-            t_bg = linspace01(Sb, dev)
-            prnd = None
-            if perturb > 0:
-                prnd = rnd.get('bg_perturb')
-                if prnd is None:
-                    prnd = torch.rand(n_rays, Sb, device=dev)
-            bg_z = _f(n_rays, Sb, device=dev)
-            bg_pts, bg_dr = _f(n_rays, Sb, ncol, device=dev), _f(n_rays, Sb, device=dev)
-            N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, Sb, t_bg.data_ptr(), perturb,
-                                       N.ptr(prnd), None, N.host3(c), N.host3(r), int(include_xyz_real),
-                                       int(cluster_2d), bg_z.data_ptr(), bg_pts.data_ptr(), bg_dr.data_ptr(), st))
-
-            def bg_points(zf):
-                s = zf.shape[1]
-                p, d = _f(n_rays, s, ncol, device=dev), _f(n_rays, s, device=dev)
-                N.check(lib.mnr_bg_samples(rays_bg.data_ptr(), None, n_bg.data_ptr(), n_rays, s, None, 0.0, None,
-                                           zf.data_ptr(), N.host3(c), N.host3(r), int(include_xyz_real),
-                                           int(cluster_2d), None, p.data_ptr(), d.data_ptr(), st))
-                return p, d
-
-            bg_part = _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg,
-                            dirs=rays_bg[:, 3:6], idx=idx_bg, points=bg_points, rays=rays_bg)
-            bg_results = _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
+            # The background branch is independent of the foreground until the blend: run it on a side
+            # stream so that its small launches (~13 % of the rays) fill the tail of the foreground waves.
+            main = torch.cuda.current_stream()
+            side = _side_stream(dev) if OVERLAP_BG else main
+            if side is not main:
+                side.wait_stream(main)
+            bg_prologue_done = torch.cuda.Event() if side is not main else None
+            with torch.cuda.stream(side):
+                bg_results = _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb,
+                                         c, r, get_depth, get_depth_variance, rnd, dev,
+                                         bg_prologue_done.record if bg_prologue_done is not None else None)
+            bg_join = (side, main) if side is not main else None
 
     # ---- foreground (rendering.py:81-100) ----
     t_c = linspace01(Nc, dev)
@@ -295,19 +347,29 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     z = _f(n_rays, Nc, device=dev)
     xyz = _f(n_rays, Nc, 3, device=dev)
     N.check(lib.mnr_fg_samples(rays.data_ptr(), N.ptr(far), n_rays, Nc, t_c.data_ptr(), perturb, N.ptr(prnd),
-                               z.data_ptr(), xyz.data_ptr(), st))
+                               z.data_ptr(), xyz.data_ptr(), N.stream_ptr()))
 
     def fg_points(zf):
         p = _f(n_rays, zf.shape[1], 3, device=dev)
-        N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), st))
+        N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), N.stream_ptr()))
         return p, None
 
+    # Join the background stream before the foreground *fine* pass: the background branch then overlaps the
+    # foreground coarse pass + sampling only, and the dominant launch (fg fine) runs on an otherwise idle GPU.
+    join = (lambda: torch.cuda.current_stream().wait_stream(bg_join[0])) if bg_join is not None else None
+    # ... and hold the foreground coarse launch until the background's tiny prologue kernels have run, so that
+    # they are not stuck behind a GPU full of long-running foreground workgroups.
+    hold = (lambda: torch.cuda.current_stream().wait_event(bg_prologue_done)) if bg_join is not None else None
     fg_part = _Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=dirs,
-                    idx=image_indices, points=fg_points, rays=rays)
+                    idx=image_indices, points=fg_points, rays=rays, tag='fg', before_fine=join, before_coarse=hold)
     results = _get_results(nerf, hparams, fg_part, get_depth, get_depth_variance, bg_nerf is not None, False, rnd, 'fg')
 
     # ---- fg/bg blend (rendering.py:102-139) ----
     if bg_nerf is not None and n_rays > 0:
+        if bg_join is not None:
+            main.wait_stream(side)
+            for v in bg_results.values():
+                v.record_stream(main)                    # allocated on the side stream, consumed on main
         types = ['fine' if Nf > 0 else 'coarse']
         if hparams.use_cascade and Nf > 0:
             types.append('coarse')
@@ -323,7 +385,7 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
             N.check(lib.mnr_bg_blend(N.ptr(rgb), N.ptr(depth), lam.data_ptr(), bg_slot.data_ptr(),
                                      N.ptr(bg_results.get('rgb_%s' % typ)), N.ptr(bg_results.get('depth_%s' % typ)),
                                      n_rays, N.ptr(outs.get('fg_rgb')), N.ptr(outs.get('bg_rgb')),
-                                     N.ptr(outs.get('fg_depth')), N.ptr(outs.get('bg_depth')), st))
+                                     N.ptr(outs.get('fg_depth')), N.ptr(outs.get('bg_depth')), N.stream_ptr()))
             for k, v in outs.items():
                 results['%s_%s' % (k, typ)] = v
     return results, n_bg, err

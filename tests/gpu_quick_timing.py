@@ -15,7 +15,10 @@ hp = O.make_hparams(coarse_samples=64, fine_samples=128)
 fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
 fg, bg = native_nerf(fcfg, common.make_weights(fcfg, 100, 1)), native_nerf(bcfg, common.make_weights(bcfg, 100, 2))
 rng = np.random.default_rng(0)
-for B in (1024 * 64, 1024 * 128, 1024 * 192, 65536 * 64):
+import sys as _s
+tile = int(_s.argv[1]) if len(_s.argv) > 1 else 0
+fg.mfma_tile = tile; bg.mfma_tile = tile
+for B in (4416, 8832, 1024 * 64, 1024 * 128, 65536 * 64):
     x = T(np.concatenate([rng.uniform(-1, 1, (B, 3)), rng.standard_normal((B, 3)), rng.integers(0, 100, (B, 1))], 1).astype(np.float32))
     with torch.no_grad():
         for _ in range(3): fg(x)

@@ -206,7 +206,7 @@ def test_merge_and_composite_against_oracle():
 
 
 # ---- fused MLP -----------------------------------------------------------------------------------
-SUPPORTED_MLP = ['fg', 'bg', 'sh2', 'noapp', 'w64']
+SUPPORTED_MLP = ['fg', 'bg', 'sh2', 'noapp', 'w64', 'w512']
 
 
 @pytest.mark.parametrize('name', SUPPORTED_MLP)
@@ -225,6 +225,19 @@ def test_mlp_forward_matches_reference(name):
         assert m(x[:0]).shape == (0, cfg.rgb_dim + 1)
         with pytest.raises(Exception, match='Unexpected input shape'):
             m(x[:, :-1])
+
+
+@pytest.mark.parametrize('name', ['fg', 'bg'])
+def test_mlp_tile32_variant(name):
+    """32-samples-per-wave kernel (v_mfma_f32_32x32x2_f32) gives the same numbers as the default (16)."""
+    g = load('mlp')
+    hp, cfg, w = mlp_variant(name)
+    m = native_nerf(cfg, w)
+    m.mfma_tile = 32
+    x = T(g[name + '_x'])
+    with torch.no_grad():
+        close(m(x), g[name + '_out'], 1e-4, 2e-6)
+        close(m(x[:77], sigma_noise=T(g[name + '_noise'][:77])), g[name + '_out_noise'][:77], 1e-4, 2e-6)
 
 
 def test_mlp_repacks_after_weight_update():
@@ -259,7 +272,7 @@ def test_mlp_large_batch_against_oracle():
 # ---- end-to-end render_rays ----------------------------------------------------------------------
 SUPPORTED_RENDER = ['render_fgbg_eval', 'render_fgonly_eval', 'render_q13_eval', 'render_default_samples_eval',
                     'render_sh2_eval', 'render_container_eval', 'render_cascade_eval', 'render_coarse_only_eval',
-                    'render_relu_noapp_eval']
+                    'render_relu_noapp_eval', 'render_w512_eval']
 
 
 def native_models(name):

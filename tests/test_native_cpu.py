@@ -22,21 +22,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.mnr_version() == 1
 
 
-def make_desc(xyz_dim=3, W=256, pos_dir_dim=4, app=48, rgb_dim=3, layers=8, skip=(4,)):
+def make_desc(xyz_dim=3, W=256, pos_dir_dim=4, app=48, rgb_dim=3, layers=8, skip=(4,), tile=0):
     d = N.ModelDesc()
     d.xyz_dim, d.pos_xyz_dim, d.pos_dir_dim, d.layers = xyz_dim, 12, pos_dir_dim, layers
     d.skip_mask = sum(1 << i for i in skip)
     d.layer_dim, d.appearance_dim, d.appearance_count, d.rgb_dim, d.sigma_activation = W, app, 10, rgb_dim, 1
+    d.mfma_tile = tile
     return d
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(xyz_dim=4), dict(W=512), dict(W=512, xyz_dim=4), dict(W=64),
+                                dict(tile=32), dict(tile=32, xyz_dim=4),
                                 dict(pos_dir_dim=0, rgb_dim=27), dict(app=0), dict(app=0, pos_dir_dim=0)])
 def test_layout_is_a_column_permutation(kw):
     d = make_desc(**kw)
     lib = N.lib()
     P = lib.mnr_layout_parts(C.byref(d))
-    assert P == (2 if d.layer_dim <= 256 else 4)
+    assert P == (2 if d.mfma_tile == 32 else 4)   # default tile: 16 samples per wave -> 4 lane-parts
     in_xyz = d.xyz_dim * (1 + 24)
     in_dir = 3 * (1 + 2 * d.pos_dir_dim) if d.pos_dir_dim else 0
     has_final = d.pos_dir_dim > 0 or d.appearance_dim > 0
