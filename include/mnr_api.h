@@ -125,6 +125,50 @@ typedef struct mnr_mlp_io {
 
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
 
+/* ---- training (the reference obtains all of this from torch autograd over nerf.py:115-160) -------------
+ * Forward pass that additionally writes the activation tape (post-ReLU output of every layer, the two
+ * positional encodings in reference column order and the gathered appearance rows) as dense row-major
+ * planes [tape_rows][width]; mnr_tape_floats_per_row() * tape_rows floats in total. */
+int64_t mnr_tape_floats_per_row(const mnr_model_desc *desc);
+int mnr_mlp_forward_train(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, float *tape_dev,
+                          int64_t tape_rows, int64_t tape_row0, void *stream);
+
+/* Transposed weight image for the data-gradient chain (re-pack after every optimiser step). */
+size_t mnr_packed_bwd_bytes(const mnr_model_desc *desc);
+int mnr_pack_model_bwd(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
+
+/* Gradient buffers with the shapes of the nn.Module parameters (= param.grad); gradients are ACCUMULATED. */
+typedef struct mnr_model_grads {
+    float *layer_w[MNR_MAX_LAYERS];
+    float *layer_b[MNR_MAX_LAYERS];
+    float *final_w, *final_b, *dir_a_w, *dir_a_b, *sigma_w, *sigma_b, *rgb_w, *rgb_b;
+    float *embedding_a;          /* [appearance_count][appearance_dim] or NULL */
+} mnr_model_grads;
+
+typedef struct mnr_mlp_grad_io {
+    const float *tape;           /* written by mnr_mlp_forward_train for the same rows */
+    float *gtape;                /* scratch of the same size: dL/d(pre-activation) of every layer */
+    int64_t tape_rows;           /* row capacity of every plane */
+    int64_t tape_row0;           /* tape row of this launch's row 0 (several passes share one tape) */
+    const float *d_out;  int64_t d_out_stride;   /* dL/d(out) [n_rows][>=4] (rgb after sigmoid, sigma after activation) */
+    const float *out;    int64_t out_stride;     /* the forward output itself */
+    float *dheads;               /* scratch [n_rows][4] */
+    const void *idx;  int64_t idx_stride;  int32_t idx_is_float;
+    int32_t rows_per_ray;
+    int64_t n_rows;
+    const int32_t *n_units_dev;  int32_t rows_per_unit;
+    mnr_model_grads grad;
+} mnr_mlp_grad_io;
+
+/* Backward, step 1: data-gradient chain (fused, register-chained like the forward) for the rows of one
+ * forward pass; fills gtape / dheads rows [tape_row0, tape_row0 + n_rows) and accumulates the appearance
+ * embedding gradient.  No gradient w.r.t. xyz / directions is produced (rays are data). */
+int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev, const mnr_model_desc *desc,
+                          const mnr_mlp_grad_io *io, void *stream);
+/* Backward, step 2: weight + bias gradients of every layer over tape rows [tape_row0, tape_row0 + n_rows) in one
+ * launch (so several forward passes that share a tape are reduced together).  d_out/out/idx are not read. */
+int mnr_mlp_backward_weights(const mnr_model_desc *desc, const mnr_mlp_grad_io *io, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Volume rendering stages -- mega_nerf/rendering.py
  * ---------------------------------------------------------------------------------------------- */
@@ -224,6 +268,31 @@ int mnr_composite(const mnr_composite_io *io, void *stream);
 int mnr_bg_blend(float *rgb_dev, float *depth_dev, const float *bg_lambda_dev, const int32_t *bg_slot_dev,
                  const float *bg_rgb_c_dev, const float *bg_depth_c_dev, int64_t N, float *fg_rgb_out,
                  float *bg_rgb_out, float *fg_depth_out, float *bg_depth_out, void *stream);
+
+/* ---- backward of the rendering stages (training; autograd over rendering.py:102-131,336-393) --------- */
+
+/* Gradient of mnr_composite's rgb (and bg_lambda) output w.r.t. the raw MLP outputs. Inputs as in the forward
+ * call; d_rgb [N][3], d_bg_lambda [N] or NULL; writes d_raw [N][S][4] (d rgb, d sigma). */
+typedef struct mnr_composite_grad_io {
+    const float *z, *raw, *last_delta, *zmax_src;
+    int32_t zmax_S, flip;
+    int64_t N;
+    const int32_t *n_units_dev;
+    int32_t S;
+    const float *d_rgb;
+    const float *d_bg_lambda;
+    float *d_raw;
+} mnr_composite_grad_io;
+int mnr_composite_backward(const mnr_composite_grad_io *io, void *stream);
+
+/* Inverse of mnr_merge_sorted for gradients: d_merged [N][Sa+Sb][4] + order (as exported by the forward) ->
+ * d_a [N][Sa][4] (fine), d_b [N][Sb][4] (coarse). */
+int mnr_merge_backward(const float *d_merged_dev, const int32_t *order_dev, int Sa, int Sb, int64_t N,
+                       const int32_t *n_units_dev, float *d_a_dev, float *d_b_dev, void *stream);
+
+/* Backward of the rgb part of mnr_bg_blend: d_lambda [N], d_bg_rgb_c [slots][3]. */
+int mnr_bg_blend_backward(const float *d_rgb_dev, const float *bg_lambda_dev, const int32_t *bg_slot_dev,
+                          const float *bg_rgb_c_dev, int64_t N, float *d_lambda_dev, float *d_bg_rgb_c_dev, void *stream);
 
 #ifdef __cplusplus
 }

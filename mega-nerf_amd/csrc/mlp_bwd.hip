@@ -1,0 +1,531 @@
+// mlp_bwd.hip -- backward pass of the fused NeRF MLP for gfx950 (training; the reference gets this
+// from torch autograd over nerf.py:115-160).
+//
+// Three kernels:
+//  * k_pack_bwd      : nn.Linear weights -> transposed MFMA-fragment chunk stream (reverse layer order).
+//  * k_mlp_bwd       : data-gradient chain.  Mirrors the forward kernel: one wavefront owns TILE samples and
+//                      all W features, dZ_l (C-layout registers) is the B operand of the W_l^T product whose
+//                      accumulators, masked by the stored ReLU activations, are dZ_{l-1}.  Every dZ_l is
+//                      written to the gradient tape for the weight-gradient GEMMs; the appearance-embedding
+//                      gradient is reduced over the wave and added atomically.
+//  * k_wgrad         : dW_l += dZ_l^T . IN_l  and  db_l += colsum(dZ_l) for every layer in ONE launch
+//                      (job table; split over row ranges; v_mfma_f32_32x32x2_f32; fp32 atomics into .grad).
+//  * k_head_grads    : sigma / rgb head weight gradients (M = 1 and 3: VALU).
+#include "mlp_device.h"
+
+namespace mnr {
+
+int layout_from_desc(const mnr_model_desc *d, ModelLayout &m);
+
+static ArchDims arch_of(const mnr_model_desc *d) {
+    return ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim, d->appearance_dim,
+                    d->rgb_dim, d->mfma_tile};
+}
+
+static int bwd_layout_from_desc(const mnr_model_desc *d, BwdLayout &b) {
+    ModelLayout m;
+    int rc = layout_from_desc(d, m);
+    if (rc != MNR_OK) return rc;
+    const char *err = nullptr;
+    if (build_bwd_layout(arch_of(d), b, &err)) return set_err(MNR_E_UNSUPPORTED, "backward layout: %s", err);
+    if (!b.has_final) return set_err(MNR_E_UNSUPPORTED, "training needs a model with the dir/appearance branch");
+    int n = 0;
+    b.layer[n++].w = d->dir_a_w;
+    b.layer[n++].w = d->final_w;
+    for (int l = d->layers - 1; l >= 1; --l) b.layer[n++].w = d->layer_w[l];
+    return MNR_OK;
+}
+
+__global__ void k_pack_bwd(BwdLayout b, float4 *__restrict__ chunks) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)b.total_chunks * CHUNK_F4) return;
+    const int chunk = (int)(tid / CHUNK_F4), within = (int)(tid % CHUNK_F4);
+    const int P = b.parts, tile = b.tile;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int li = -1;
+    for (int i = 0; i < b.n_layers; ++i)
+        if (chunk >= b.layer[i].chunk0 && chunk < b.layer[i].chunk0 + b.layer[i].nchunks) li = i;
+    if (li >= 0) {
+        const BwdLayerLayout &l = b.layer[li];
+        const int lane = within & 63, blk = within >> 6;
+        const int gic = blk / l.nob, ob = blk % l.nob;
+        const int g = (chunk - l.chunk0) * l.gpc + gic;
+        if (gic < l.gpc && g < l.ngroups) {
+            const int row = ob * tile + lane % tile, part = lane / tile;
+            if (row < l.n_rows) {
+                const int in_col = row < l.split ? l.in_off + row : l.in_off2 + (row - l.split);
+                float t[4];
+                for (int c = 0; c < 4; ++c) t[c] = l.w[(long)hid_src(P, 4 * g + c, part) * l.ld + in_col];
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    }
+    chunks[tid] = v;
+}
+
+struct MlpBwdArgs {
+    const float4 *chunks;          // backward chunk stream
+    const float *aux;              // forward aux image (sigma / rgb head weights in lane order)
+    const float *tape;             // forward activations
+    float *gtape;                  // gradient tape (same plane layout): dZ of every layer
+    long tape_rows;
+    TapeLayout tl;
+    const float *d_out;  long d_out_stride;     // dL/d(out) [rows][>=4]
+    const float *out;    long out_stride;       // forward output (rgb after sigmoid, sigma after activation)
+    float *dheads;                 // [rows][4]: dL/d(rgb pre-sigmoid) x3, dL/d(sigma pre-activation)
+    float *d_emb_a;                // [appearance_count][APP] gradient, atomically accumulated (may be NULL)
+    const void *idx;  long idx_stride;  int idx_is_float;
+    int rows_per_ray, app_count, sigma_act, sigma_off, rgb_off;
+    long n_rows;
+    const int32_t *n_units_dev;  int rows_per_unit;
+    long tape_row0;                // tape / gradient-tape row of this launch's row 0
+};
+
+// dZ = dH masked by the stored post-ReLU activation; write dZ to the gradient tape
+template <int P, int NH>
+__device__ __forceinline__ void relu_mask_store(float (&g)[NH], const float *act_row, float *g_row, int part, bool valid) {
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(act_row + 4 * P * q + 4 * part);
+        g[4 * q + 0] = a4.x > 0.f ? g[4 * q + 0] : 0.f;
+        g[4 * q + 1] = a4.y > 0.f ? g[4 * q + 1] : 0.f;
+        g[4 * q + 2] = a4.z > 0.f ? g[4 * q + 2] : 0.f;
+        g[4 * q + 3] = a4.w > 0.f ? g[4 * q + 3] : 0.f;
+        if (valid)
+            *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+    }
+}
+
+template <int NOB, class AccT>
+__device__ __forceinline__ void zero_acc(AccT (&acc)[NOB]) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc[ob] = AccT(0.f);
+}
+
+template <class C>
+__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_bwd(MlpBwdArgs a) {
+    constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB, H2 = C::H2, W = C::W;
+    static_assert(C::HAS_FINAL && C::RGB == 3, "backward kernel covers the dir/appearance architecture");
+    using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
+    // dir_a^T produces W final-feature rows + APP appearance rows, padded to a multiple of 4 blocks
+    constexpr int ROWS_D = cdiv(W + C::APP, 4 * TILE) * 4 * TILE, NOBD = ROWS_D / TILE;
+    constexpr int GPCD = CHUNK_F4 / (NOBD * 64) < 1 ? 1 : CHUNK_F4 / (NOBD * 64);
+    extern __shared__ float4 lds_ring[];
+
+    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
+    if ((long)blockIdx.x * C::ROWS_PER_WG >= n_rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane / TILE;
+    const long row = ((long)blockIdx.x * 4 + wave) * TILE + (lane % TILE);
+    const bool valid = row < n_rows;
+    const long rc = valid ? row : n_rows - 1;
+    const long cap = a.tape_rows;
+    const long trow = rc + a.tape_row0;          // row in tape space
+
+    WStream st;
+    st.g = a.chunks + threadIdx.x;
+    st.lds = lds_ring;
+    st.cur = 1;
+    st.issue();
+
+    // ---- output activations backward -------------------------------------------------------------
+    float dr[3], ds;
+    {
+        const float *go = a.d_out + rc * a.d_out_stride, *o = a.out + rc * a.out_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dr[c] = valid ? go[c] * o[c] * (1.f - o[c]) : 0.f;        // sigmoid'
+        const float sg = o[3];
+        const float da = a.sigma_act ? (1.f - expf(-sg)) : (sg > 0.f ? 1.f : 0.f);           // softplus' = 1 - e^-softplus
+        ds = valid ? go[3] * da : 0.f;
+        if (valid && part == 0) *reinterpret_cast<float4 *>(a.dheads + trow * 4) = make_float4(dr[0], dr[1], dr[2], ds);
+    }
+
+    // ---- rgb head backward -> dZ of dir_a ---------------------------------------------------------
+    float dd[H2];
+    {
+        const float *wr = a.aux + a.rgb_off;
+#pragma unroll
+        for (int q = 0; q < H2 / 4; ++q) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H2 + 4 * q);
+                s.x = fmaf(dr[c], w4.x, s.x); s.y = fmaf(dr[c], w4.y, s.y);
+                s.z = fmaf(dr[c], w4.z, s.z); s.w = fmaf(dr[c], w4.w, s.w);
+            }
+            dd[4 * q] = s.x; dd[4 * q + 1] = s.y; dd[4 * q + 2] = s.z; dd[4 * q + 3] = s.w;
+        }
+        relu_mask_store<P>(dd, a.tape + a.tl.dact_off * cap + trow * (W / 2), a.gtape + a.tl.dact_off * cap + trow * (W / 2),
+                           part, valid);
+    }
+
+    // ---- dir_a^T: d(final features) and d(appearance embedding) -----------------------------------
+    float g[H];
+    {
+        AccT accd[NOBD];
+        zero_acc(accd);
+        st.next_chunk();
+        run_segment<TILE, NOBD, H2 / 4, GPCD, 0>(accd, dd, st, lane);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < RPB; ++r) g[ob * RPB + r] = accd[ob][r];
+        if (valid) {                               // dZ of xyz_encoding_final (no activation)
+            float *gr = a.gtape + a.tl.fin_off * cap + trow * W + 4 * part;
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q)
+                *reinterpret_cast<float4 *>(gr + 4 * P * q) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        }
+        if constexpr (C::APP > 0) {
+            if (a.d_emb_a) {
+                constexpr int NAB = cdiv(C::APP, TILE);          // appearance blocks after the W final-feature rows
+                const long ray = rc / a.rows_per_ray;
+                long idx = a.idx_is_float ? (long)reinterpret_cast<const float *>(a.idx)[ray * a.idx_stride]
+                                          : (long)reinterpret_cast<const int32_t *>(a.idx)[ray * a.idx_stride];
+                idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);
+                const bool uniform = (a.rows_per_ray % TILE) == 0;     // all rows of this wave share one ray
+#pragma unroll
+                for (int b = 0; b < NAB; ++b)
+#pragma unroll
+                    for (int r = 0; r < RPB; ++r) {
+                        float v = accd[NOB + b][r];
+                        // feature of flat register (b, r): C layout of one TILE-row block
+                        const int col = TILE == 32 ? b * 32 + (r & 3) + 8 * (r >> 2) + 4 * part : b * 16 + 4 * part + r;
+                        if (uniform) {
+#pragma unroll
+                            for (int o = 1; o < TILE; o <<= 1) v += __shfl_xor(v, o);
+                            if ((lane % TILE) == 0 && col < C::APP) atomicAdd(a.d_emb_a + idx * C::APP + col, v);
+                        } else if (valid && col < C::APP) {
+                            atomicAdd(a.d_emb_a + idx * C::APP + col, v);
+                        }
+                    }
+            }
+        }
+    }
+
+    // ---- final^T (+ sigma head): dZ of trunk layer L-1 ---------------------------------------------
+    AccT acc[NOB];
+    {
+        const float *ws = a.aux + a.sigma_off + part * H;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int q = 0; q < RPB / 4; ++q) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(ws + ob * RPB + 4 * q);
+                acc[ob][4 * q + 0] = ds * w4.x; acc[ob][4 * q + 1] = ds * w4.y;
+                acc[ob][4 * q + 2] = ds * w4.z; acc[ob][4 * q + 3] = ds * w4.w;
+            }
+        st.next_chunk();
+        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
+        acc_to_regs<NOB, RPB, false>(g, acc);
+        relu_mask_store<P>(g, a.tape + a.tl.act_off[C::NL - 1] * cap + trow * W, a.gtape + a.tl.act_off[C::NL - 1] * cap + trow * W,
+                           part, valid);
+    }
+
+    // ---- trunk layers L-1 .. 1 transposed ------------------------------------------------------------
+    static_for<0, C::NL - 1>([&](auto jc) {
+        constexpr int l = C::NL - 1 - decltype(jc)::value;       // consumes dZ_l, produces dZ_{l-1}
+        zero_acc(acc);
+        st.next_chunk();
+        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
+        acc_to_regs<NOB, RPB, false>(g, acc);
+        relu_mask_store<P>(g, a.tape + a.tl.act_off[l - 1] * cap + trow * W, a.gtape + a.tl.act_off[l - 1] * cap + trow * W, part,
+                           valid);
+    });
+}
+
+// =================================================================================================
+// Weight gradients: dW[M][ldw] (+col0) += dZ[rows][M]^T . IN[rows][N], db[M] += colsum(dZ)
+// =================================================================================================
+struct WgradJob {
+    const float *dz;  int ldz, M;        // ldz == M (planes are dense)
+    const float *in;  int ldin, N;
+    float *dw;  int ldw, col0;
+    float *db;                            // NULL: no bias gradient from this job
+    int wg0, nwg;
+};
+constexpr int WGRAD_MAX_JOBS = 20;
+struct WgradArgs {
+    WgradJob job[WGRAD_MAX_JOBS];
+    int njobs;
+    long n_rows;
+    const int32_t *n_units_dev;
+    int rows_per_unit;
+    long row0;                            // first tape row of the region
+};
+
+constexpr int WG_KT = 32;                 // rows (K) per LDS tile
+
+__global__ __launch_bounds__(256, 1) void k_wgrad(WgradArgs a) {
+    extern __shared__ float wlds[];
+    const int bid = blockIdx.x;
+    int j = 0;
+    for (int i = 0; i < a.njobs; ++i)
+        if (bid >= a.job[i].wg0 && bid < a.job[i].wg0 + a.job[i].nwg) j = i;
+    const WgradJob &J = a.job[j];
+    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
+    const int slice = bid - J.wg0;
+    long rps = (n_rows + J.nwg - 1) / J.nwg;
+    rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
+    const long r_begin = (long)slice * rps, r_end = min(n_rows, r_begin + rps);
+    if (r_begin >= r_end) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int MB = J.M / 32, NB = (J.N + 31) / 32;
+    const int MBW = MB / 2, NBW = (NB + 1) / 2;            // blocks per wave (<= 4 each)
+    const int i32 = lane & 31, kk = lane >> 5;
+    float *dz_t = wlds;                                    // [WG_KT][M]
+    float *in_t = wlds + WG_KT * J.M;                      // [WG_KT][ldin] (+ slack)
+    const int dz_f4 = WG_KT * J.M / 4, in_f4 = WG_KT * J.ldin / 4;
+
+    floatx16 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = floatx16(0.f);
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (long r0 = r_begin; r0 < r_end; r0 += WG_KT) {
+        const int nr = (int)min((long)WG_KT, r_end - r0);
+        __syncthreads();                                   // previous tile fully consumed
+        const float4 *gz = reinterpret_cast<const float4 *>(J.dz + (a.row0 + r0) * J.ldz);
+        const float4 *gi = reinterpret_cast<const float4 *>(J.in + (a.row0 + r0) * J.ldin);
+        for (int t = threadIdx.x; t < dz_f4; t += 256)
+            reinterpret_cast<float4 *>(dz_t)[t] = (t * 4 / J.M) < nr ? gz[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = threadIdx.x; t < in_f4; t += 256)
+            reinterpret_cast<float4 *>(in_t)[t] = (t * 4 / J.ldin) < nr ? gi[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        for (int k = 0; k < WG_KT; k += 2) {
+            const float *zr = dz_t + (k + kk) * J.M + wr * MBW * 32 + i32;
+            const float *ir = in_t + (k + kk) * J.ldin + wc * NBW * 32 + i32;
+            float af[4], bf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = m < MBW ? zr[m * 32] : 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n] = n < NBW ? ir[n * 32] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m < MBW) {
+                    bsum[m] += af[m];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        if (n < NBW) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // write-out: C layout -> atomics into the nn.Parameter gradient
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m >= MBW) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (n >= NBW) continue;
+            const int col = (wc * NBW + n) * 32 + i32;
+            if (col >= J.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowm = (wr * MBW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                atomicAdd(J.dw + (long)rowm * J.ldw + J.col0 + col, acc[m][n][r]);
+            }
+        }
+        if (J.db && wc == 0) {
+            const float s = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (kk == 0) atomicAdd(J.db + (wr * MBW + m) * 32 + i32, s);
+        }
+    }
+}
+
+// sigma / rgb head weight gradients:  d w_sigma[W] = sum_r ds[r] * a_{L-1}[r][:],  d w_rgb[3][W/2] = sum_r dr[r][c] * d[r][:]
+__global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
+                                                    const float *__restrict__ dact, int W2, long row0, long n_rows,
+                                                    const int32_t *__restrict__ n_units_dev, int rows_per_unit,
+                                                    float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
+                                                    float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b) {
+    const long n = n_units_dev ? (long)(*n_units_dev) * rows_per_unit : n_rows;
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
+    if (rb >= re) return;
+    const long r0 = row0 + rb, r1 = row0 + re;
+    const int t = threadIdx.x;
+    for (int f0 = 0; f0 < W; f0 += 256) {                  // sigma head: thread t <-> feature f0 + t
+        const int f = f0 + t;
+        float s = 0.f;
+        if (f < W) for (long r = r0; r < r1; ++r) s = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s);
+        if (f < W) atomicAdd(d_sigma_w + f, s);
+    }
+    for (int f0 = 0; f0 < W2; f0 += 256) {                 // rgb head
+        const int f = f0 + t;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (f < W2) {
+            for (long r = r0; r < r1; ++r) {
+                const float d = dact[r * W2 + f];
+                s0 = fmaf(dheads[r * 4 + 0], d, s0); s1 = fmaf(dheads[r * 4 + 1], d, s1); s2 = fmaf(dheads[r * 4 + 2], d, s2);
+            }
+            atomicAdd(d_rgb_w + f, s0); atomicAdd(d_rgb_w + W2 + f, s1); atomicAdd(d_rgb_w + 2 * W2 + f, s2);
+        }
+    }
+    if (t < 4) {                                           // biases
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += dheads[r * 4 + t];
+        atomicAdd(t < 3 ? d_rgb_b + t : d_sigma_b, s);
+    }
+}
+
+template <class C>
+static int launch_bwd(const BwdLayout &b, const ModelLayout &m, MlpBwdArgs &a, long n_rows_cap, hipStream_t stream) {
+    constexpr int ROWS_D = cdiv(C::W + C::APP, 4 * C::TILE) * 4 * C::TILE;
+    if (b.tile != C::TILE || b.layer[0].n_rows_pad != ROWS_D || b.layer[1].gpc != C::GPC || b.n_layers != C::NL + 1)
+        return set_err(MNR_E_INVALID, "internal: backward kernel template / layout mismatch");
+    a.sigma_off = m.sigma_off;
+    a.rgb_off = m.rgb_off;
+    const long nwg = (n_rows_cap + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+    if (nwg <= 0) return MNR_OK;
+    hipLaunchKernelGGL(k_mlp_bwd<C>, dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
+    return check_launch("k_mlp_bwd");
+}
+
+}  // namespace mnr
+
+using namespace mnr;
+
+extern "C" size_t mnr_packed_bwd_bytes(const mnr_model_desc *d) {
+    BwdLayout b;
+    if (bwd_layout_from_desc(d, b) != MNR_OK) return 0;
+    return packed_bwd_bytes(b);
+}
+
+extern "C" int mnr_pack_model_bwd(void *packed_dev, size_t bytes, const mnr_model_desc *d, void *stream) {
+    BwdLayout b;
+    int rc = bwd_layout_from_desc(d, b);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(packed_dev && bytes >= packed_bwd_bytes(b), "backward packed buffer missing or too small");
+    for (int i = 0; i < b.n_layers; ++i) MNR_REQUIRE(b.layer[i].w, "missing weight pointer for backward layer %d", i);
+    const long total = (long)b.total_chunks * CHUNK_F4;
+    hipLaunchKernelGGL(k_pack_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), b,
+                       reinterpret_cast<float4 *>(packed_dev));
+    return check_launch("k_pack_bwd");
+}
+
+static int check_grad_io(const mnr_model_desc *d, const mnr_mlp_grad_io *io) {
+    MNR_REQUIRE(io, "NULL argument");
+    MNR_REQUIRE(io->tape && io->gtape && io->dheads, "NULL tape / gradient pointer");
+    MNR_REQUIRE(io->tape_row0 >= 0 && io->tape_rows >= io->tape_row0 + io->n_rows && io->rows_per_ray >= 1,
+                "bad tape capacity / row offset / rows_per_ray");
+    (void)d;
+    return MNR_OK;
+}
+
+extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev, const mnr_model_desc *d,
+                                     const mnr_mlp_grad_io *io, void *stream) {
+    ModelLayout m;
+    BwdLayout b;
+    int rc = layout_from_desc(d, m);
+    if (rc != MNR_OK) return rc;
+    rc = bwd_layout_from_desc(d, b);
+    if (rc != MNR_OK) return rc;
+    rc = check_grad_io(d, io);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(packed_fwd_dev && packed_bwd_dev && io->d_out && io->out, "NULL argument");
+    MNR_REQUIRE(d->appearance_dim == 0 || io->idx, "image indices required");
+    hipStream_t s = as_stream(stream);
+    MlpBwdArgs a{};
+    a.chunks = reinterpret_cast<const float4 *>(packed_bwd_dev);
+    a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed_fwd_dev) + (size_t)m.total_chunks * CHUNK_BYTES);
+    a.tape = io->tape; a.gtape = io->gtape; a.tape_rows = io->tape_rows; a.tl = tape_layout(arch_of(d));
+    a.d_out = io->d_out; a.d_out_stride = io->d_out_stride; a.out = io->out; a.out_stride = io->out_stride;
+    a.dheads = io->dheads; a.d_emb_a = io->grad.embedding_a;
+    a.idx = io->idx; a.idx_stride = io->idx_stride; a.idx_is_float = io->idx_is_float;
+    a.rows_per_ray = io->rows_per_ray; a.app_count = d->appearance_count; a.sigma_act = d->sigma_activation;
+    a.n_rows = io->n_rows; a.n_units_dev = io->n_units_dev; a.rows_per_unit = io->rows_per_unit;
+    a.tape_row0 = io->tape_row0;
+    rc = MNR_E_UNSUPPORTED;
+#define MNR_TRY_B(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                      \
+    if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&        \
+        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL)      \
+        rc = launch_bwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(b, m, a, io->n_rows, s);
+    MNR_TRY_B(3, 12, 4, 48, 256, 8, 16, 3, 16)
+    MNR_TRY_B(4, 12, 4, 48, 256, 8, 16, 3, 16)
+#undef MNR_TRY_B
+    if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "
+                                                   "default 8x256 fg/bg models)");
+    return rc;
+}
+
+extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_grad_io *io, void *stream) {
+    ModelLayout m;
+    int rc = layout_from_desc(d, m);
+    if (rc != MNR_OK) return rc;
+    rc = check_grad_io(d, io);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(m.has_final, "training needs a model with the dir/appearance branch");
+    hipStream_t s = as_stream(stream);
+    const TapeLayout tl = tape_layout(arch_of(d));
+    // weight gradients: one launch over a job table
+    const mnr_model_grads &G = io->grad;
+    const int W = d->layer_dim, L = d->layers;
+    const int Ecols = emb_cols(d->xyz_dim, d->pos_xyz_dim), EDcols = emb_cols(3, d->pos_dir_dim);
+    const long cap = io->tape_rows;
+    WgradArgs wa{};
+    int nj = 0;
+    auto add = [&](const float *dz, int M, const float *in, int ldin, int N, float *dw, int ldw, int col0, float *db) {
+        WgradJob &J = wa.job[nj++];
+        J.dz = dz; J.ldz = M; J.M = M; J.in = in; J.ldin = ldin; J.N = N; J.dw = dw; J.ldw = ldw; J.col0 = col0; J.db = db;
+    };
+    for (int l = 0; l < L; ++l) {
+        MNR_REQUIRE(G.layer_w[l] && G.layer_b[l], "missing gradient pointer for layer %d", l);
+        const float *dz = io->gtape + (long)tl.act_off[l] * cap;
+        const bool skip = (d->skip_mask >> l) & 1;
+        if (l == 0) {
+            add(dz, W, io->tape + (long)tl.embx_off * cap, tl.embx_w, Ecols, G.layer_w[l], Ecols, 0, G.layer_b[l]);
+        } else {
+            const int ldw = skip ? Ecols + W : W;
+            if (skip) add(dz, W, io->tape + (long)tl.embx_off * cap, tl.embx_w, Ecols, G.layer_w[l], ldw, 0, nullptr);
+            add(dz, W, io->tape + (long)tl.act_off[l - 1] * cap, W, W, G.layer_w[l], ldw, skip ? Ecols : 0, G.layer_b[l]);
+        }
+    }
+    MNR_REQUIRE(G.final_w && G.final_b && G.dir_a_w && G.dir_a_b && G.sigma_w && G.sigma_b && G.rgb_w && G.rgb_b,
+                "missing head / final gradient pointers");
+    add(io->gtape + (long)tl.fin_off * cap, W, io->tape + (long)tl.act_off[L - 1] * cap, W, W, G.final_w, W, 0, G.final_b);
+    {
+        const float *dz = io->gtape + (long)tl.dact_off * cap;
+        const int ldw = W + EDcols + d->appearance_dim;
+        add(dz, W / 2, io->tape + (long)tl.fin_off * cap, W, W, G.dir_a_w, ldw, 0, G.dir_a_b);
+        if (EDcols) add(dz, W / 2, io->tape + (long)tl.embd_off * cap, tl.embd_w, EDcols, G.dir_a_w, ldw, W, nullptr);
+        if (d->appearance_dim) add(dz, W / 2, io->tape + (long)tl.app_off * cap, tl.app_w, d->appearance_dim, G.dir_a_w, ldw,
+                                   W + EDcols, nullptr);
+    }
+    // distribute ~2 x 256 workgroups over the jobs in proportion to M * N (cost per row)
+    double tot = 0;
+    for (int i = 0; i < nj; ++i) tot += (double)wa.job[i].M * ((wa.job[i].N + 31) / 32 * 32);
+    int wg = 0;
+    const long tiles = (io->n_rows + WG_KT - 1) / WG_KT;
+    size_t lds = 0;
+    for (int i = 0; i < nj; ++i) {
+        WgradJob &J = wa.job[i];
+        int n = (int)(512.0 * J.M * ((J.N + 31) / 32 * 32) / tot + 0.5);
+        n = n < 1 ? 1 : n;
+        if (n > tiles) n = (int)(tiles < 1 ? 1 : tiles);
+        J.wg0 = wg; J.nwg = n; wg += n;
+        const size_t need = (size_t)(WG_KT * J.M + WG_KT * J.ldin + 160) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    wa.njobs = nj;
+    wa.n_rows = io->n_rows; wa.n_units_dev = io->n_units_dev; wa.rows_per_unit = io->rows_per_unit;
+    wa.row0 = io->tape_row0;
+    if (io->n_rows > 0) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad): %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(256), lds, s, wa);
+        rc = check_launch("k_wgrad");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_head_grads, dim3(256), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[L - 1] * cap, W,
+                           io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev, io->rows_per_unit,
+                           G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b);
+        rc = check_launch("k_head_grads");
+    }
+    return rc;
+}

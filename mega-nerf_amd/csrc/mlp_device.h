@@ -1,0 +1,172 @@
+// mlp_device.h -- device-side building blocks shared by the fused MLP forward (mlp_fwd.hip) and the
+// backward data-gradient chain (mlp_bwd.hip): MFMA segment runner, LDS-DMA weight stream, encoders.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace mnr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int XYZ_, int LX_, int LD_, int APP_, int W_, int NL_, int SKIP_, int RGB_, int TILE_ = tile_for_width(W_)>
+struct MlpCfg {
+    static constexpr int XYZ = XYZ_, LX = LX_, LD = LD_, APP = APP_, W = W_, NL = NL_, SKIP = SKIP_, RGB = RGB_;
+    static constexpr int TILE = TILE_, P = 64 / TILE;
+    static constexpr int RPB = TILE * TILE / 64;                 // accumulator registers per output block
+    static constexpr int H = hid_regs(W_, P);                    // hidden registers per lane
+    static constexpr int NOB = W_ / TILE;
+    static constexpr int EX = emb_regs(XYZ_, LX_, P);
+    static constexpr bool HAS_FINAL = (LD_ > 0 || APP_ > 0);
+    static constexpr int ED = emb_regs(3, LD_, P);
+    static constexpr int AP = app_regs(APP_, P);
+    static constexpr int NOB2 = (W_ / 2) / TILE;
+    static constexpr int H2 = HAS_FINAL ? (W_ / 2) / P : H;      // inputs of the rgb head per lane
+    static constexpr int GPC = CHUNK_F4 / (NOB * 64);
+    static constexpr int GPC2 = HAS_FINAL ? CHUNK_F4 / (NOB2 * 64) : 1;
+    static constexpr int ROWS_PER_WG = 4 * TILE;
+};
+
+
+
+// ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
+// `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at
+// (wave-uniform LDS base) + lane*16 -- the packed image is lane-linear, so no staging registers and no
+// ds_write pass are needed.  The barrier that publishes chunk c also proves every wave has finished
+// reading the buffer chunk c+1 is then loaded into (2-deep ring).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_cvoid_t;
+
+struct WStream {
+    const float4 *g;     // this thread's slice of the next chunk to load
+    float4 *lds;         // base of the 2-chunk LDS ring
+    int cur;             // buffer the MFMAs currently read
+    __device__ __forceinline__ void issue() {
+        const int wave = threadIdx.x >> 6;
+        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;      // wave-uniform base; HW adds lane*16
+#pragma unroll
+        for (int i = 0; i < CHUNK_F4 / 256; ++i)
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * 256), (lds_void_t *)(dst + i * 256), 16, 0, 0);
+        g += CHUNK_F4;
+    }
+    // publish the chunk in flight (hipcc drains vmcnt before the barrier), make it current, start the next one
+    __device__ __forceinline__ void next_chunk() {
+        __syncthreads();
+        cur ^= 1;
+        issue();
+    }
+};
+
+// One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
+// G0 = index of the segment's first group inside the layer (chunk boundaries are static).
+template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB>
+__device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], WStream &st, int lane) {
+    static_assert(NB >= 4 * NG, "B register array too small");
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = G0 + decltype(gi)::value;
+        constexpr int gl = decltype(gi)::value;
+        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
+        const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
+        if constexpr (TILE == 32) {
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const float4 a = p[ob * 64];
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * gl + 0], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * gl + 1], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * gl + 2], acc[ob], 0, 0, 0);
+                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * gl + 3], acc[ob], 0, 0, 0);
+            }
+        } else {
+            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk all blocks per k step
+            // (in batches of OBB blocks so that the A fragments stay within OBB*4 registers)
+            constexpr int OBB = NOB < 4 ? NOB : 4;
+            static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
+#pragma unroll
+            for (int o0 = 0; o0 < NOB; o0 += OBB) {
+                float4 a[OBB];
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) a[ob] = p[(o0 + ob) * 64];
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[o0 + ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[o0 + ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[o0 + ob], 0, 0, 0);
+#pragma unroll
+                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[o0 + ob], 0, 0, 0);
+            }
+        }
+    });
+}
+
+template <int NOB, int RPB, class AccT>
+__device__ __forceinline__ void init_acc(AccT (&acc)[NOB], const float *bias_part) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int q = 0; q < RPB / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(bias_part + ob * RPB + 4 * q);
+            acc[ob][4 * q + 0] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
+        }
+    }
+}
+
+template <int NOB, int RPB, bool RELU, class AccT, int NH>
+__device__ __forceinline__ void acc_to_regs(float (&h)[NH], const AccT (&acc)[NOB]) {
+    static_assert(NH >= NOB * RPB, "register array too small");
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) h[ob * RPB + r] = RELU ? fmaxf(acc[ob][r], 0.f) : acc[ob][r];
+}
+
+// Positional encoding of D coordinates into this lane's registers (layout: mlp_layout.h emb_src).
+template <int D, int L, int P, int NE>
+__device__ __forceinline__ void embed(float (&e)[NE], const float (&x)[D], int part) {
+    constexpr int NP = emb_pairs(D, L, P);
+    static_assert(NE == emb_regs(D, L, P), "embedding register count");
+    float xs[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xs[d] = ldexpf(x[d], part * (L / P));     // exact: power-of-two scale
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const float arg = xs[i % D] * (float)(1 << (i / D));              // == fl(2^f * x), nerf.py:22-23
+        float s, c;
+        sincosf(arg, &s, &c);
+        e[2 * i] = s;
+        e[2 * i + 1] = c;
+    }
+#pragma unroll
+    for (int j = 2 * NP; j < NE; ++j) {
+        const int dim = (j - 2 * NP) * P + part;
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) v = (dim == d && (j - 2 * NP) < cdiv(D, P)) ? x[d] : v;
+        e[j] = v;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ float reduce_parts(float v) {
+    v += __shfl_xor(v, 32);
+    if constexpr (P == 4) v += __shfl_xor(v, 16);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_shifted(float x) {   // F.softplus(x - 1, beta=1, threshold=20), nerf.py:38
+    const float y = x - 1.f;
+    return y > 20.f ? y : log1pf(expf(y));
+}
+
+}  // namespace mnr

@@ -11,43 +11,11 @@
 // 8 trunk layers (+skip), sigma head (VALU dot + cross-lane add), xyz_encoding_final, dir/appearance
 // layer, rgb head, sigmoid / shifted softplus -- nothing but the inputs (<= 36 B) and the 16 B result
 // touches HBM.
-#include <type_traits>
-
-#include "common.h"
-#include "mlp_layout.h"
+#include "mlp_device.h"
 
 namespace mnr {
 
 int layout_from_desc(const mnr_model_desc *d, ModelLayout &m);
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
-template <int XYZ_, int LX_, int LD_, int APP_, int W_, int NL_, int SKIP_, int RGB_, int TILE_ = tile_for_width(W_)>
-struct MlpCfg {
-    static constexpr int XYZ = XYZ_, LX = LX_, LD = LD_, APP = APP_, W = W_, NL = NL_, SKIP = SKIP_, RGB = RGB_;
-    static constexpr int TILE = TILE_, P = 64 / TILE;
-    static constexpr int RPB = TILE * TILE / 64;                 // accumulator registers per output block
-    static constexpr int H = hid_regs(W_, P);                    // hidden registers per lane
-    static constexpr int NOB = W_ / TILE;
-    static constexpr int EX = emb_regs(XYZ_, LX_, P);
-    static constexpr bool HAS_FINAL = (LD_ > 0 || APP_ > 0);
-    static constexpr int ED = emb_regs(3, LD_, P);
-    static constexpr int AP = app_regs(APP_, P);
-    static constexpr int NOB2 = (W_ / 2) / TILE;
-    static constexpr int H2 = HAS_FINAL ? (W_ / 2) / P : H;      // inputs of the rgb head per lane
-    static constexpr int GPC = CHUNK_F4 / (NOB * 64);
-    static constexpr int GPC2 = HAS_FINAL ? CHUNK_F4 / (NOB2 * 64) : 1;
-    static constexpr int ROWS_PER_WG = 4 * TILE;
-};
 
 struct MlpFwdArgs {
     const float4 *chunks;
@@ -57,136 +25,36 @@ struct MlpFwdArgs {
     int32_t bias_off[MAX_MFMA_LAYERS];
     int32_t sigma_off, rgb_off;
     int32_t sigma_act, app_count;
+    float *tape;              // training only: activation tape (TapeLayout planes), else NULL
+    long tape_rows;           // row capacity of every tape plane
+    long tape_row0;           // tape row of this launch's row 0
+    TapeLayout tl;
 };
 
-// ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
-// `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at
-// (wave-uniform LDS base) + lane*16 -- the packed image is lane-linear, so no staging registers and no
-// ds_write pass are needed.  The barrier that publishes chunk c also proves every wave has finished
-// reading the buffer chunk c+1 is then loaded into (2-deep ring).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_cvoid_t;
-
-struct WStream {
-    const float4 *g;     // this thread's slice of the next chunk to load
-    float4 *lds;         // base of the 2-chunk LDS ring
-    int cur;             // buffer the MFMAs currently read
-    __device__ __forceinline__ void issue() {
-        const int wave = threadIdx.x >> 6;
-        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;      // wave-uniform base; HW adds lane*16
+// tape stores (training): flat register i of a C-layout array <-> feature 4P*(i/4) + 4*part + i%4
+template <int P, int NH>
+__device__ __forceinline__ void tape_store_regs(float *plane, long row, int width, const float (&h)[NH], int part) {
+    float *r = plane + row * width + 4 * part;
 #pragma unroll
-        for (int i = 0; i < CHUNK_F4 / 256; ++i)
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * 256), (lds_void_t *)(dst + i * 256), 16, 0, 0);
-        g += CHUNK_F4;
-    }
-    // publish the chunk in flight (hipcc drains vmcnt before the barrier), make it current, start the next one
-    __device__ __forceinline__ void next_chunk() {
-        __syncthreads();
-        cur ^= 1;
-        issue();
-    }
-};
-
-// One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
-// G0 = index of the segment's first group inside the layer (chunk boundaries are static).
-template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB>
-__device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], WStream &st, int lane) {
-    static_assert(NB >= 4 * NG, "B register array too small");
-    static_for<0, NG>([&](auto gi) {
-        constexpr int g = G0 + decltype(gi)::value;
-        constexpr int gl = decltype(gi)::value;
-        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
-        const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
-        if constexpr (TILE == 32) {
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) {
-                const float4 a = p[ob * 64];
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * gl + 0], acc[ob], 0, 0, 0);
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * gl + 1], acc[ob], 0, 0, 0);
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * gl + 2], acc[ob], 0, 0, 0);
-                acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * gl + 3], acc[ob], 0, 0, 0);
-            }
-        } else {
-            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk all blocks per k step
-            // (in batches of OBB blocks so that the A fragments stay within OBB*4 registers)
-            constexpr int OBB = NOB < 4 ? NOB : 4;
-            static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
-#pragma unroll
-            for (int o0 = 0; o0 < NOB; o0 += OBB) {
-                float4 a[OBB];
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) a[ob] = p[(o0 + ob) * 64];
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[o0 + ob], 0, 0, 0);
-            }
-        }
-    });
+    for (int q = 0; q < NH / 4; ++q)
+        *reinterpret_cast<float4 *>(r + 4 * P * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
 }
-
-template <int NOB, int RPB, class AccT>
-__device__ __forceinline__ void init_acc(AccT (&acc)[NOB], const float *bias_part) {
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-#pragma unroll
-        for (int q = 0; q < RPB / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(bias_part + ob * RPB + 4 * q);
-            acc[ob][4 * q + 0] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
-        }
-    }
-}
-
-template <int NOB, int RPB, bool RELU, class AccT, int NH>
-__device__ __forceinline__ void acc_to_regs(float (&h)[NH], const AccT (&acc)[NOB]) {
-    static_assert(NH >= NOB * RPB, "register array too small");
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-        for (int r = 0; r < RPB; ++r) h[ob * RPB + r] = RELU ? fmaxf(acc[ob][r], 0.f) : acc[ob][r];
-}
-
-// Positional encoding of D coordinates into this lane's registers (layout: mlp_layout.h emb_src).
+// positional-encoding registers -> reference column order (nerf.py:20-25)
 template <int D, int L, int P, int NE>
-__device__ __forceinline__ void embed(float (&e)[NE], const float (&x)[D], int part) {
+__device__ __forceinline__ void tape_store_emb(float *plane, long row, int width, const float (&e)[NE], int part) {
     constexpr int NP = emb_pairs(D, L, P);
-    static_assert(NE == emb_regs(D, L, P), "embedding register count");
-    float xs[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xs[d] = ldexpf(x[d], part * (L / P));     // exact: power-of-two scale
+    float *r = plane + row * width;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const float arg = xs[i % D] * (float)(1 << (i / D));              // == fl(2^f * x), nerf.py:22-23
-        float s, c;
-        sincosf(arg, &s, &c);
-        e[2 * i] = s;
-        e[2 * i + 1] = c;
+        const int col = D + (part * (L / P) + i / D) * 2 * D + i % D;
+        r[col] = e[2 * i];
+        r[col + D] = e[2 * i + 1];
     }
 #pragma unroll
-    for (int j = 2 * NP; j < NE; ++j) {
-        const int dim = (j - 2 * NP) * P + part;
-        float v = 0.f;
-#pragma unroll
-        for (int d = 0; d < D; ++d) v = (dim == d && (j - 2 * NP) < cdiv(D, P)) ? x[d] : v;
-        e[j] = v;
+    for (int j = 0; j < cdiv(D, P); ++j) {
+        const int dim = j * P + part;
+        if (dim < D) r[dim] = e[2 * NP + j];
     }
-}
-
-template <int P>
-__device__ __forceinline__ float reduce_parts(float v) {
-    v += __shfl_xor(v, 32);
-    if constexpr (P == 4) v += __shfl_xor(v, 16);
-    return v;
-}
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float softplus_shifted(float x) {   // F.softplus(x - 1, beta=1, threshold=20), nerf.py:38
-    const float y = x - 1.f;
-    return y > 20.f ? y : log1pf(expf(y));
 }
 
 // spherical_harmonics.py:55-107 (deg <= 4), coefficients c[k] for one colour channel
@@ -219,7 +87,7 @@ __device__ __forceinline__ float eval_sh_channel(int deg, const float *c, float 
     return r;
 }
 
-template <class C>
+template <class C, bool TRAIN>
 __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_fwd(MlpFwdArgs a) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
@@ -247,6 +115,9 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[rc * io.xyz_stride + d];
     float ex[C::EX];
     embed<C::XYZ, C::LX, P>(ex, x, part);
+    if constexpr (TRAIN) {
+        if (valid) tape_store_emb<C::XYZ, C::LX, P>(a.tape + a.tl.embx_off * a.tape_rows, row + a.tape_row0, a.tl.embx_w, ex, part);
+    }
 
     float h[H];
     AccT acc[NOB];
@@ -266,6 +137,9 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
+        if constexpr (TRAIN) {
+            if (valid) tape_store_regs<P>(a.tape + a.tl.act_off[l] * a.tape_rows, row + a.tape_row0, C::W, h, part);
+        }
     });
     li = C::NL;
 
@@ -297,6 +171,9 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         st.next_chunk();
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
         acc_to_regs<NOB, RPB, false>(h, acc);                    // xyz_encoding_final: no activation
+        if constexpr (TRAIN) {
+            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, row + a.tape_row0, C::W, h, part);
+        }
         ++li;
 
         constexpr int NOB2 = C::NOB2, H2 = C::H2;
@@ -310,6 +187,9 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
             float ed[C::ED];
             embed<3, C::LD, P>(ed, dv, part);
+            if constexpr (TRAIN) {
+                if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, row + a.tape_row0, a.tl.embd_w, ed, part);
+            }
             run_segment<TILE, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane);
         }
         if constexpr (C::AP > 0) {
@@ -320,10 +200,20 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             float ap[C::AP];
 #pragma unroll
             for (int i = 0; i < C::AP; ++i) ap[i] = (i < C::APP / P) ? ea[i] : 0.f;
+            if constexpr (TRAIN) {
+                if (valid) {
+                    float *r = a.tape + a.tl.app_off * a.tape_rows + (row + a.tape_row0) * a.tl.app_w + part * (C::APP / P);
+#pragma unroll
+                    for (int i = 0; i < C::APP / P; ++i) r[i] = ap[i];
+                }
+            }
             run_segment<TILE, NOB2, C::AP / 4, C::GPC2, H / 4 + C::ED / 4>(acc2, ap, st, lane);
         }
         float dreg[H2];
         acc_to_regs<NOB2, RPB, true>(dreg, acc2);
+        if constexpr (TRAIN) {
+            if (valid) tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, row + a.tape_row0, C::W / 2, dreg, part);
+        }
 #pragma unroll
         for (int c = 0; c < C::RGB; ++c) {
             float s = 0.f;
@@ -369,9 +259,9 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     }
 }
 
-template <class C>
+template <class C, bool TRAIN = false>
 static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
-                      hipStream_t stream) {
+                      hipStream_t stream, float *tape = nullptr, long tape_rows = 0, long tape_row0 = 0) {
     // the template's static structure must agree with the runtime layout the packer used
     if (m.tile != C::TILE || m.layer[0].nsteps != C::EX || m.layer[0].gpc != C::GPC || m.has_final != (int)C::HAS_FINAL ||
         m.rgb_in_regs != C::H2 || m.n_mfma_layers != C::NL + (C::HAS_FINAL ? 2 : 0))
@@ -388,9 +278,14 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     a.rgb_off = m.rgb_off;
     a.sigma_act = d->sigma_activation;
     a.app_count = d->appearance_count;
+    a.tape = tape;
+    a.tape_rows = tape_rows;
+    a.tape_row0 = tape_row0;
+    a.tl = tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
+                                d->appearance_dim, d->rgb_dim, d->mfma_tile});
     const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
     if (nwg <= 0) return MNR_OK;
-    hipLaunchKernelGGL(k_mlp_fwd<C>, dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
+    hipLaunchKernelGGL((k_mlp_fwd<C, TRAIN>), dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
     return check_launch("k_mlp_fwd");
 }
 
@@ -398,7 +293,29 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
 
 using namespace mnr;
 
+static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
+                            float *tape, long tape_rows, long tape_row0);
+
 extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream) {
+    return mlp_forward_impl(packed_dev, d, io, stream, nullptr, 0, 0);
+}
+
+extern "C" int mnr_mlp_forward_train(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io,
+                                     float *tape_dev, int64_t tape_rows, int64_t tape_row0, void *stream) {
+    MNR_REQUIRE(tape_dev && io && tape_row0 >= 0 && tape_rows >= tape_row0 + io->n_rows, "tape buffer missing or too small");
+    MNR_REQUIRE(!io->sigma_only, "sigma_only has no training variant");
+    return mlp_forward_impl(packed_dev, d, io, stream, tape_dev, (long)tape_rows, (long)tape_row0);
+}
+
+extern "C" int64_t mnr_tape_floats_per_row(const mnr_model_desc *d) {
+    ModelLayout m;
+    if (layout_from_desc(d, m) != MNR_OK) return -1;
+    return tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
+                                d->appearance_dim, d->rgb_dim, d->mfma_tile}).floats_per_row;
+}
+
+static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
+                            float *tape, long tape_rows, long tape_row0) {
     ModelLayout m;
     int rc = layout_from_desc(d, m);
     if (rc != MNR_OK) return rc;
@@ -413,12 +330,19 @@ extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, 
     hipStream_t s = as_stream(stream);
 #define MNR_TRY_T(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                     \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
-        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL)     \
+        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL && !tape) \
         return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(m, packed_dev, d, io, s);
+#define MNR_TRY_TRAIN(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                 \
+    if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
+        d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL && tape) \
+        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>, true>(m, packed_dev, d, io, s, tape, tape_rows, tape_row0);
 #define MNR_TRY(XYZ, LX, LD, APP, W, NL, SKIP, RGB) MNR_TRY_T(XYZ, LX, LD, APP, W, NL, SKIP, RGB, tile_for_width(W))
     // configs/mega-nerf/*.yaml (opts.py defaults): fg / bg
     MNR_TRY(3, 12, 4, 48, 256, 8, 16, 3)
     MNR_TRY(4, 12, 4, 48, 256, 8, 16, 3)
+    // ... and their training variants (forward pass that also writes the activation tape)
+    MNR_TRY_TRAIN(3, 12, 4, 48, 256, 8, 16, 3, 16)
+    MNR_TRY_TRAIN(4, 12, 4, 48, 256, 8, 16, 3, 16)
     // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
     MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)
     MNR_TRY_T(4, 12, 4, 48, 256, 8, 16, 3, 32)
@@ -439,6 +363,7 @@ extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, 
 #endif
 #undef MNR_TRY
 #undef MNR_TRY_T
+#undef MNR_TRY_TRAIN
     return set_err(MNR_E_UNSUPPORTED,
                    "no fused MLP kernel for xyz_dim=%d pos_xyz_dim=%d pos_dir_dim=%d appearance_dim=%d layer_dim=%d "
                    "layers=%d skip_mask=%d rgb_dim=%d",

@@ -15,6 +15,7 @@
 // Packed image = sequence of fixed-size CHUNKs (32 KiB) in consumption order; a layer starts on a
 // chunk boundary; chunk = up to GPC groups x NOB output blocks x 64 lanes x float4.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -177,5 +178,91 @@ inline int build_layout(const ArchDims &a, ModelLayout &m, const char **err) {
 inline size_t packed_bytes(const ModelLayout &m) {
     return (size_t)m.total_chunks * CHUNK_BYTES + (size_t)m.aux_floats * 4;
 }
+
+// ---- training tape: what the forward pass keeps for the backward pass ---------------------------
+// Row-major planes [rows_cap][width]; plane p starts at float offset off_p * rows_cap.
+//   act[l]  post-ReLU output of trunk layer l (width W)      -> ReLU masks + wgrad inputs
+//   fin     xyz_encoding_final output (W), dact: dir_a post-ReLU (W/2)
+//   embx / embd: positional encodings in REFERENCE column order (nerf.py:20-25), app: gathered embedding_a rows
+struct TapeLayout {
+    int32_t act_off[16];
+    int32_t fin_off, dact_off, embx_off, embd_off, app_off;
+    int32_t embx_w, embd_w, app_w;
+    int32_t floats_per_row;
+};
+inline TapeLayout tape_layout(const ArchDims &a) {
+    TapeLayout t{};
+    int off = 0;
+    for (int l = 0; l < a.layers; ++l) { t.act_off[l] = off; off += a.W; }
+    const bool has_final = a.pos_dir_dim > 0 || a.app_dim > 0;
+    t.fin_off = off; off += has_final ? a.W : 0;
+    t.dact_off = off; off += has_final ? a.W / 2 : 0;
+    t.embx_w = pad4(emb_cols(a.xyz_dim, a.pos_xyz_dim));
+    t.embx_off = off; off += t.embx_w;
+    t.embd_w = pad4(emb_cols(3, a.pos_dir_dim));
+    t.embd_off = off; off += t.embd_w;
+    t.app_w = pad4(a.app_dim);
+    t.app_off = off; off += t.app_w;
+    t.floats_per_row = off;
+    return t;
+}
+
+// ---- backward (data-gradient) weight stream: transposed layers in reverse order -------------------
+//   bwd layer 0: dir_a^T   rows = [final features (W) | appearance inputs (A)], K = dir_a outputs (W/2)
+//   bwd layer 1: final^T   rows = W, K = W
+//   bwd layer 2+j: trunk layer (L-1-j)^T for j = 0 .. L-2 (hidden-input columns only), rows = W, K = W
+// Packed A operand element (row r, step s, part p) = weight[out = hid_src(P, s, p)][in = in_col(r)].
+struct BwdLayerLayout {
+    int32_t n_rows, n_rows_pad, nsteps, ngroups, nob, gpc, chunk0, nchunks;
+    int32_t ld, in_off, in_off2, split;     // in_col(r) = r < split ? in_off + r : in_off2 + (r - split)
+    const float *w;
+};
+struct BwdLayout {
+    int32_t tile, parts, W, n_layers, has_final, total_chunks;
+    int32_t app_rows;                        // appearance-gradient rows appended to dir_a^T (0 if none)
+    BwdLayerLayout layer[MAX_MFMA_LAYERS];
+};
+inline int build_bwd_layout(const ArchDims &a, BwdLayout &b, const char **err) {
+    ModelLayout m;
+    if (build_layout(a, m, err)) return -1;
+    b = BwdLayout{};
+    const int tile = m.tile, P = m.parts;
+    b.tile = tile; b.parts = P; b.W = a.W; b.has_final = m.has_final;
+    const int Ecols = emb_cols(a.xyz_dim, a.pos_xyz_dim), EDcols = emb_cols(3, a.pos_dir_dim);
+    int chunk = 0, n = 0;
+    auto finish = [&](BwdLayerLayout &l, int n_rows, int k_feats) {
+        l.n_rows = n_rows;
+        l.n_rows_pad = cdiv(n_rows, 4 * tile) * 4 * tile;   // whole batches of 4 output blocks (run_segment)
+        l.nob = l.n_rows_pad / tile;
+        l.nsteps = k_feats / P;
+        l.ngroups = l.nsteps / 4;
+        l.gpc = CHUNK_F4 / (l.nob * 64);
+        if (l.gpc < 1) l.gpc = 1;
+        l.chunk0 = chunk;
+        l.nchunks = cdiv(l.ngroups, l.gpc);
+        chunk += l.nchunks;
+    };
+    if (m.has_final) {
+        BwdLayerLayout &d = b.layer[n++];
+        b.app_rows = a.app_dim;
+        d.ld = a.W + EDcols + a.app_dim; d.in_off = 0; d.split = a.W; d.in_off2 = a.W + EDcols;
+        finish(d, a.W + a.app_dim, a.W / 2);
+        BwdLayerLayout &f = b.layer[n++];
+        f.ld = a.W; f.in_off = 0; f.split = a.W; f.in_off2 = 0;
+        finish(f, a.W, a.W);
+    }
+    for (int l = a.layers - 1; l >= 1; --l) {
+        BwdLayerLayout &t = b.layer[n++];
+        const bool skip = (a.skip_mask >> l) & 1;
+        t.ld = skip ? Ecols + a.W : a.W; t.in_off = skip ? Ecols : 0; t.split = a.W; t.in_off2 = 0;
+        finish(t, a.W, a.W);
+    }
+    b.n_layers = n;
+    b.total_chunks = chunk + 1;
+    for (int i = 0; i < n; ++i)
+        if ((long)b.layer[i].nob * 64 * 16 > CHUNK_BYTES) { *err = "backward layer too wide for one chunk group"; return -1; }
+    return 0;
+}
+inline size_t packed_bwd_bytes(const BwdLayout &b) { return (size_t)b.total_chunks * CHUNK_BYTES; }
 
 }  // namespace mnr

@@ -556,3 +556,165 @@ extern "C" int mnr_bg_blend(float *rgb, float *depth, const float *lam, const in
                        bg_depth, (long)N, fg_rgb_o, bg_rgb_o, fg_depth_o, bg_depth_o);
     return check_launch("k_bg_blend");
 }
+
+// =================================================================================================
+// Backward of the rendering stages (training).  The reference gets these from autograd over
+// rendering.py:353-393 (compositing), :336-350 (sort/gather) and :102-131 (fg/bg blend).
+// =================================================================================================
+namespace mnr {
+
+// Compositing backward w.r.t. the raw MLP outputs, one wavefront per ray.
+//   rgb = sum_k w_k c_k,  w_k = alpha_k T_{k-1},  T_k = prod_{i<=k}(1 - alpha_i + 1e-8),  lambda = T_{S-1}
+//   dL/dc_k     = w_k * dL/drgb
+//   dL/dalpha_k = g_k T_{k-1} - (sum_{m>k} g_m w_m + dL/dlambda * lambda) / (1 - alpha_k + 1e-8),  g_k = dL/drgb . c_k
+//   dL/dsigma_k = dL/dalpha_k * delta_k * exp(-delta_k sigma_k)
+template <int E>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_composite_bwd(mnr_composite_grad_io io) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (ray >= unit_limit(io.N, io.n_units_dev)) return;
+    const int S = io.S;
+    const float *z = io.z + ray * S;
+    const float4 *raw = reinterpret_cast<const float4 *>(io.raw) + ray * S;
+    float last = io.last_delta ? io.last_delta[ray] : 1e10f;
+    if (io.zmax_src && last < 1e10f) {
+        float m = -INFINITY;
+        for (int i = lane; i < io.zmax_S; i += 64) m = fmaxf(m, io.zmax_src[ray * io.zmax_S + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        last = last - m;
+    }
+    const float gr = io.d_rgb[ray * 3 + 0], gg = io.d_rgb[ray * 3 + 1], gb = io.d_rgb[ray * 3 + 2];
+    const float dlam = io.d_bg_lambda ? io.d_bg_lambda[ray] : 0.f;
+    float alpha[E], ex[E], delta[E], tt[E];
+    float4 c[E];
+    double prod = 1.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        alpha[e] = 0.f; ex[e] = 1.f; delta[e] = 0.f; tt[e] = 1.f; c[e] = make_float4(0, 0, 0, 0);
+        if (k < S) {
+            const float zk = z[k];
+            c[e] = raw[k];
+            delta[e] = (k == S - 1) ? last : (io.flip ? zk - z[k + 1] : z[k + 1] - zk);
+            ex[e] = expf(-delta[e] * c[e].w);
+            alpha[e] = 1.f - ex[e];
+            tt[e] = 1.f - alpha[e] + 1e-8f;
+            prod *= (double)tt[e];
+        }
+    }
+    double incl = prod;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if (lane >= o) incl *= up;
+    }
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0;
+    const float lambda = (float)__shfl(incl, 63);
+    // forward weights and per-lane sums of g_k w_k
+    float T[E], w[E], gk[E];
+    double run = excl;
+    float gw_lane = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        T[e] = (float)run; w[e] = 0.f; gk[e] = 0.f;
+        if (k < S) {
+            w[e] = alpha[e] * T[e];
+            run *= (double)tt[e];
+            gk[e] = gr * c[e].x + gg * c[e].y + gb * c[e].z;
+            gw_lane += gk[e] * w[e];
+        }
+    }
+    // suffix sums: sum over lanes > this lane (exclusive), then within the lane from the back
+    float suf = gw_lane;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float dn = __shfl_down(suf, o);
+        if (lane + o < 64) suf += dn;
+    }
+    float after = suf - gw_lane;                 // sum of g_m w_m over all samples in higher lanes
+    float4 *dr = reinterpret_cast<float4 *>(io.d_raw) + ray * S;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        const int k = lane * E + e;
+        if (k < S) {
+            const float dalpha = gk[e] * T[e] - (after + dlam * lambda) / tt[e];
+            const float dsigma = dalpha * delta[e] * ex[e];
+            dr[k] = make_float4(w[e] * gr, w[e] * gg, w[e] * gb, dsigma);
+            after += gk[e] * w[e];
+        }
+    }
+}
+
+// scatter the merged-order gradient back to the fine / coarse arrays (inverse of k_merge_sorted)
+__global__ void k_merge_bwd(const float4 *__restrict__ d_merged, const int32_t *__restrict__ order, int Sa, int Sb, long N,
+                            const int32_t *__restrict__ n_dev, float4 *__restrict__ d_a, float4 *__restrict__ d_b) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int St = Sa + Sb;
+    if (i >= unit_limit(N, n_dev) * St) return;
+    const long ray = i / St;
+    const int e = order[i];
+    if (e < Sa) d_a[ray * Sa + e] = d_merged[i];
+    else d_b[ray * Sb + (e - Sa)] = d_merged[i];
+}
+
+// rgb = fg + lambda * bg[slot]:  d_lambda[ray] = d_rgb . bg[slot],  d_bg[slot] = lambda * d_rgb
+__global__ void k_bg_blend_bwd(const float *__restrict__ d_rgb, const float *__restrict__ lam, const int32_t *__restrict__ slot,
+                               const float *__restrict__ bg_rgb, long N, float *__restrict__ d_lambda,
+                               float *__restrict__ d_bg_rgb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int k = slot[i];
+    float dl = 0.f;
+    if (k >= 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dl += d_rgb[3 * i + c] * bg_rgb[3 * (long)k + c];
+            d_bg_rgb[3 * (long)k + c] = lam[i] * d_rgb[3 * i + c];
+        }
+    }
+    d_lambda[i] = dl;
+}
+
+}  // namespace mnr
+
+extern "C" int mnr_composite_backward(const mnr_composite_grad_io *io, void *stream) {
+    MNR_REQUIRE(io && io->z && io->raw && io->d_rgb && io->d_raw && io->S > 0 && io->N >= 0, "bad arguments to mnr_composite_backward");
+    MNR_REQUIRE(io->S <= 64 * 16, "at most 1024 samples per ray");
+    if (io->N == 0) return MNR_OK;
+    const int E = (io->S + 63) / 64;
+    const dim3 grid(nblk(io->N, WAVES_PER_BLOCK)), block(64 * WAVES_PER_BLOCK);
+    hipStream_t s = as_stream(stream);
+#define MNR_COMPB(EE) hipLaunchKernelGGL(k_composite_bwd<EE>, grid, block, 0, s, *io)
+    if (E <= 1) MNR_COMPB(1);
+    else if (E <= 2) MNR_COMPB(2);
+    else if (E <= 3) MNR_COMPB(3);
+    else if (E <= 4) MNR_COMPB(4);
+    else if (E <= 6) MNR_COMPB(6);
+    else if (E <= 8) MNR_COMPB(8);
+    else if (E <= 12) MNR_COMPB(12);
+    else MNR_COMPB(16);
+#undef MNR_COMPB
+    return check_launch("k_composite_bwd");
+}
+
+extern "C" int mnr_merge_backward(const float *d_merged, const int32_t *order, int Sa, int Sb, int64_t N, const int32_t *n_dev,
+                                  float *d_a, float *d_b, void *stream) {
+    MNR_REQUIRE(d_merged && order && d_a && d_b && Sa > 0 && Sb > 0 && N >= 0, "bad arguments to mnr_merge_backward");
+    if (N == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_merge_bwd, dim3(nblk((long)N * (Sa + Sb), 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(d_merged), order, Sa, Sb, (long)N, n_dev,
+                       reinterpret_cast<float4 *>(d_a), reinterpret_cast<float4 *>(d_b));
+    return check_launch("k_merge_bwd");
+}
+
+extern "C" int mnr_bg_blend_backward(const float *d_rgb, const float *lam, const int32_t *slot, const float *bg_rgb, int64_t N,
+                                     float *d_lambda, float *d_bg_rgb, void *stream) {
+    MNR_REQUIRE(d_rgb && lam && slot && bg_rgb && d_lambda && d_bg_rgb && N >= 0, "bad arguments to mnr_bg_blend_backward");
+    if (N == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_bg_blend_bwd, dim3(nblk(N, 256)), dim3(256), 0, as_stream(stream), d_rgb, lam, slot, bg_rgb, (long)N,
+                       d_lambda, d_bg_rgb);
+    return check_launch("k_bg_blend_bwd");
+}

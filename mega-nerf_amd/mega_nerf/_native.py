@@ -61,11 +61,38 @@ class CompositeIO(C.Structure):
     ]
 
 
+class ModelGrads(C.Structure):
+    """struct mnr_model_grads"""
+    _fields_ = [('layer_w', C.c_void_p * MNR_MAX_LAYERS), ('layer_b', C.c_void_p * MNR_MAX_LAYERS),
+                ('final_w', C.c_void_p), ('final_b', C.c_void_p), ('dir_a_w', C.c_void_p), ('dir_a_b', C.c_void_p),
+                ('sigma_w', C.c_void_p), ('sigma_b', C.c_void_p), ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p),
+                ('embedding_a', C.c_void_p)]
+
+
+class MlpGradIO(C.Structure):
+    """struct mnr_mlp_grad_io"""
+    _fields_ = [('tape', C.c_void_p), ('gtape', C.c_void_p), ('tape_rows', C.c_int64), ('tape_row0', C.c_int64),
+                ('d_out', C.c_void_p), ('d_out_stride', C.c_int64), ('out', C.c_void_p), ('out_stride', C.c_int64),
+                ('dheads', C.c_void_p), ('idx', C.c_void_p), ('idx_stride', C.c_int64), ('idx_is_float', C.c_int32),
+                ('rows_per_ray', C.c_int32), ('n_rows', C.c_int64), ('n_units_dev', C.c_void_p),
+                ('rows_per_unit', C.c_int32), ('grad', ModelGrads)]
+
+
+class CompositeGradIO(C.Structure):
+    """struct mnr_composite_grad_io"""
+    _fields_ = [('z', C.c_void_p), ('raw', C.c_void_p), ('last_delta', C.c_void_p), ('zmax_src', C.c_void_p),
+                ('zmax_S', C.c_int32), ('flip', C.c_int32), ('N', C.c_int64), ('n_units_dev', C.c_void_p),
+                ('S', C.c_int32), ('d_rgb', C.c_void_p), ('d_bg_lambda', C.c_void_p), ('d_raw', C.c_void_p)]
+
+
 EXPORTS = [
     'mnr_version', 'mnr_last_error', 'mnr_device_available', 'mnr_ray_directions', 'mnr_get_rays',
     'mnr_packed_model_bytes', 'mnr_pack_model', 'mnr_layout_src_col', 'mnr_layout_num_steps', 'mnr_layout_parts',
     'mnr_mlp_forward', 'mnr_ray_setup', 'mnr_fg_samples', 'mnr_fg_points', 'mnr_bg_samples', 'mnr_sample_pdf',
     'mnr_sample_fine', 'mnr_merge_sorted', 'mnr_sort_rows', 'mnr_composite', 'mnr_bg_blend',
+    'mnr_tape_floats_per_row', 'mnr_mlp_forward_train', 'mnr_packed_bwd_bytes', 'mnr_pack_model_bwd',
+    'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
+    'mnr_bg_blend_backward',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -113,6 +140,20 @@ def lib() -> C.CDLL:
                                        C.c_void_p]
         _lib.mnr_composite.argtypes = [C.POINTER(CompositeIO), C.c_void_p]
         _lib.mnr_bg_blend.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 5
+        _lib.mnr_tape_floats_per_row.restype = C.c_int64
+        _lib.mnr_tape_floats_per_row.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_mlp_forward_train.argtypes = [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(MlpIO), C.c_void_p, C.c_int64,
+                                               C.c_int64, C.c_void_p]
+        _lib.mnr_packed_bwd_bytes.restype = C.c_size_t
+        _lib.mnr_packed_bwd_bytes.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_pack_model_bwd.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
+        _lib.mnr_mlp_backward_data.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.POINTER(MlpGradIO),
+                                               C.c_void_p]
+        _lib.mnr_mlp_backward_weights.argtypes = [C.POINTER(ModelDesc), C.POINTER(MlpGradIO), C.c_void_p]
+        _lib.mnr_composite_backward.argtypes = [C.POINTER(CompositeGradIO), C.c_void_p]
+        _lib.mnr_merge_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        _lib.mnr_bg_blend_backward.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
     return _lib
 
 

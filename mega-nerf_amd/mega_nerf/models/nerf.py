@@ -137,6 +137,63 @@ class NeRF(nn.Module):
         N.check(N.lib().mnr_mlp_forward(packed.data_ptr(), C.byref(desc), C.byref(io), N.stream_ptr()))
         return out
 
+    # ---- training plumbing --------------------------------------------------------------------
+    def packed_bwd(self):
+        """Transposed weight image for the data-gradient chain (same cache key as :meth:`packed`)."""
+        desc, _ = self.packed()
+        key = self._packed_key
+        if getattr(self, '_packed_bwd', None) is None or self._packed_bwd_key != key:
+            nbytes = N.lib().mnr_packed_bwd_bytes(C.byref(desc))
+            if nbytes == 0:
+                raise N.NativeError(N.lib().mnr_last_error().decode())
+            if getattr(self, '_packed_bwd', None) is None or self._packed_bwd.numel() != nbytes:
+                self._packed_bwd = torch.empty(nbytes, dtype=torch.uint8, device=self._packed.device)
+            N.check(N.lib().mnr_pack_model_bwd(self._packed_bwd.data_ptr(), nbytes, C.byref(desc), N.stream_ptr()))
+            self._packed_bwd_key = key
+        return self._packed_bwd
+
+    def tape_floats_per_row(self) -> int:
+        n = N.lib().mnr_tape_floats_per_row(C.byref(self.model_desc()))
+        if n <= 0:
+            raise N.NativeError(N.lib().mnr_last_error().decode())
+        return int(n)
+
+    def mlp_io(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out, sigma_noise=None,
+               n_units_dev=None, rows_per_unit=0) -> 'N.MlpIO':
+        io = N.MlpIO()
+        io.xyz, io.xyz_stride = xyz.data_ptr(), xyz_stride
+        io.dir, io.dir_stride = (dirs.data_ptr() if dirs is not None else None), dir_stride
+        if idx is not None:
+            io.idx_is_float = 1 if idx.dtype == torch.float32 else 0
+            io.idx, io.idx_stride = idx.data_ptr(), idx_stride
+        io.rows_per_ray = rows_per_ray
+        io.sigma_noise = sigma_noise.data_ptr() if sigma_noise is not None else None
+        io.out, io.out_stride = out.data_ptr(), out.stride(0)
+        io.n_rows = n_rows
+        io.n_units_dev = n_units_dev.data_ptr() if n_units_dev is not None else None
+        io.rows_per_unit = rows_per_unit
+        io.apply_sh_deg = -1
+        return io
+
+    def evaluate_train(self, io: 'N.MlpIO', tape: torch.Tensor, tape_rows: int, tape_row0: int) -> None:
+        desc, packed = self.packed()
+        N.check(N.lib().mnr_mlp_forward_train(packed.data_ptr(), C.byref(desc), C.byref(io), tape.data_ptr(), tape_rows,
+                                              tape_row0, N.stream_ptr()))
+
+    def grad_struct(self, grads: dict) -> 'N.ModelGrads':
+        """mnr_model_grads pointing at ``grads[param_name]`` tensors (same shapes as the parameters)."""
+        g = N.ModelGrads()
+        for i in range(self.layers):
+            g.layer_w[i] = grads['xyz_encodings.%d.0.weight' % i].data_ptr()
+            g.layer_b[i] = grads['xyz_encodings.%d.0.bias' % i].data_ptr()
+        g.final_w, g.final_b = grads['xyz_encoding_final.weight'].data_ptr(), grads['xyz_encoding_final.bias'].data_ptr()
+        g.dir_a_w, g.dir_a_b = grads['dir_a_encoding.0.weight'].data_ptr(), grads['dir_a_encoding.0.bias'].data_ptr()
+        g.sigma_w, g.sigma_b = grads['sigma.weight'].data_ptr(), grads['sigma.bias'].data_ptr()
+        g.rgb_w, g.rgb_b = grads['rgb.weight'].data_ptr(), grads['rgb.bias'].data_ptr()
+        if self.embedding_a is not None:
+            g.embedding_a = grads['embedding_a.weight'].data_ptr()
+        return g
+
     # ---- reference API -----------------------------------------------------------------------
     def forward(self, x: torch.Tensor, sigma_only: bool = False,
                 sigma_noise: Optional[torch.Tensor] = None) -> torch.Tensor:

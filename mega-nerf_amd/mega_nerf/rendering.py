@@ -253,9 +253,9 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return s
 
 
-def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, get_depth,
-                get_depth_variance, rnd, dev, before_coarse=None):
-    """Background branch of render_rays (rendering.py:47-75) on the current stream."""
+def _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd, dev,
+                     before_coarse=None) -> _Part:
+    """Coarse background samples (rendering.py:47-56) for the compacted background rays, on the current stream."""
     lib = N.lib()
     Sb = hparams.coarse_samples // 2
     include_xyz_real = hparams.container_path is not None or hparams.train_mega_nerf is not None
@@ -283,9 +283,15 @@ def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_ra
                                    int(cluster_2d), None, p.data_ptr(), d.data_ptr(), N.stream_ptr()))
         return p, d
 
-    bg_part = _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg,
-                    dirs=rays_bg[:, 3:6], idx=idx_bg, points=bg_points, rays=rays_bg, tag='bg',
-                    before_coarse=before_coarse)
+    return _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg, dirs=rays_bg[:, 3:6], idx=idx_bg,
+                 points=bg_points, rays=rays_bg, tag='bg', before_coarse=before_coarse)
+
+
+def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, get_depth,
+                get_depth_variance, rnd, dev, before_coarse=None):
+    """Background branch of render_rays (rendering.py:47-75) on the current stream."""
+    bg_part = _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd,
+                               dev, before_coarse)
     return _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
 
 
@@ -295,6 +301,10 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     """Enqueue the whole render on the current stream.  Returns (results, n_bg_dev, err_flag_dev); the two
     device scalars are None without a background model.  No host synchronisation."""
     N.require_device(rays, 'rays')
+    if torch.is_grad_enabled() and any(p.requires_grad for m in (nerf, bg_nerf) if m is not None for p in m.parameters()):
+        from mega_nerf.training import render_rays_train       # differentiable path (hand-written backward)
+        return render_rays_train(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth,
+                                 get_depth_variance, get_bg_fg_rgb, _randoms)
     lib = N.lib()
     dev = rays.device
     rnd = _randoms if _randoms is not None else {}

@@ -1,0 +1,296 @@
+"""Training path of render_rays on the MI355X: forward with an activation tape + hand-written backward.
+
+The reference trains through torch autograd over ``rendering.render_rays`` (runner.py:347-381, 263-277).
+Here the whole differentiable part of the render -- fg/bg blend, compositing, coarse/fine merge and the NeRF
+MLP -- has explicit HIP backward kernels; :class:`RenderFunction` exposes them to autograd as ONE node whose
+inputs are the model parameters and whose output is ``rgb_fine``, so ``loss.backward()`` / ``optimizer.step()``
+in a reference-style training loop work unchanged.  :class:`TrainStep` is that loop body for the benchmark.
+
+Scope (round 1): the default architecture without cascade / container (single NeRF per branch, 8x256,
+fine_samples > 0).  Importance-sampling weights are detached exactly as in the reference (rendering.py:215),
+so gradients reach the MLP only through the compositing of ``rgb_fine``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from argparse import Namespace
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from mega_nerf import _native as N
+from mega_nerf import rendering as R
+
+
+def _f(*shape, device):
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
+class _Branch:
+    """Everything one branch (fg or bg) keeps between forward and backward."""
+    pass
+
+
+def _branch_forward(model, hparams: Namespace, part, flip: bool, get_bg_lambda: bool, rnd: dict, tag: str) -> _Branch:
+    """Training-mode _get_results (rendering.py:176-248, non-cascade, Nf > 0) writing the activation tape."""
+    lib = N.lib()
+    b = _Branch()
+    dev = part.z.device
+    n, Sc = part.z.shape
+    nf = hparams.fine_samples // 2 if flip else hparams.fine_samples
+    b.n, b.Sc, b.Sf, b.flip, b.part, b.model = n, Sc, nf, flip, part, model
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    rows_c, rows_f = n * Sc, n * nf
+    b.cap = rows_c + rows_f
+    b.tape = _f(b.cap * model.tape_floats_per_row(), device=dev)
+    b.raw_all = _f(b.cap, 4, device=dev)                       # coarse rows, then fine rows
+
+    xyz_c, z_c = part.xyz, part.z
+    if flip:                                                   # rendering.py:271-273
+        xyz_c, z_c = xyz_c.flip(1).contiguous(), z_c.flip(1).contiguous()
+    b.z_c = z_c
+    noise_c = rnd.get(tag + '_noise_coarse') if model.training else None
+    if model.training and noise_c is None:
+        noise_c = torch.rand(rows_c, device=dev)
+    dirs, dstride = part.dirs, part.dirs.stride(0)
+    io = model.mlp_io(xyz_c, xyz_c.shape[-1], dirs, dstride, part.idx, 1, Sc, rows_c, b.raw_all[:rows_c], noise_c,
+                      part.n_units, Sc)
+    model.evaluate_train(io, b.tape, b.cap, 0)
+    raw_c = b.raw_all[:rows_c].view(n, Sc, 4)
+    comp = R._composite(z_c, raw_c, n, Sc, part, part.last_delta, part.z, flip, part.depth_real, {'weights'}, dev)
+
+    det = (hparams.perturb if model.training else 0) == 0
+    if det:
+        u = R.linspace01(nf, dev)
+    else:
+        u = rnd.get(tag + '_u')
+        if u is None:
+            u = torch.rand(n, nf, device=dev)
+    z_f = _f(n, nf, device=dev)
+    N.check(lib.mnr_sample_fine(part.z.data_ptr(), comp['weights'].data_ptr(), n, nunits, Sc, nf, int(det), u.data_ptr(),
+                                z_f.data_ptr(), None, N.stream_ptr()))
+    b.z_f = z_f
+    xyz_f, dr_f = part.points(z_f)
+    noise_f = rnd.get(tag + '_noise_fine') if model.training else None
+    if model.training and noise_f is None:
+        noise_f = torch.rand(rows_f, device=dev)
+    io = model.mlp_io(xyz_f, xyz_f.shape[-1], dirs, dstride, part.idx, 1, nf, rows_f, b.raw_all[rows_c:], noise_f,
+                      part.n_units, nf)
+    model.evaluate_train(io, b.tape, b.cap, rows_c)
+    raw_f = b.raw_all[rows_c:].view(n, nf, 4)
+
+    Sm = nf + Sc
+    b.Sm = Sm
+    b.z_m, b.raw_m = _f(n, Sm, device=dev), _f(n, Sm, 4, device=dev)
+    dr_m = _f(n, Sm, device=dev) if dr_f is not None else None
+    b.order = torch.empty(n, Sm, device=dev, dtype=torch.int32)
+    N.check(lib.mnr_merge_sorted(z_f.data_ptr(), raw_f.data_ptr(), N.ptr(dr_f), nf, z_c.data_ptr(), raw_c.data_ptr(),
+                                 N.ptr(part.depth_real), Sc, n, nunits, int(flip), b.z_m.data_ptr(), b.raw_m.data_ptr(),
+                                 N.ptr(dr_m), b.order.data_ptr(), N.stream_ptr()))
+    want = {'rgb', 'depth', 'depth_var'}
+    if get_bg_lambda:
+        want.add('bg_lambda')
+    b.out = R._composite(b.z_m, b.raw_m, n, Sm, part, part.last_delta, z_f, flip, dr_m, want, dev)
+    return b
+
+
+def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.Tensor], grads: Dict[str, torch.Tensor]):
+    """d(rgb of this branch) [n,3] (+ d bg_lambda) -> parameter gradients (accumulated into ``grads``)."""
+    lib = N.lib()
+    part, model = b.part, b.model
+    dev = b.z_m.device
+    n, Sc, Sf, Sm = b.n, b.Sc, b.Sf, b.Sm
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    rows_c, rows_f = n * Sc, n * Sf
+    # compositing backward -> gradient of the merged raw outputs
+    d_raw_m = _f(n, Sm, 4, device=dev)
+    io = N.CompositeGradIO()
+    io.z, io.raw = b.z_m.data_ptr(), b.raw_m.data_ptr()
+    io.last_delta = part.last_delta.data_ptr() if part.last_delta is not None else None
+    if part.last_delta is not None:
+        io.zmax_src, io.zmax_S = b.z_f.data_ptr(), Sf
+    io.flip, io.N, io.S = int(b.flip), n, Sm
+    io.n_units_dev = nunits
+    io.d_rgb = d_rgb.data_ptr()
+    io.d_bg_lambda = d_lambda.data_ptr() if d_lambda is not None else None
+    io.d_raw = d_raw_m.data_ptr()
+    N.check(lib.mnr_composite_backward(C.byref(io), N.stream_ptr()))
+    # un-merge: fine rows / coarse rows of one [cap][4] gradient array (same row space as the tape)
+    d_raw_all = _f(b.cap, 4, device=dev)
+    N.check(lib.mnr_merge_backward(d_raw_m.data_ptr(), b.order.data_ptr(), Sf, Sc, n, nunits,
+                                   d_raw_all[rows_c:].data_ptr(), d_raw_all[:rows_c].data_ptr(), N.stream_ptr()))
+    # MLP backward
+    desc, packed = model.packed()
+    packed_bwd = model.packed_bwd()
+    gtape = _f(b.tape.numel(), device=dev)
+    dheads = _f(b.cap, 4, device=dev)
+    gs = model.grad_struct(grads)
+
+    def gio(row0, rows, rows_per_ray):
+        g = N.MlpGradIO()
+        g.tape, g.gtape, g.tape_rows, g.tape_row0 = b.tape.data_ptr(), gtape.data_ptr(), b.cap, row0
+        g.d_out, g.d_out_stride = d_raw_all[row0:].data_ptr(), 4
+        g.out, g.out_stride = b.raw_all[row0:].data_ptr(), 4
+        g.dheads = dheads.data_ptr()
+        if part.idx is not None:
+            g.idx, g.idx_stride = part.idx.data_ptr(), 1
+            g.idx_is_float = 1 if part.idx.dtype == torch.float32 else 0
+        g.rows_per_ray = rows_per_ray
+        g.n_rows = rows
+        g.n_units_dev = nunits
+        g.rows_per_unit = rows_per_ray
+        g.grad = gs
+        return g
+
+    gc, gf = gio(0, rows_c, Sc), gio(rows_c, rows_f, Sf)
+    N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gc), N.stream_ptr()))
+    N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gf), N.stream_ptr()))
+    if part.n_units is None:
+        # foreground: coarse + fine rows are one dense region of the tape -> a single weight-gradient launch
+        gall = gio(0, b.cap, Sc)
+        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gall), N.stream_ptr()))
+    else:
+        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gc), N.stream_ptr()))
+        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gf), N.stream_ptr()))
+
+
+def _param_list(m: Optional[nn.Module]):
+    return [] if m is None else [(k, p) for k, p in m.named_parameters()]
+
+
+class RenderFunction(torch.autograd.Function):
+    """rgb_fine = render(params...) with hand-written HIP backward.  Non-differentiable by-products (depth
+    variance, bg_lambda, device flags) are returned through ``ctx_out``."""
+
+    @staticmethod
+    def forward(ctx, nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, ctx_out, *params):
+        N.require_device(rays, 'rays')
+        lib = N.lib()
+        dev = rays.device
+        rays = rays.contiguous().float()
+        n_rays = rays.shape[0]
+        Nc = hparams.coarse_samples
+        if image_indices is not None:
+            if image_indices.dtype not in (torch.float32, torch.int32):
+                image_indices = image_indices.float()
+            image_indices = image_indices.contiguous()
+        perturb = float(hparams.perturb) if nerf.training else 0.0
+        far = last_delta = bg_slot = n_bg = err = None
+        bgb = None
+        if bg_nerf is not None:
+            c, r = R._host_vec(sphere_center), R._host_vec(sphere_radius)
+            far, last_delta = _f(n_rays, device=dev), _f(n_rays, device=dev)
+            bg_list = torch.zeros(max(n_rays, 1), device=dev, dtype=torch.int32)
+            bg_slot = torch.empty(max(n_rays, 1), device=dev, dtype=torch.int32)
+            scal = torch.zeros(2, device=dev, dtype=torch.int32)
+            n_bg, err = scal[0:1], scal[1:2]
+            N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
+                                      last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
+                                      err.data_ptr(), N.stream_ptr()))
+            bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r,
+                                         rnd, dev)
+            bgb = _branch_forward(bg_nerf, hparams, bg_part, True, False, rnd, 'bg')
+        t_c = R.linspace01(Nc, dev)
+        prnd = None
+        if perturb > 0:
+            prnd = rnd.get('fg_perturb')
+            if prnd is None:
+                prnd = torch.rand(n_rays, Nc, device=dev)
+        z, xyz = _f(n_rays, Nc, device=dev), _f(n_rays, Nc, 3, device=dev)
+        N.check(lib.mnr_fg_samples(rays.data_ptr(), N.ptr(far), n_rays, Nc, t_c.data_ptr(), perturb, N.ptr(prnd),
+                                   z.data_ptr(), xyz.data_ptr(), N.stream_ptr()))
+
+        def fg_points(zf):
+            p = _f(n_rays, zf.shape[1], 3, device=dev)
+            N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), N.stream_ptr()))
+            return p, None
+
+        fg_part = R._Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=rays[:, 3:6],
+                          idx=image_indices, points=fg_points, rays=rays, tag='fg')
+        fgb = _branch_forward(nerf, hparams, fg_part, False, bg_nerf is not None, rnd, 'fg')
+        rgb = fgb.out['rgb']
+        ctx.fg_rgb_unblended = None
+        if bgb is not None:
+            # blend in place (rendering.py:102-131); depth is not part of the training outputs
+            N.check(lib.mnr_bg_blend(rgb.data_ptr(), None, fgb.out['bg_lambda'].data_ptr(), bg_slot.data_ptr(),
+                                     bgb.out['rgb'].data_ptr(), None, n_rays, None, None, None, None, N.stream_ptr()))
+        ctx.fgb, ctx.bgb, ctx.bg_slot, ctx.n_rays = fgb, bgb, bg_slot, n_rays
+        ctx.names_fg = [k for k, _ in _param_list(nerf)]
+        ctx.names_bg = [k for k, _ in _param_list(bg_nerf)]
+        ctx.params = params
+        ctx_out['depth_variance_fine'] = fgb.out['depth_var']
+        if bg_nerf is not None:
+            ctx_out['bg_lambda_fine'] = fgb.out['bg_lambda']
+        ctx_out['n_bg'], ctx_out['err'] = n_bg, err
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        lib = N.lib()
+        fgb, bgb = ctx.fgb, ctx.bgb
+        d_rgb = d_rgb.contiguous().float()
+        dev = d_rgb.device
+        n_fg, n_bgp = len(ctx.names_fg), len(ctx.names_bg)
+        grads_fg = {k: torch.zeros_like(p) for k, p in zip(ctx.names_fg, ctx.params[:n_fg])}
+        grads_bg = {k: torch.zeros_like(p) for k, p in zip(ctx.names_bg, ctx.params[n_fg:n_fg + n_bgp])}
+        d_lambda = None
+        if bgb is not None:
+            d_lambda = _f(ctx.n_rays, device=dev)
+            d_bg_rgb = torch.zeros(bgb.n, 3, device=dev)
+            N.check(lib.mnr_bg_blend_backward(d_rgb.data_ptr(), fgb.out['bg_lambda'].data_ptr(), ctx.bg_slot.data_ptr(),
+                                              bgb.out['rgb'].data_ptr(), ctx.n_rays, d_lambda.data_ptr(),
+                                              d_bg_rgb.data_ptr(), N.stream_ptr()))
+            _branch_backward(bgb, d_bg_rgb, None, grads_bg)
+        _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
+        out = [grads_fg[k] for k in ctx.names_fg] + [grads_bg[k] for k in ctx.names_bg]
+        return (None,) * 9 + tuple(out)
+
+
+def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
+                      image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
+                      get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
+    """Differentiable render (training flags of runner.py:349-358).  Returns (results, n_bg_dev, err_dev)."""
+    if hparams.use_cascade or hparams.fine_samples == 0 or hparams.container_path is not None or \
+            getattr(hparams, 'train_mega_nerf', None) is not None:
+        raise NotImplementedError('the MI355X training path covers the single-NeRF, non-cascade configuration')
+    if get_depth or get_bg_fg_rgb:
+        raise NotImplementedError('training render returns rgb_fine / depth_variance_fine / bg_lambda_fine only')
+    rnd = _randoms if _randoms is not None else {}
+    params = [p for _, p in _param_list(nerf)] + [p for _, p in _param_list(bg_nerf)]
+    aux: Dict[str, torch.Tensor] = {}
+    rgb = RenderFunction.apply(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, aux, *params)
+    results = {'rgb_fine': rgb}
+    if get_depth_variance:
+        results['depth_variance_fine'] = aux['depth_variance_fine']
+    if bg_nerf is not None:
+        results['bg_lambda_fine'] = aux['bg_lambda_fine']
+    return results, aux.get('n_bg'), aux.get('err')
+
+
+class TrainStep:
+    """One optimisation step of the reference trainer (runner.py:244-277, fp32): render -> MSE -> backward ->
+    Adam on fg and bg -> LR decay.  No host synchronisation inside the step."""
+
+    def __init__(self, nerf: nn.Module, bg_nerf: Optional[nn.Module], hparams: Namespace, sphere_center, sphere_radius,
+                 lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000):
+        self.nerf, self.bg_nerf, self.hparams = nerf, bg_nerf, hparams
+        self.sc, self.sr = sphere_center, sphere_radius
+        self.opts = [torch.optim.Adam(nerf.parameters(), lr=lr)]
+        if bg_nerf is not None:
+            self.opts.append(torch.optim.Adam(bg_nerf.parameters(), lr=lr))
+        gamma = lr_decay_factor ** (1 / train_iterations)
+        self.scheds = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=gamma) for o in self.opts]
+
+    def __call__(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
+        for o in self.opts:
+            o.zero_grad(set_to_none=True)
+        results, n_bg, err = render_rays_train(self.nerf, self.bg_nerf, rays, image_indices, self.hparams, self.sc, self.sr,
+                                               False, True, False)
+        loss = torch.nn.functional.mse_loss(results['rgb_fine'], rgbs, reduction='mean')
+        loss.backward()
+        for o in self.opts:          # NB: the reference skips the bg optimiser when no ray had a bg segment
+            o.step()                 # (runner.py:269-272); with zero bg rays every bg gradient is exactly 0 here
+        for s in self.scheds:
+            s.step()
+        return loss, n_bg, err
