@@ -78,7 +78,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--mode', choices=['eval', 'train'], default='eval')
+    ap.add_argument('--mode', choices=['eval', 'train'], default='train',
+                    help='train: fwd+bwd+Adam step (BASELINE metric: train rays/s); eval: render_rays forward only')
     ap.add_argument('--rays', type=int, default=1024, help='rays per batch (BASELINE: 1024)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -162,27 +163,57 @@ def main():
         dist.all_reduce(packed)
     psnr = float(packed[0] / packed[1])
 
+    # a second, untimed pass of the other mode so that one line carries both halves of the BASELINE metric
+    other = None
+    if rank == 0 or dist is not None:
+        if args.mode == 'train':
+            fg.eval(), bg.eval()
+            with torch.no_grad():
+                for _ in range(3):
+                    render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
+                torch.cuda.synchronize()
+                other = ('eval_rays_per_sec_per_gpu', args.rays * args.steps / (time.perf_counter() - t1))
+
     if rank == 0:
         total_rays = args.rays * args.steps * world
-        fine_ms = [a.elapsed_time(b) for tag, a, b in ev if tag == 'fg_fine']
-        roof = None
-        if fine_ms:
-            avg = sum(fine_ms) / len(fine_ms) * 1e-3
-            flops = args.rays * 128 * FG_FLOP_PER_SAMPLE * (3.0 if args.mode == 'train' and False else 1.0)
+        traffic_file = ROOT / 'profiles' / 'hbm_traffic.json'
+        traffic_tab = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
+
+        def roofline(tag, kernel, flops, key):
+            ms = [a.elapsed_time(b) for t, a, b in ev if t == tag]
+            if not ms:
+                return None
+            avg = sum(ms) / len(ms) * 1e-3
             ach = flops / avg / 1e12
-            traffic = None
-            tf = ROOT / 'profiles' / 'hbm_traffic.json'
-            if tf.exists():
-                traffic = json.loads(tf.read_text()).get('k_mlp_fwd_fg_fine_bytes_per_launch')
-            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-                    'kernel': 'k_mlp_fwd<fg> (fine pass, %d rows)' % (args.rays * 128),
-                    'avg_launch_ms': round(avg * 1e3, 4)}
+            return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_tab.get(key), 'kernel': kernel,
+                    'avg_launch_ms': round(avg * 1e3, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
+
+        n_fine, n_all = args.rays * 128, args.rays * 192
+        fwd_fine = roofline('fg_fine', 'k_mlp_fwd<fg> (fine pass, %d rows)' % n_fine, n_fine * FG_FLOP_PER_SAMPLE,
+                            'k_mlp_fwd_fg_fine_bytes_per_launch')
+        if args.mode == 'train':
+            # dominant kernel of a training step: the weight-gradient GEMMs of all fg layers in one launch
+            # (algorithmic FLOPs = 2 * rows * sum_l M_l*N_l over the MFMA layers = per-sample forward MACs * 2
+            #  minus the two VALU heads)
+            wgrad_flops = n_all * (FG_FLOP_PER_SAMPLE - 2 * (256 + 3 * 128))
+            roof = roofline('fg_wgrad', 'k_wgrad (fg, %d rows x 13 layer jobs)' % n_all, wgrad_flops,
+                            'k_wgrad_fg_bytes_per_launch')
+            extra_roof = {'k_mlp_fwd_train_fg_fine': fwd_fine,
+                          'k_mlp_bwd_fg_fine': roofline('fg_bwd_fine', 'k_mlp_bwd<fg> (fine rows)',
+                                                        n_fine * (FG_FLOP_PER_SAMPLE - 2 * 80 * 256 - 2 * (27 * 128)),
+                                                        'k_mlp_bwd_fg_fine_bytes_per_launch')}
+        else:
+            roof, extra_roof = fwd_fine, None
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), fw, bw, fcfg, bcfg, min(256, args.rays))
         line = {
-            'metric': 'rays_per_sec (%s)' % ('train step: fwd+bwd+Adam' if args.mode == 'train' else 'eval render_rays fwd'),
+            'metric': 'train rays/sec (fwd+bwd+2xAdam step)' if args.mode == 'train' else 'eval rays/sec (render_rays fwd)',
             'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -193,6 +224,10 @@ def main():
             'eval_psnr_vs_random_target_db': round(psnr, 4),
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if extra_roof:
+            line['roofline_other_kernels'] = extra_roof
+        if other:
+            line[other[0]] = other[1]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -157,6 +157,7 @@ typedef struct mnr_mlp_grad_io {
     int32_t rows_per_ray;
     int64_t n_rows;
     const int32_t *n_units_dev;  int32_t rows_per_unit;
+    int32_t *work_counter;       /* scratch: one device int32 (item queue head of the weight-gradient launch) */
     mnr_model_grads grad;
 } mnr_mlp_grad_io;
 

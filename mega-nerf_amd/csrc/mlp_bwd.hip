@@ -11,6 +11,8 @@
 //  * k_wgrad         : dW_l += dZ_l^T . IN_l  and  db_l += colsum(dZ_l) for every layer in ONE launch
 //                      (job table; split over row ranges; v_mfma_f32_32x32x2_f32; fp32 atomics into .grad).
 //  * k_head_grads    : sigma / rgb head weight gradients (M = 1 and 3: VALU).
+#include <stdlib.h>
+
 #include "mlp_device.h"
 
 namespace mnr {
@@ -252,87 +254,175 @@ struct WgradArgs {
     const int32_t *n_units_dev;
     int rows_per_unit;
     long row0;                            // first tape row of the region
+    int32_t *work_counter;                // device-side item queue head (zeroed before the launch)
 };
 
 constexpr int WG_KT = 32;                 // rows (K) per LDS tile
+constexpr int WG_THREADS = 512;           // 8 waves: 2 (M) x 4 (N)
 
-__global__ __launch_bounds__(256, 1) void k_wgrad(WgradArgs a) {
-    extern __shared__ float wlds[];
-    const int bid = blockIdx.x;
-    int j = 0;
+// One (M x N) weight-gradient job slice.  Wave (wr, wc) of the 2 x 2 wave grid owns MBW x NBW blocks of 32 x 32.
+// Tiles of WG_KT rows of dZ and IN are streamed global -> LDS with LDS-DMA into a 2-stage ring; the MFMA loop
+// reads both operands with conflict-free ds_read_b32 (lanes run along the feature dimension).
+// decode a work item -> (job, row range); returns false when the item is past the end of the table
+__device__ __forceinline__ bool wgrad_decode(const WgradArgs &a, int item, long n_rows, int &job, long &r_begin, long &r_end) {
+    job = -1;
     for (int i = 0; i < a.njobs; ++i)
-        if (bid >= a.job[i].wg0 && bid < a.job[i].wg0 + a.job[i].nwg) j = i;
-    const WgradJob &J = a.job[j];
-    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
-    const int slice = bid - J.wg0;
+        if (item >= a.job[i].wg0 && item < a.job[i].wg0 + a.job[i].nwg) job = i;
+    if (job < 0) return false;
+    const WgradJob &J = a.job[job];
     long rps = (n_rows + J.nwg - 1) / J.nwg;
     rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
-    const long r_begin = (long)slice * rps, r_end = min(n_rows, r_begin + rps);
-    if (r_begin >= r_end) return;
+    r_begin = (long)(item - J.wg0) * rps;
+    r_end = min(n_rows, r_begin + rps);
+    return true;
+}
 
+// workgroup-wide pull of the next item from the device-side queue (mailbox = first word of the LDS block)
+__device__ __forceinline__ int wgrad_pull(const WgradArgs &a, float *lds) {
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<int *>(lds)[0] = atomicAdd(a.work_counter, 1);
+    __syncthreads();
+    return reinterpret_cast<volatile int *>(lds)[0];
+}
+
+// Runs consecutive work items of ONE (M x N) job, accumulating in registers, then flushes with atomics.
+// The workgroup has 8 waves (2 per SIMD, so one wave's LDS waits hide behind the other's MFMAs); wave (wr, wc) of
+// the 2 x 4 wave grid owns MBW x NBW blocks of 32 x 32.  Tiles of WG_KT rows of dZ and IN are
+// streamed global -> LDS with LDS-DMA into a 2-stage ring; the MFMA loop reads both operands with conflict-free
+// ds_read_b32 (lanes run along the feature dimension).  Returns the first item that belongs to another job.
+template <int MBW, int NBW>
+__device__ __forceinline__ int wgrad_run(const WgradArgs &a, int item, long n_rows, float *lds_all) {
+    float *lds = lds_all + 64;                         // word 0 is the queue mailbox
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int MB = J.M / 32, NB = (J.N + 31) / 32;
-    const int MBW = MB / 2, NBW = (NB + 1) / 2;            // blocks per wave (<= 4 each)
+    const int wr = wave >> 2, wc = wave & 3;
     const int i32 = lane & 31, kk = lane >> 5;
-    float *dz_t = wlds;                                    // [WG_KT][M]
-    float *in_t = wlds + WG_KT * J.M;                      // [WG_KT][ldin] (+ slack)
-    const int dz_f4 = WG_KT * J.M / 4, in_f4 = WG_KT * J.ldin / 4;
+    int job;
+    long r_begin, r_end;
+    wgrad_decode(a, item, n_rows, job, r_begin, r_end);
+    const WgradJob &J = a.job[job];
+    const long row0 = a.row0;
+    const int M = J.M, ldin = J.ldin;
+    const int dz_f4 = WG_KT * M / 4, n_f4 = dz_f4 + WG_KT * ldin / 4;
+    const int stage_floats = (WG_KT * (M + ldin) + 255) / 256 * 256 + 256;     // slack: B fragments may read past ldin
 
-    floatx16 acc[4][4];
+    floatx16 acc[MBW][NBW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MBW; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = floatx16(0.f);
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NBW; ++n) acc[m][n] = floatx16(0.f);
+    float bsum[MBW];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) bsum[m] = 0.f;
 
-    for (long r0 = r_begin; r0 < r_end; r0 += WG_KT) {
-        const int nr = (int)min((long)WG_KT, r_end - r0);
-        __syncthreads();                                   // previous tile fully consumed
-        const float4 *gz = reinterpret_cast<const float4 *>(J.dz + (a.row0 + r0) * J.ldz);
-        const float4 *gi = reinterpret_cast<const float4 *>(J.in + (a.row0 + r0) * J.ldin);
-        for (int t = threadIdx.x; t < dz_f4; t += 256)
-            reinterpret_cast<float4 *>(dz_t)[t] = (t * 4 / J.M) < nr ? gz[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = threadIdx.x; t < in_f4; t += 256)
-            reinterpret_cast<float4 *>(in_t)[t] = (t * 4 / J.ldin) < nr ? gi[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        for (int k = 0; k < WG_KT; k += 2) {
-            const float *zr = dz_t + (k + kk) * J.M + wr * MBW * 32 + i32;
-            const float *ir = in_t + (k + kk) * J.ldin + wc * NBW * 32 + i32;
-            float af[4], bf[4];
+    int next;
+    for (;;) {
+        const long ntiles = (r_end - r_begin + WG_KT - 1) / WG_KT;
+        auto issue = [&](long ti) {
+            const long r0 = r_begin + ti * WG_KT;
+            const int nr = (int)min((long)WG_KT, r_end - r0);
+            float *stage = lds + (ti & 1) * stage_floats;
+            if (nr == WG_KT) {
+                // full tile: both operand tiles are contiguous blocks of WG_KT rows -> pure pointer arithmetic
+                const float *zsrc = J.dz + (row0 + r0) * (long)M, *isrc = J.in + (row0 + r0) * (long)ldin;
+                for (int t0 = 0; t0 < n_f4; t0 += WG_THREADS) {
+                    const int t = t0 + threadIdx.x;
+                    if (t < n_f4) {
+                        const float *src = t < dz_f4 ? zsrc + t * 4 : isrc + (t - dz_f4) * 4;
+                        float *dst = stage + (t0 + wave * 64) * 4;        // wave-uniform base; HW adds lane*16
+                        __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, 0);
+                    }
+                }
+                return;
+            }
+            for (int t0 = 0; t0 < n_f4; t0 += WG_THREADS) {                     // ragged tile (at most one per region)
+                const int t = t0 + threadIdx.x;
+                if (t < n_f4) {
+                    const float *src;
+                    if (t < dz_f4) {
+                        const int e = t * 4, r = min(e / M, nr - 1);      // clamp: rows past the region re-read the last row
+                        src = J.dz + (row0 + r0 + r) * (long)M + (e % M);
+                    } else {
+                        const int e = (t - dz_f4) * 4, r = min(e / ldin, nr - 1);
+                        src = J.in + (row0 + r0 + r) * (long)ldin + (e % ldin);
+                    }
+                    float *dst = stage + (t0 + wave * 64) * 4;
+                    __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, 0);
+                }
+            }
+        };
+        if (ntiles > 0) issue(0);
+        for (long ti = 0; ti < ntiles; ++ti) {
+            __syncthreads();                               // tile ti landed; everyone is done with tile ti-1
+            if (ti + 1 < ntiles) issue(ti + 1);
+            float *dz_t = lds + (ti & 1) * stage_floats, *in_t = dz_t + WG_KT * M;
+            const int nr = (int)min((long)WG_KT, r_end - (r_begin + ti * WG_KT));
+            if (nr < WG_KT) {                              // ragged last tile: rows >= nr must contribute nothing
+                for (int e = nr * M + threadIdx.x; e < WG_KT * M; e += WG_THREADS) dz_t[e] = 0.f;
+                for (int e = nr * ldin + threadIdx.x; e < WG_KT * ldin; e += WG_THREADS) in_t[e] = 0.f;
+                __syncthreads();
+            }
+            const float *zr = dz_t + kk * M + wr * MBW * 32 + i32;
+            const float *ir = in_t + kk * ldin + wc * NBW * 32 + i32;
+#pragma unroll 4
+            for (int k = 0; k < WG_KT; k += 2) {
+                float af[MBW], bf[NBW];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = m < MBW ? zr[m * 32] : 0.f;
+                for (int m = 0; m < MBW; ++m) af[m] = zr[k * M + m * 32];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n] = n < NBW ? ir[n * 32] : 0.f;
+                for (int n = 0; n < NBW; ++n) bf[n] = ir[k * ldin + n * 32];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < MBW) {
+                for (int m = 0; m < MBW; ++m) {
                     bsum[m] += af[m];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        if (n < NBW) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NBW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
                 }
             }
         }
+        next = wgrad_pull(a, lds_all);                     // (also fences the last tile's LDS reads)
+        int njob;
+        if (!wgrad_decode(a, next, n_rows, njob, r_begin, r_end) || njob != job) break;
     }
-    // write-out: C layout -> atomics into the nn.Parameter gradient
+    // flush: C layout -> atomics into the nn.Parameter gradient
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (m >= MBW) continue;
+    for (int m = 0; m < MBW; ++m) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (n >= NBW) continue;
+        for (int n = 0; n < NBW; ++n) {
             const int col = (wc * NBW + n) * 32 + i32;
-            if (col >= J.N) continue;
+            if (col < J.N) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowm = (wr * MBW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                atomicAdd(J.dw + (long)rowm * J.ldw + J.col0 + col, acc[m][n][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int rowm = (wr * MBW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    atomicAdd(J.dw + (long)rowm * J.ldw + J.col0 + col, acc[m][n][r]);
+                }
             }
         }
         if (J.db && wc == 0) {
-            const float s = bsum[m] + __shfl_xor(bsum[m], 32);
-            if (kk == 0) atomicAdd(J.db + (wr * MBW + m) * 32 + i32, s);
+            const float sm = bsum[m] + __shfl_xor(bsum[m], 32);
+            if (kk == 0) atomicAdd(J.db + (wr * MBW + m) * 32 + i32, sm);
+        }
+    }
+    return next;
+}
+
+// Persistent workgroups pulling (job, row-range) items from a device-side queue: perfect load balance across
+// jobs of very different shapes, while consecutive items of one job share a single accumulator flush.
+__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
+    extern __shared__ float wlds[];
+    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
+    int item = wgrad_pull(a, wlds);
+    for (;;) {
+        int job;
+        long rb, re;
+        if (!wgrad_decode(a, item, n_rows, job, rb, re)) return;
+        const WgradJob &J = a.job[job];
+        const int NBW = ((J.N + 31) / 32 + 3) / 4;         // column blocks per wave (4 wave columns)
+        if (J.M == 256) {
+            if (NBW == 2) item = wgrad_run<4, 2>(a, item, n_rows, wlds);
+            else item = wgrad_run<4, 1>(a, item, n_rows, wlds);
+        } else {   // M == 128
+            if (NBW == 2) item = wgrad_run<2, 2>(a, item, n_rows, wlds);
+            else item = wgrad_run<2, 1>(a, item, n_rows, wlds);
         }
     }
 }
@@ -496,30 +586,49 @@ extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_g
         if (d->appearance_dim) add(dz, W / 2, io->tape + (long)tl.app_off * cap, tl.app_w, d->appearance_dim, G.dir_a_w, ldw,
                                    W + EDcols, nullptr);
     }
-    // distribute ~2 x 256 workgroups over the jobs in proportion to M * N (cost per row)
-    double tot = 0;
-    for (int i = 0; i < nj; ++i) tot += (double)wa.job[i].M * ((wa.job[i].N + 31) / 32 * 32);
+    MNR_REQUIRE(W == 256, "weight-gradient kernel supports layer_dim 256");
+    // distribute ~256 workgroups (one per CU) over the jobs in proportion to M * N (cost per row)
+    // Per-tile cost model (cycles): MFMA time of one wave vs LDS-DMA fill time of the tile, plus a fixed
+    // barrier/latency term -- small-N jobs are fill/latency bound, not MFMA bound (calibrated on MI355X, round 1).
+    // Work items: every job is cut into row ranges of roughly equal cost (cycles per tile = MFMA time of one wave vs
+    // LDS-DMA fill time, plus a fixed barrier/latency term); ~6 items per CU keep the tail short.
+    auto env_d = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };
+    const double fill_bpc = env_d("MNR_WGRAD_FILL_BPC", 6.0), fixed = env_d("MNR_WGRAD_FIXED", 2500.0);
+    const int budget = (int)env_d("MNR_WGRAD_ITEMS", 1536.0);
+    double cost[WGRAD_MAX_JOBS], tot = 0;
+    for (int i = 0; i < nj; ++i) {
+        const WgradJob &J = wa.job[i];
+        const int mbw = J.M / 64, nbw = ((J.N + 31) / 32 + 3) / 4;
+        const double mfma = 2 * 16.0 * 64.0 * mbw * nbw, fill = (J.M + J.ldin) * WG_KT * 4.0 / fill_bpc;
+        cost[i] = (mfma > fill ? mfma : fill) + fixed;
+        tot += cost[i];
+    }
     int wg = 0;
     const long tiles = (io->n_rows + WG_KT - 1) / WG_KT;
     size_t lds = 0;
     for (int i = 0; i < nj; ++i) {
         WgradJob &J = wa.job[i];
-        int n = (int)(512.0 * J.M * ((J.N + 31) / 32 * 32) / tot + 0.5);
+        int n = (int)(budget * cost[i] / tot + 0.5);
         n = n < 1 ? 1 : n;
         if (n > tiles) n = (int)(tiles < 1 ? 1 : tiles);
-        J.wg0 = wg; J.nwg = n; wg += n;
-        const size_t need = (size_t)(WG_KT * J.M + WG_KT * J.ldin + 160) * sizeof(float);
+        J.wg0 = wg; J.nwg = n; wg += n;                    // wg0 / nwg = first item / item count of the job
+        const size_t need = (2 * (size_t)((WG_KT * (J.M + J.ldin) + 255) / 256 * 256 + 256) + 64) * sizeof(float);
         lds = need > lds ? need : lds;
     }
     wa.njobs = nj;
     wa.n_rows = io->n_rows; wa.n_units_dev = io->n_units_dev; wa.rows_per_unit = io->rows_per_unit;
     wa.row0 = io->tape_row0;
+    MNR_REQUIRE(io->work_counter, "work_counter (device int32) required");
+    wa.work_counter = io->work_counter;
     if (io->n_rows > 0) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static size_t lds_enabled = 0;       // raise the dynamic-LDS cap once (monotonic; benign if raced)
+        if (lds > 64 * 1024 && lds > lds_enabled) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad): %s", hipGetErrorString(e));
+            lds_enabled = 160 * 1024;
         }
-        hipLaunchKernelGGL(k_wgrad, dim3(wg), dim3(256), lds, s, wa);
+        if (hipMemsetAsync(io->work_counter, 0, sizeof(int32_t), s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(work_counter)");
+        hipLaunchKernelGGL(k_wgrad, dim3(wg < 256 ? wg : 256), dim3(WG_THREADS), lds, s, wa);
         rc = check_launch("k_wgrad");
         if (rc) return rc;
         hipLaunchKernelGGL(k_head_grads, dim3(256), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[L - 1] * cap, W,

@@ -75,7 +75,7 @@ class MlpGradIO(C.Structure):
                 ('d_out', C.c_void_p), ('d_out_stride', C.c_int64), ('out', C.c_void_p), ('out_stride', C.c_int64),
                 ('dheads', C.c_void_p), ('idx', C.c_void_p), ('idx_stride', C.c_int64), ('idx_is_float', C.c_int32),
                 ('rows_per_ray', C.c_int32), ('n_rows', C.c_int64), ('n_units_dev', C.c_void_p),
-                ('rows_per_unit', C.c_int32), ('grad', ModelGrads)]
+                ('rows_per_unit', C.c_int32), ('work_counter', C.c_void_p), ('grad', ModelGrads)]
 
 
 class CompositeGradIO(C.Structure):

@@ -27,6 +27,18 @@ def _f(*shape, device):
     return torch.empty(*shape, device=device, dtype=torch.float32)
 
 
+def _timed(tag, fn):
+    """Run ``fn`` between two HIP events on the launch stream when bench.py asked for kernel timings."""
+    if R.KERNEL_EVENTS is None:
+        return fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    R.KERNEL_EVENTS.append((tag, a, b))
+    return out
+
+
 class _Branch:
     """Everything one branch (fg or bg) keeps between forward and backward."""
     pass
@@ -77,7 +89,7 @@ def _branch_forward(model, hparams: Namespace, part, flip: bool, get_bg_lambda: 
         noise_f = torch.rand(rows_f, device=dev)
     io = model.mlp_io(xyz_f, xyz_f.shape[-1], dirs, dstride, part.idx, 1, nf, rows_f, b.raw_all[rows_c:], noise_f,
                       part.n_units, nf)
-    model.evaluate_train(io, b.tape, b.cap, rows_c)
+    _timed(tag + '_fine', lambda: model.evaluate_train(io, b.tape, b.cap, rows_c))
     raw_f = b.raw_all[rows_c:].view(n, nf, 4)
 
     Sm = nf + Sc
@@ -126,6 +138,7 @@ def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.T
     gtape = _f(b.tape.numel(), device=dev)
     dheads = _f(b.cap, 4, device=dev)
     gs = model.grad_struct(grads)
+    counter = torch.zeros(1, device=dev, dtype=torch.int32)
 
     def gio(row0, rows, rows_per_ray):
         g = N.MlpGradIO()
@@ -140,16 +153,19 @@ def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.T
         g.n_rows = rows
         g.n_units_dev = nunits
         g.rows_per_unit = rows_per_ray
+        g.work_counter = counter.data_ptr()
         g.grad = gs
         return g
 
     gc, gf = gio(0, rows_c, Sc), gio(rows_c, rows_f, Sf)
     N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gc), N.stream_ptr()))
-    N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gf), N.stream_ptr()))
+    _timed(part.tag + '_bwd_fine', lambda: N.check(lib.mnr_mlp_backward_data(
+        packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gf), N.stream_ptr())))
     if part.n_units is None:
         # foreground: coarse + fine rows are one dense region of the tape -> a single weight-gradient launch
         gall = gio(0, b.cap, Sc)
-        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gall), N.stream_ptr()))
+        _timed(part.tag + '_wgrad', lambda: N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gall),
+                                                                                 N.stream_ptr())))
     else:
         N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gc), N.stream_ptr()))
         N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gf), N.stream_ptr()))

@@ -409,6 +409,8 @@ def test_mlp_backward_against_fp64_autograd(name):
     gio.dheads = dheads.data_ptr()
     gio.idx, gio.idx_stride, gio.idx_is_float, gio.rows_per_ray = idx_t.data_ptr(), 1, 1, S
     gio.n_rows = B
+    counter = torch.zeros(1, device=DEV, dtype=torch.int32)
+    gio.work_counter = counter.data_ptr()
     gio.grad = m.grad_struct(grads)
     N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), pb.data_ptr(), C.byref(desc), C.byref(gio), None))
     N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gio), None))
