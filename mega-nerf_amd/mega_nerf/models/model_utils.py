@@ -55,7 +55,7 @@ def _get_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, x
         nerf = Cascade(_get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim),
                        _get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim))
     elif hparams.train_mega_nerf is not None:
-        meta = torch.load(hparams.train_mega_nerf, map_location='cpu')
+        meta = torch.load(hparams.train_mega_nerf, map_location='cpu', weights_only=False)
         centroids = meta['centroids']
         nerf = MegaNeRF([_get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim)
                          for _ in range(len(centroids))], centroids, 1, xyz_dim == 4, meta['cluster_2d'], True)
@@ -63,7 +63,7 @@ def _get_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, x
         nerf = _get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim)
 
     if hparams.ckpt_path is not None:
-        state_dict = torch.load(hparams.ckpt_path, map_location='cpu')[weight_key]
+        state_dict = torch.load(hparams.ckpt_path, map_location='cpu', weights_only=False)[weight_key]
         consume_prefix_in_state_dict_if_present(state_dict, prefix='module.')
         merged = nerf.state_dict()
         merged.update(state_dict)
