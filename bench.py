@@ -50,27 +50,44 @@ def build_models(hp, dev, seed):
     return out
 
 
-def cpu_baseline(hp, rays_np, idx_np, fw, bw, fcfg, bcfg, n_sample):
-    """The numpy oracle (port of the reference CPU path) timed on this box's host cores, bounded sample."""
+def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode):
+    """The reference algorithm restated with the same torch CPU ops (oracle/torch_oracle.py, pinned to the golden
+    vectors) timed on this box's host cores on a bounded sample of the same batch: forward render for --mode eval,
+    forward + autograd backward + 2x Adam for --mode train (runner.py:246-277)."""
     import common
-    from oracle import nerf_oracle as O
+    from oracle import torch_oracle as TO
     s = common.SCENE
-    r, i = rays_np[:n_sample], idx_np[:n_sample].astype(np.float32)
-    fn = lambda: O.render_rays(O.Model(fcfg, fw), O.Model(bcfg, bw), r, i, hp, s['sphere_center'], s['sphere_radius'],  # noqa: E731
-                               True, False, True)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fg, bg = TO.make_models(hp, fcfg, fw, bcfg, bw, s['appearance_count'])
+    rays, idx, tgt = torch.from_numpy(rays_np[:n_sample]), torch.from_numpy(idx_np[:n_sample]), torch.from_numpy(tgt_np[:n_sample])
+    sc, sr = torch.from_numpy(s['sphere_center']), torch.from_numpy(s['sphere_radius'])
+    if mode == 'train':
+        fg.train(), bg.train()
+        opts = [torch.optim.Adam(fg.parameters(), lr=5e-4), torch.optim.Adam(bg.parameters(), lr=5e-4)]
+
+        def fn():
+            for o in opts:
+                o.zero_grad(set_to_none=True)
+            res = TO.render_rays(fg, bg, rays, idx, hp, sc, sr)
+            torch.nn.functional.mse_loss(res['rgb_fine'], tgt).backward()
+            for o in opts:
+                o.step()
+    else:
+        fg.eval(), bg.eval()
+
+        def fn():
+            with torch.inference_mode():
+                TO.render_rays(fg, bg, rays, idx, hp, sc, sr)
     fn()
     best = 1e30
     for _ in range(3):
         t0 = time.perf_counter()
         fn()
         best = min(best, time.perf_counter() - t0)
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     return {'value': n_sample / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-            'sample': 'numpy oracle render_rays (eval flags), %d rays x (64+128) samples, best of 3' % n_sample}
+            'sample': 'torch-CPU restatement of the reference (%s), %d rays x (64+128) samples of the same batch, '
+                      '%d threads, best of 3 after 1 warm-up' % ('fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n_sample, cores)}
 
 
 def main():
@@ -211,7 +228,8 @@ def main():
             roof, extra_roof = fwd_fine, None
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), fw, bw, fcfg, bcfg, min(256, args.rays))
+            cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), target.cpu().numpy(), fw, bw, fcfg, bcfg,
+                               min(1024, args.rays), args.mode)
         line = {
             'metric': 'train rays/sec (fwd+bwd+2xAdam step)' if args.mode == 'train' else 'eval rays/sec (render_rays fwd)',
             'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -540,7 +540,17 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 #undef MNR_TRY_B
     if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "
                                                    "default 8x256 fg/bg models)");
-    return rc;
+    if (rc != MNR_OK || io->n_rows == 0) return rc;
+    // sigma / rgb head weight gradients of the same rows (dheads was just written by the chain kernel)
+    const mnr_model_grads &G = io->grad;
+    MNR_REQUIRE(G.sigma_w && G.sigma_b && G.rgb_w && G.rgb_b, "missing head gradient pointers");
+    const TapeLayout &tl = a.tl;
+    const long cap = io->tape_rows;
+    const int W = d->layer_dim;
+    hipLaunchKernelGGL(k_head_grads, dim3(256), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
+                       io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
+                       io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b);
+    return check_launch("k_head_grads");
 }
 
 extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_grad_io *io, void *stream) {
@@ -631,10 +641,6 @@ extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_g
         hipLaunchKernelGGL(k_wgrad, dim3(wg < 256 ? wg : 256), dim3(WG_THREADS), lds, s, wa);
         rc = check_launch("k_wgrad");
         if (rc) return rc;
-        hipLaunchKernelGGL(k_head_grads, dim3(256), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[L - 1] * cap, W,
-                           io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev, io->rows_per_unit,
-                           G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b);
-        rc = check_launch("k_head_grads");
     }
     return rc;
 }

@@ -104,6 +104,11 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
                 for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[o0 + ob], 0, 0, 0);
 #pragma unroll
                 for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[o0 + ob], 0, 0, 0);
+                // wide layers (W = 512: 32 blocks): stop the scheduler from hoisting the A-fragment loads of many
+                // batches ahead -- it would blow the register budget (676 spilled VGPRs without this fence)
+                if constexpr (NOB > 16) {
+                    if ((o0 / OBB) % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     });

@@ -204,9 +204,15 @@ class RenderFunction(torch.autograd.Function):
             N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
                                       last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
                                       err.data_ptr(), N.stream_ptr()))
-            bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r,
-                                         rnd, dev)
-            bgb = _branch_forward(bg_nerf, hparams, bg_part, True, False, rnd, 'bg')
+            # background branch on the side stream (independent of the foreground until the blend)
+            main = torch.cuda.current_stream()
+            side = R._side_stream(dev) if R.OVERLAP_BG else main
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb,
+                                             c, r, rnd, dev)
+                bgb = _branch_forward(bg_nerf, hparams, bg_part, True, False, rnd, 'bg')
         t_c = R.linspace01(Nc, dev)
         prnd = None
         if perturb > 0:
@@ -228,6 +234,10 @@ class RenderFunction(torch.autograd.Function):
         rgb = fgb.out['rgb']
         ctx.fg_rgb_unblended = None
         if bgb is not None:
+            if side is not main:
+                main.wait_stream(side)
+                for v in bgb.out.values():
+                    v.record_stream(main)
             # blend in place (rendering.py:102-131); depth is not part of the training outputs
             N.check(lib.mnr_bg_blend(rgb.data_ptr(), None, fgb.out['bg_lambda'].data_ptr(), bg_slot.data_ptr(),
                                      bgb.out['rgb'].data_ptr(), None, n_rays, None, None, None, None, N.stream_ptr()))
@@ -257,8 +267,17 @@ class RenderFunction(torch.autograd.Function):
             N.check(lib.mnr_bg_blend_backward(d_rgb.data_ptr(), fgb.out['bg_lambda'].data_ptr(), ctx.bg_slot.data_ptr(),
                                               bgb.out['rgb'].data_ptr(), ctx.n_rays, d_lambda.data_ptr(),
                                               d_bg_rgb.data_ptr(), N.stream_ptr()))
-            _branch_backward(bgb, d_bg_rgb, None, grads_bg)
-        _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
+            main = torch.cuda.current_stream()
+            side = R._side_stream(dev) if R.OVERLAP_BG else main
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _branch_backward(bgb, d_bg_rgb, None, grads_bg)
+            _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
+            if side is not main:
+                main.wait_stream(side)
+        else:
+            _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
         out = [grads_fg[k] for k in ctx.names_fg] + [grads_bg[k] for k in ctx.names_bg]
         return (None,) * 9 + tuple(out)
 

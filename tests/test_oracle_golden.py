@@ -197,3 +197,20 @@ def test_render_rays_matches_reference(name):
         if 'inds_' + part in g and part in dbg and 'inds' in dbg[part]:
             mism = float((dbg[part]['inds'] != g['inds_' + part].astype(np.int64)).mean())
             assert mism < (5e-3 if part == "fg" else 3e-2), (part, mism)
+
+
+# ---- torch-CPU baseline oracle (oracle/torch_oracle.py) -------------------------------------------
+@pytest.mark.parametrize('name', ['render_fgbg_eval', 'render_default_samples_eval'])
+def test_torch_oracle_matches_reference(name):
+    import torch
+    from oracle import torch_oracle as TO
+    g = load(name)
+    hp, nerf, bg_nerf = build_case(name)
+    s = common.SCENE
+    fg, bg = TO.make_models(hp, nerf.cfg, nerf.params, bg_nerf.cfg, bg_nerf.params, s['appearance_count'])
+    fg.eval(), bg.eval()
+    with torch.no_grad():
+        res = TO.render_rays(fg, bg, torch.from_numpy(g['rays']), torch.from_numpy(g['idx']), hp,
+                             torch.from_numpy(s['sphere_center']), torch.from_numpy(s['sphere_radius']))
+    for k in ('rgb_fine', 'fg_rgb_fine', 'bg_rgb_fine', 'depth_fine', 'bg_lambda_fine', 'fg_depth_fine'):
+        np.testing.assert_allclose(res[k].numpy(), g['res_' + k], rtol=2e-4, atol=2e-5, err_msg=k)
