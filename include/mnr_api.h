@@ -121,6 +121,9 @@ typedef struct mnr_mlp_io {
     int32_t sigma_only;
     int32_t apply_sh_deg;                         /* -1: raw output; >=0: rgb = sigmoid(eval_sh(deg, coeffs, dir))
                                                      (rendering.py:301-306), output is 4 floats */
+    const int32_t *row_index;                     /* optional gather: logical row r reads the inputs (xyz, dir, idx,
+                                                     sigma_noise) of source row row_index[r]; the output stays compact
+                                                     at out[r] (per-cell evaluation under the MegaNeRF router) */
 } mnr_mlp_io;
 
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
@@ -262,6 +265,20 @@ typedef struct mnr_composite_io {
     float *bg_lambda;
 } mnr_composite_io;
 int mnr_composite(const mnr_composite_io *io, void *stream);
+
+/* MegaNeRF routing (mega_nerf.py:19-49).  For every row (first 3 floats of pos = world position) the blend weight
+ * of every cell: hard arg-min for boundary_margin == 1, else w_i = (1/(d_i+1e-8)) [d_i <= margin * d_min], normalised.
+ *   centroids_host [n_sub][3]; cluster_dim_start = 1 drops the altitude axis (cluster_2d)
+ *   weights_out [n_sub][B]; lists_out [n_sub][B] compacted row ids of the rows routed to cell i (device-side append,
+ *   order unspecified); counts_out [n_sub] (zeroed by the call).  No host synchronisation. */
+int mnr_route(const float *pos_dev, int64_t pos_stride, int64_t B, const int32_t *n_units_dev, int rows_per_unit,
+              const float *centroids_host, int n_sub, int cluster_dim_start, float boundary_margin,
+              float *weights_out_dev, int32_t *lists_out_dev, int32_t *counts_out_dev, void *stream);
+
+/* out[list[r]][c] (+)= sub_out[r][c] * (weights ? weights[list[r]] : 1) for r < *count  (mega_nerf.py:45-49). */
+int mnr_route_accumulate(float *out_dev, int64_t out_stride, const float *sub_out_dev, int64_t sub_stride, int n_cols,
+                         const int32_t *list_dev, const int32_t *count_dev, int64_t B_max, const float *weights_dev,
+                         int assign, void *stream);
 
 /* fg/bg blend (rendering.py:102-139): for every ray, slot = bg_slot[ray]:
  *   bg_rgb = slot>=0 ? lambda*bg_rgb_c[slot] : 0;  rgb = fg + bg_rgb  (same for depth).

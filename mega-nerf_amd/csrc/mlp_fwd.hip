@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     const long row = ((long)blockIdx.x * 4 + wave) * TILE + (lane % TILE);
     const bool valid = row < n_rows;
     const long rc = valid ? row : n_rows - 1;
-    const long ray = rc / io.rows_per_ray;
+    const long src = io.row_index ? (long)io.row_index[rc] : rc;      // gathered evaluation (MegaNeRF router)
+    const long ray = src / io.rows_per_ray;
 
     WStream st;
     st.g = a.chunks + threadIdx.x;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
 
     float x[C::XYZ];
 #pragma unroll
-    for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[rc * io.xyz_stride + d];
+    for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
     float ex[C::EX];
     embed<C::XYZ, C::LX, P>(ex, x, part);
     if constexpr (TRAIN) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
         }
         s = reduce_parts<P>(s) + ws[P * H];
-        if (io.sigma_noise) s += io.sigma_noise[rc];
+        if (io.sigma_noise) s += io.sigma_noise[src];
         sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
     }
     if (io.sigma_only) {

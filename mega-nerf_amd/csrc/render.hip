@@ -718,3 +718,110 @@ extern "C" int mnr_bg_blend_backward(const float *d_rgb, const float *lam, const
                        d_lambda, d_bg_rgb);
     return check_launch("k_bg_blend_bwd");
 }
+
+// =================================================================================================
+// MegaNeRF router (mega_nerf/models/mega_nerf.py:19-49): blend weights + per-cell row lists on the device.
+// =================================================================================================
+namespace mnr {
+
+constexpr int ROUTE_MAX_SUB = 64;
+struct Centroids {
+    float c[ROUTE_MAX_SUB][3];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, long pos_stride, long B,
+                                               const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
+                                               float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
+                                               int32_t *__restrict__ counts) {
+    const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = row < n;
+    const int lane = threadIdx.x & 63;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (valid) { p[0] = pos[row * pos_stride]; p[1] = pos[row * pos_stride + 1]; p[2] = pos[row * pos_stride + 2]; }
+    // distances (torch.cdist, p = 2) over the clustered dimensions
+    float dmin = INFINITY;
+    int amin = 0;
+    for (int i = 0; i < cen.n; ++i) {
+        float s = 0.f;
+        for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
+        const float d = sqrtf(s);
+        if (d < dmin) { dmin = d; amin = i; }
+    }
+    float wsum = 0.f;
+    if (margin > 1.f) {
+        for (int i = 0; i < cen.n; ++i) {
+            float s = 0.f;
+            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
+            const float d = sqrtf(s);
+            wsum += d > margin * dmin ? 0.f : 1.f / (d + 1e-8f);
+        }
+    }
+    for (int i = 0; i < cen.n; ++i) {
+        float w;
+        if (margin > 1.f) {
+            float s = 0.f;
+            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
+            const float d = sqrtf(s);
+            w = d > margin * dmin ? 0.f : (1.f / (d + 1e-8f)) / wsum;
+        } else {
+            w = i == amin ? 1.f : 0.f;
+        }
+        const bool routed = valid && w > 0.f;
+        if (valid) weights[(long)i * B + row] = w;
+        // wave-aggregated append to cell i's row list
+        const unsigned long long m = __ballot(routed);
+        if (m) {
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counts + i, __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (routed) lists[(long)i * B + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)row;
+        }
+    }
+}
+
+__global__ void k_route_accumulate(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long sub_stride,
+                                   int n_cols, const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                                   const float *__restrict__ weights, int assign) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *count) return;
+    const long dst = list[r];
+    const float w = weights ? weights[dst] : 1.f;
+    for (int c = 0; c < n_cols; ++c) {
+        const float v = sub[r * sub_stride + c] * w;
+        if (assign) out[dst * out_stride + c] = v;
+        else out[dst * out_stride + c] += v;
+    }
+}
+
+}  // namespace mnr
+
+extern "C" int mnr_route(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
+                         const float *centroids, int n_sub, int d0, float margin, float *weights, int32_t *lists,
+                         int32_t *counts, void *stream) {
+    MNR_REQUIRE(pos && centroids && weights && lists && counts && B >= 0, "bad arguments to mnr_route");
+    MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
+    MNR_REQUIRE(d0 == 0 || d0 == 1, "cluster_dim_start must be 0 or 1");
+    MNR_REQUIRE(margin >= 1.f, "boundary_margin must be >= 1");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * n_sub, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(counts)");
+    if (B == 0) return MNR_OK;
+    Centroids cen;
+    cen.n = n_sub;
+    for (int i = 0; i < n_sub; ++i)
+        for (int k = 0; k < 3; ++k) cen.c[i][k] = centroids[3 * i + k];
+    hipLaunchKernelGGL(k_route, dim3(nblk(B, 256)), dim3(256), 0, s, pos, (long)pos_stride, (long)B, n_dev, rows_per_unit, cen,
+                       d0, margin, weights, lists, counts);
+    return check_launch("k_route");
+}
+
+extern "C" int mnr_route_accumulate(float *out, int64_t out_stride, const float *sub, int64_t sub_stride, int n_cols,
+                                    const int32_t *list, const int32_t *count, int64_t B_max, const float *weights,
+                                    int assign, void *stream) {
+    MNR_REQUIRE(out && sub && list && count && n_cols > 0 && B_max >= 0, "bad arguments to mnr_route_accumulate");
+    if (B_max == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_route_accumulate, dim3(nblk(B_max, 256)), dim3(256), 0, as_stream(stream), out, (long)out_stride, sub,
+                       (long)sub_stride, n_cols, list, count, weights, assign);
+    return check_launch("k_route_accumulate");
+}

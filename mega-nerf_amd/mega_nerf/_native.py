@@ -47,6 +47,7 @@ class MlpIO(C.Structure):
         ('n_rows', C.c_int64),
         ('n_units_dev', C.c_void_p), ('rows_per_unit', C.c_int32),
         ('sigma_only', C.c_int32), ('apply_sh_deg', C.c_int32),
+        ('row_index', C.c_void_p),
     ]
 
 
@@ -92,7 +93,7 @@ EXPORTS = [
     'mnr_sample_fine', 'mnr_merge_sorted', 'mnr_sort_rows', 'mnr_composite', 'mnr_bg_blend',
     'mnr_tape_floats_per_row', 'mnr_mlp_forward_train', 'mnr_packed_bwd_bytes', 'mnr_pack_model_bwd',
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
-    'mnr_bg_blend_backward',
+    'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -153,6 +154,10 @@ def lib() -> C.CDLL:
         _lib.mnr_composite_backward.argtypes = [C.POINTER(CompositeGradIO), C.c_void_p]
         _lib.mnr_merge_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+        _lib.mnr_route.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_route_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib.mnr_bg_blend_backward.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
     return _lib
 

@@ -1,9 +1,11 @@
 """Spatial router over per-cell NeRFs (reference: mega_nerf/models/mega_nerf.py:7-61).
 
-Routing weights follow the reference exactly: hard argmin for ``boundary_margin == 1`` and
-inverse-distance blending of every cell within ``boundary_margin * d_min`` otherwise.  Each cell's
-samples are evaluated by the fused MLP kernel of that cell's weights.
+Routing runs on the device (``k_route``: blend weights of every cell + per-cell row lists appended with
+wave-aggregated atomics); each cell then evaluates only its own rows through the fused MLP kernel in gather mode
+(``mnr_mlp_io.row_index``) and ``k_route_accumulate`` blends the results in cell order -- the same summation order
+as the reference loop, with no host synchronisation (the reference syncs once per cell, mega_nerf.py:38).
 """
+import ctypes as C
 from typing import List, Optional
 
 import torch
@@ -23,6 +25,7 @@ class MegaNeRF(nn.Module):
         self.xyz_real = xyz_real
         self.cluster_dim_start = 1 if cluster_2d else 0
         self.joint_training = joint_training
+        self._cent_host = None
 
     # attributes rendering.py reads from a plain NeRF
     @property
@@ -33,70 +36,69 @@ class MegaNeRF(nn.Module):
     def embedding_a(self):
         return self.sub_modules[0].embedding_a
 
-    def _route(self, pos: torch.Tensor):
-        """(n_sub, B) blend weights; zero = not routed (mega_nerf.py:21-31)."""
-        d = torch.cdist(pos[:, self.cluster_dim_start:3], self.centroids[:, self.cluster_dim_start:].to(pos.device))
-        if self.boundary_margin > 1:
-            inv = 1 / (d + 1e-8)
-            inv[d > self.boundary_margin * d.min(dim=1, keepdim=True)[0]] = 0
-            return (inv / inv.sum(dim=-1, keepdim=True)).t().contiguous()
-        w = torch.zeros_like(d)
-        w.scatter_(1, d.argmin(dim=1, keepdim=True), 1.0)
-        return w.t().contiguous()
+    def _centroids_host(self):
+        if self._cent_host is None:
+            c = self.centroids.detach().float().cpu().contiguous().view(-1).tolist()
+            self._cent_host = (C.c_float * len(c))(*c)
+        return self._cent_host
 
-    def _run(self, x_in: torch.Tensor, pos: torch.Tensor, dirs_rows, idx_rows, out: torch.Tensor, sigma_only: bool,
-             noise: Optional[torch.Tensor], sh_deg: int):
-        w = self._route(pos)
+    def _routed(self, pos: torch.Tensor, pos_stride: int, xyz: torch.Tensor, xyz_stride: int,
+                dirs: Optional[torch.Tensor], dir_stride: int, idx: Optional[torch.Tensor], idx_stride: int,
+                rows_per_ray: int, B: int, out: torch.Tensor, noise: Optional[torch.Tensor], sigma_only: bool, sh_deg: int,
+                n_units: Optional[torch.Tensor], rows_per_unit: int) -> None:
+        """out [B, C] = sum_i w_i * cell_i(rows routed to i).  All pointers are views into caller-owned buffers."""
+        lib = N.lib()
+        dev = out.device
+        n_sub = len(self.sub_modules)
+        ncol = out.shape[1]
+        weights = torch.empty(n_sub, B, device=dev, dtype=torch.float32)
+        lists = torch.empty(n_sub, B, device=dev, dtype=torch.int32)
+        counts = torch.empty(n_sub, device=dev, dtype=torch.int32)
+        N.check(lib.mnr_route(pos.data_ptr(), pos_stride, B, N.ptr(n_units), rows_per_unit, self._centroids_host(), n_sub,
+                              self.cluster_dim_start, float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(),
+                              counts.data_ptr(), N.stream_ptr()))
         out.zero_()
+        sub_out = torch.empty(B, ncol, device=dev, dtype=torch.float32)
+        blend = self.boundary_margin > 1
         for i, child in enumerate(self.sub_modules):
-            rows = torch.nonzero(w[i] > 0, as_tuple=False).view(-1)      # host sync, like mega_nerf.py:38
-            if rows.numel() == 0:
-                continue
-            xi = x_in.index_select(0, rows)
-            di = dirs_rows.index_select(0, rows) if dirs_rows is not None else None
-            ii = idx_rows.index_select(0, rows) if idx_rows is not None else None
-            ni = noise.index_select(0, rows) if noise is not None else None
-            sub = torch.empty(rows.numel(), out.shape[1], device=out.device, dtype=torch.float32)
-            child.evaluate(xi, xi.shape[1], di, 3, ii, 1, 1, rows.numel(), sub, ni, sigma_only, sh_deg)
-            if self.boundary_margin == 1:
-                out.index_copy_(0, rows, sub)
-            else:
-                out.index_add_(0, rows, sub * w[i].index_select(0, rows).unsqueeze(-1))
+            io = child.mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, sub_out, noise,
+                              counts[i:i + 1], 1)
+            io.row_index = lists[i].data_ptr()
+            io.sigma_only = 1 if sigma_only else 0
+            io.apply_sh_deg = sh_deg
+            child.launch(io)
+            N.check(lib.mnr_route_accumulate(out.data_ptr(), ncol, sub_out.data_ptr(), ncol, ncol, lists[i].data_ptr(),
+                                             counts[i:i + 1].data_ptr(), B, weights[i].data_ptr() if blend else None,
+                                             0 if blend else 1, N.stream_ptr()))
 
     def evaluate_routed(self, xyz: torch.Tensor, part, S: int, out: torch.Tensor, noise, sh_deg: int):
-        """Render-path entry: xyz [n, S, 3|4|7], per-ray dirs/idx in ``part``."""
-        n = xyz.shape[0]
-        if part.n_units is not None:
-            n = min(n, int(part.n_units.item()))                         # compacted background rays
-            if n == 0:
-                return
-        x = xyz[:n].reshape(n * S, xyz.shape[-1])
-        pos = x[:, :3]
-        x_in = x[:, 3:].contiguous() if self.xyz_real else x
+        """Render-path entry: xyz [n, S, 3] (fg) or [n, S, 7] = [xyz_real | sphere point | 1/r] (bg, quirk Q15);
+        per-ray dirs / image indices in ``part``; ``out`` [n, S, 4]."""
+        n, ncol_in = xyz.shape[0], xyz.shape[-1]
         child0 = self.sub_modules[0]
         need_dir = child0.has_dir or sh_deg >= 0
-        dirs_rows = part.dirs[:n].unsqueeze(1).expand(n, S, 3).reshape(n * S, 3) if need_dir else None
-        idx_rows = None
-        if child0.embedding_a is not None:
-            idx_rows = part.idx[:n].unsqueeze(1).expand(n, S).reshape(n * S).contiguous()
-        self._run(x_in, pos, dirs_rows.contiguous() if dirs_rows is not None else None, idx_rows,
-                  out.view(-1, out.shape[-1])[:n * S], False, noise[:n * S] if noise is not None else None, sh_deg)
+        x_in = xyz.view(-1, ncol_in)[:, 3:] if self.xyz_real else xyz.view(-1, ncol_in)   # pointer offset only
+        self._routed(xyz, ncol_in, x_in, ncol_in, part.dirs if need_dir else None, part.dirs.stride(0) if need_dir else 0,
+                     part.idx if child0.embedding_a is not None else None, 1, S, n * S, out.view(-1, out.shape[-1]), noise,
+                     False, sh_deg, part.n_units, S)
 
     def forward(self, x: torch.Tensor, sigma_only: bool = False,
                 sigma_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         N.require_device(x, 'x')
         child0 = self.sub_modules[0]
         x = x.contiguous().float()
-        pos = x[:, :3]
-        x_in = x[:, 3:].contiguous() if self.xyz_real else x
-        D = child0.xyz_dim
-        dirs_rows = idx_rows = None
+        B, ncol = x.shape
+        off = 3 if self.xyz_real else 0
+        x_in = x[:, off:]
+        dirs = idx = None
         if not sigma_only:
             if child0.has_dir:
-                dirs_rows = x_in[:, x_in.shape[1] - 4:x_in.shape[1] - 1].contiguous()
+                dirs = x[:, ncol - 4:]
             if child0.embedding_a is not None:
-                idx_rows = x_in[:, -1].contiguous()
-        out = torch.empty(x.shape[0], 1 if sigma_only else child0.rgb_dim + 1, device=x.device, dtype=torch.float32)
-        self._run(x_in[:, :D].contiguous() if not sigma_only else x_in, pos, dirs_rows, idx_rows, out, sigma_only,
-                  sigma_noise.view(-1) if sigma_noise is not None else None, -1)
+                idx = x[:, ncol - 1:]
+        out = torch.empty(B, 1 if sigma_only else child0.rgb_dim + 1, device=x.device, dtype=torch.float32)
+        if B == 0:
+            return out
+        noise = sigma_noise.contiguous().float().view(-1) if sigma_noise is not None else None
+        self._routed(x, ncol, x_in, ncol, dirs, ncol, idx, ncol, 1, B, out, noise, sigma_only, -1, None, 0)
         return out

@@ -137,6 +137,11 @@ class NeRF(nn.Module):
         N.check(N.lib().mnr_mlp_forward(packed.data_ptr(), C.byref(desc), C.byref(io), N.stream_ptr()))
         return out
 
+    def launch(self, io: 'N.MlpIO') -> None:
+        """Enqueue one inference launch described by a caller-built ``mnr_mlp_io``."""
+        desc, packed = self.packed()
+        N.check(N.lib().mnr_mlp_forward(packed.data_ptr(), C.byref(desc), C.byref(io), N.stream_ptr()))
+
     # ---- training plumbing --------------------------------------------------------------------
     def packed_bwd(self):
         """Transposed weight image for the data-gradient chain (same cache key as :meth:`packed`)."""

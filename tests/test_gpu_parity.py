@@ -521,3 +521,26 @@ def test_train_step_reduces_loss():
     losses = [float(step(rays, idx, tgt)[0]) for _ in range(8)]
     assert np.isfinite(losses).all()
     assert losses[-1] < losses[0]
+
+
+def test_meganerf_router_forward_matches_oracle():
+    """MegaNeRF.forward (device routing + gathered per-cell launches) vs the numpy oracle, hard and blended."""
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    hp, cfg, _ = mlp_variant('fg')
+    rng = np.random.default_rng(4)
+    cent = np.array([[0, -.4, -.4], [0, -.4, .4], [0, .4, -.4], [0, .4, .4]], f32)
+    subs_w = [common.make_weights(cfg, 100, 300 + i, sharpen=False) for i in range(4)]
+    B = 1000
+    x = np.concatenate([rng.uniform(-.8, .8, (B, 3)), rng.standard_normal((B, 3)), rng.integers(0, 100, (B, 1))], 1).astype(f32)
+    for margin in (1.0, 1.15):
+        m = MegaNeRF([native_nerf(cfg, w) for w in subs_w], torch.from_numpy(cent), margin, False, False).to(DEV).eval()
+        with torch.no_grad():
+            got = m(T(x)).cpu().numpy()
+            got_s = m(T(x[:, :3]), sigma_only=True).cpu().numpy()
+        exp = O.mega_nerf_forward(subs_w, cfg, cent, margin, False, False, x)
+        exp_s = O.mega_nerf_forward(subs_w, cfg, cent, margin, False, False, x[:, :3], sigma_only=True)
+        # a sample whose distance ratio sits within rounding of the margin may be blended differently: allow a few
+        bad = np.abs(got - exp).max(-1) > 1e-4 * (1 + np.abs(exp).max(-1))
+        assert bad.mean() < 5e-3, (margin, bad.mean())
+        bad = np.abs(got_s - exp_s).max(-1) > 1e-4 * (1 + np.abs(exp_s).max(-1))
+        assert bad.mean() < 5e-3, (margin, bad.mean())
