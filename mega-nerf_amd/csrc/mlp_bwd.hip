@@ -98,6 +98,26 @@ __device__ __forceinline__ void relu_mask_store(float (&g)[NH], const float *act
     }
 }
 
+// The ReLU masks of the layer about to be produced do not depend on the MFMA results: issue their loads BEFORE the
+// layer's MFMA loop and consume them after it (the values just sit in registers; no use before the loop, so no wait).
+template <int P, int NH>
+__device__ __forceinline__ void mask_prefetch(float4 (&m)[NH / 4], const float *act_row, int part) {
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) m[q] = *reinterpret_cast<const float4 *>(act_row + 4 * P * q + 4 * part);
+}
+template <int P, int NH>
+__device__ __forceinline__ void mask_apply_store(float (&g)[NH], const float4 (&m)[NH / 4], float *g_row, int part, bool valid) {
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) {
+        g[4 * q + 0] = m[q].x > 0.f ? g[4 * q + 0] : 0.f;
+        g[4 * q + 1] = m[q].y > 0.f ? g[4 * q + 1] : 0.f;
+        g[4 * q + 2] = m[q].z > 0.f ? g[4 * q + 2] : 0.f;
+        g[4 * q + 3] = m[q].w > 0.f ? g[4 * q + 3] : 0.f;
+        if (valid)
+            *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+    }
+}
+
 template <int NOB, class AccT>
 __device__ __forceinline__ void zero_acc(AccT (&acc)[NOB]) {
 #pragma unroll
@@ -217,22 +237,24 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
                 acc[ob][4 * q + 0] = ds * w4.x; acc[ob][4 * q + 1] = ds * w4.y;
                 acc[ob][4 * q + 2] = ds * w4.z; acc[ob][4 * q + 3] = ds * w4.w;
             }
+        float4 bits[H / 4];
+        mask_prefetch<P, H>(bits, a.tape + a.tl.act_off[C::NL - 1] * cap + trow * W, part);
         st.next_chunk();
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
-        relu_mask_store<P>(g, a.tape + a.tl.act_off[C::NL - 1] * cap + trow * W, a.gtape + a.tl.act_off[C::NL - 1] * cap + trow * W,
-                           part, valid);
+        mask_apply_store<P>(g, bits, a.gtape + a.tl.act_off[C::NL - 1] * cap + trow * W, part, valid);
     }
 
     // ---- trunk layers L-1 .. 1 transposed ------------------------------------------------------------
     static_for<0, C::NL - 1>([&](auto jc) {
         constexpr int l = C::NL - 1 - decltype(jc)::value;       // consumes dZ_l, produces dZ_{l-1}
         zero_acc(acc);
+        float4 bits[H / 4];
+        mask_prefetch<P, H>(bits, a.tape + a.tl.act_off[l - 1] * cap + trow * W, part);
         st.next_chunk();
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
-        relu_mask_store<P>(g, a.tape + a.tl.act_off[l - 1] * cap + trow * W, a.gtape + a.tl.act_off[l - 1] * cap + trow * W, part,
-                           valid);
+        mask_apply_store<P>(g, bits, a.gtape + a.tl.act_off[l - 1] * cap + trow * W, part, valid);
     });
 }
 

@@ -301,8 +301,11 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     """Enqueue the whole render on the current stream.  Returns (results, n_bg_dev, err_flag_dev); the two
     device scalars are None without a background model.  No host synchronisation."""
     N.require_device(rays, 'rays')
-    if torch.is_grad_enabled() and any(p.requires_grad for m in (nerf, bg_nerf) if m is not None for p in m.parameters()):
-        from mega_nerf.training import render_rays_train       # differentiable path (hand-written backward)
+    if (torch.is_grad_enabled() and not (get_depth or get_bg_fg_rgb)
+            and any(p.requires_grad for m in (nerf, bg_nerf) if m is not None for p in m.parameters())):
+        # differentiable path (hand-written backward) for the trainer's flag set (runner.py:349-358); renders that
+        # ask for depth / fg-bg splits are evaluation renders and take the inference path below (no graph)
+        from mega_nerf.training import render_rays_train
         return render_rays_train(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth,
                                  get_depth_variance, get_bg_fg_rgb, _randoms)
     lib = N.lib()
