@@ -227,7 +227,7 @@ def main():
         else:
             roof, extra_roof = fwd_fine, None
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), target.cpu().numpy(), fw, bw, fcfg, bcfg,
                                min(1024, args.rays), args.mode)
         line = {

@@ -544,3 +544,21 @@ def test_meganerf_router_forward_matches_oracle():
         assert bad.mean() < 5e-3, (margin, bad.mean())
         bad = np.abs(got_s - exp_s).max(-1) > 1e-4 * (1 + np.abs(exp_s).max(-1))
         assert bad.mean() < 5e-3, (margin, bad.mean())
+
+
+def test_psnr_within_0p05_db_of_reference():
+    """North-star PSNR criterion on identical rays/weights: PSNR of our render and of the reference render against the
+    same target image differ by far less than 0.05 dB (fg+bg eval fixture, 96 rays)."""
+    from mega_nerf.metrics import psnr
+    from mega_nerf.rendering import render_rays
+    g = load('render_fgbg_eval')
+    hp, nerf, bg_nerf = native_models('render_fgbg_eval')
+    s = common.SCENE
+    with torch.no_grad():
+        res, _ = render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)),
+                             T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    rng = np.random.default_rng(0)
+    ref = torch.from_numpy(g['res_rgb_fine'])
+    for target in (torch.from_numpy(rng.uniform(0, 1, ref.shape).astype(f32)), (ref + 0.01 * torch.randn_like(ref)).clamp(0, 1)):
+        assert abs(psnr(res['rgb_fine'].cpu(), target) - psnr(ref, target)) < 0.05
+    assert psnr(res['rgb_fine'].cpu(), ref) > 80.0          # image-level agreement with the reference itself
