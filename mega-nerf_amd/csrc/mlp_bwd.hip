@@ -461,21 +461,40 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
     if (rb >= re) return;
     const long r0 = row0 + rb, r1 = row0 + re;
     const int t = threadIdx.x;
+    // 4 independent accumulators per output so that 4 row loads are in flight per thread (latency-bound otherwise)
     for (int f0 = 0; f0 < W; f0 += 256) {                  // sigma head: thread t <-> feature f0 + t
         const int f = f0 + t;
-        float s = 0.f;
-        if (f < W) for (long r = r0; r < r1; ++r) s = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s);
-        if (f < W) atomicAdd(d_sigma_w + f, s);
+        if (f < W) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            long r = r0;
+            for (; r + 3 < r1; r += 4) {
+                s0 = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s0);
+                s1 = fmaf(dheads[(r + 1) * 4 + 3], a_last[(r + 1) * W + f], s1);
+                s2 = fmaf(dheads[(r + 2) * 4 + 3], a_last[(r + 2) * W + f], s2);
+                s3 = fmaf(dheads[(r + 3) * 4 + 3], a_last[(r + 3) * W + f], s3);
+            }
+            for (; r < r1; ++r) s0 = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s0);
+            atomicAdd(d_sigma_w + f, (s0 + s1) + (s2 + s3));
+        }
     }
     for (int f0 = 0; f0 < W2; f0 += 256) {                 // rgb head
         const int f = f0 + t;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         if (f < W2) {
-            for (long r = r0; r < r1; ++r) {
-                const float d = dact[r * W2 + f];
-                s0 = fmaf(dheads[r * 4 + 0], d, s0); s1 = fmaf(dheads[r * 4 + 1], d, s1); s2 = fmaf(dheads[r * 4 + 2], d, s2);
+            float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            long r = r0;
+            for (; r + 1 < r1; r += 2) {
+                const float da = dact[r * W2 + f], db = dact[(r + 1) * W2 + f];
+                const float4 ha = *reinterpret_cast<const float4 *>(dheads + r * 4), hb = *reinterpret_cast<const float4 *>(dheads + (r + 1) * 4);
+                s[0][0] = fmaf(ha.x, da, s[0][0]); s[0][1] = fmaf(ha.y, da, s[0][1]); s[0][2] = fmaf(ha.z, da, s[0][2]);
+                s[1][0] = fmaf(hb.x, db, s[1][0]); s[1][1] = fmaf(hb.y, db, s[1][1]); s[1][2] = fmaf(hb.z, db, s[1][2]);
             }
-            atomicAdd(d_rgb_w + f, s0); atomicAdd(d_rgb_w + W2 + f, s1); atomicAdd(d_rgb_w + 2 * W2 + f, s2);
+            for (; r < r1; ++r) {
+                const float d = dact[r * W2 + f];
+                s[0][0] = fmaf(dheads[r * 4 + 0], d, s[0][0]); s[0][1] = fmaf(dheads[r * 4 + 1], d, s[0][1]);
+                s[0][2] = fmaf(dheads[r * 4 + 2], d, s[0][2]);
+            }
+            atomicAdd(d_rgb_w + f, s[0][0] + s[1][0]); atomicAdd(d_rgb_w + W2 + f, s[0][1] + s[1][1]);
+            atomicAdd(d_rgb_w + 2 * W2 + f, s[0][2] + s[1][2]);
         }
     }
     if (t < 4) {                                           // biases
@@ -569,7 +588,7 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     const TapeLayout &tl = a.tl;
     const long cap = io->tape_rows;
     const int W = d->layer_dim;
-    hipLaunchKernelGGL(k_head_grads, dim3(256), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
+    hipLaunchKernelGGL(k_head_grads, dim3(1024), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
                        io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
                        io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b);
     return check_launch("k_head_grads");

@@ -171,6 +171,19 @@ def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.T
         N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gf), N.stream_ptr()))
 
 
+def _zero_grads(names, params) -> Dict[str, torch.Tensor]:
+    """Gradient tensors of all parameters of one model as views of ONE zero-filled buffer (a single memset)."""
+    if not params:
+        return {}
+    sizes = [(p.numel() + 3) // 4 * 4 for p in params]          # keep every view 16-byte aligned
+    flat = torch.zeros(sum(sizes), device=params[0].device, dtype=torch.float32)
+    out, o = {}, 0
+    for k, p, n in zip(names, params, sizes):
+        out[k] = flat[o:o + p.numel()].view(p.shape)
+        o += n
+    return out
+
+
 def _param_list(m: Optional[nn.Module]):
     return [] if m is None else [(k, p) for k, p in m.named_parameters()]
 
@@ -258,8 +271,8 @@ class RenderFunction(torch.autograd.Function):
         d_rgb = d_rgb.contiguous().float()
         dev = d_rgb.device
         n_fg, n_bgp = len(ctx.names_fg), len(ctx.names_bg)
-        grads_fg = {k: torch.zeros_like(p) for k, p in zip(ctx.names_fg, ctx.params[:n_fg])}
-        grads_bg = {k: torch.zeros_like(p) for k, p in zip(ctx.names_bg, ctx.params[n_fg:n_fg + n_bgp])}
+        grads_fg = _zero_grads(ctx.names_fg, ctx.params[:n_fg])
+        grads_bg = _zero_grads(ctx.names_bg, ctx.params[n_fg:n_fg + n_bgp])
         d_lambda = None
         if bgb is not None:
             d_lambda = _f(ctx.n_rays, device=dev)
