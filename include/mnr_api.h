@@ -127,6 +127,22 @@ typedef struct mnr_mlp_io {
 } mnr_mlp_io;
 
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
+/* Host-side query (no GPU work): 1 if mnr_mlp_forward has a fused kernel for this architecture, else 0. */
+int mnr_fused_supported(const mnr_model_desc *desc);
+
+/* ---- generic-width fallback (layer_dim > 512 or architectures without a fused instantiation) ---------------
+ * One launch per nn.Linear with activations in HBM; same exact-fp32 MFMA arithmetic.  The host sequences them like
+ * nerf.py:115-160 (mega_nerf/models/nerf.py::_evaluate_layerwise). */
+/* out[r][:] = [x, sin(2^0 x), cos(2^0 x), ...] (nerf.py:20-25) of x = src[(r / rows_per_src)][0..D) */
+int mnr_embed(float *out_dev, int64_t ldo, const float *x_dev, int64_t ldx, int D, int L, int64_t rows_per_src, int64_t B,
+              void *stream);
+/* out[r][0..width) = table[idx[r / rows_per_ray]][:]  (nerf.py:149) */
+int mnr_gather_rows(float *out_dev, int64_t ldo, const float *table_dev, int width, int count, const void *idx_dev,
+                    int64_t idx_stride, int idx_is_float, int64_t rows_per_ray, int64_t B, void *stream);
+/* Y[b][n] = act( [X1 | X2][b] . W[n] + bias[n] + row_add[b] ), act: 0 none, 1 ReLU, 2 sigmoid, 3 softplus(x-1) */
+int mnr_linear(float *Y_dev, int64_t ldy, const float *X1_dev, int64_t ldx1, int K1, const float *X2_dev, int64_t ldx2, int K2,
+               const float *W_dev, int64_t ldw, const float *bias_dev, const float *row_add_dev, int64_t B, int N, int act,
+               void *stream);
 
 /* ---- training (the reference obtains all of this from torch autograd over nerf.py:115-160) -------------
  * Forward pass that additionally writes the activation tape (post-ReLU output of every layer, the two

@@ -297,6 +297,21 @@ using namespace mnr;
 static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
                             float *tape, long tape_rows, long tape_row0);
 
+// 1 if mnr_mlp_forward has a register-chained instantiation for this architecture, else 0 (host-side query).
+extern "C" int mnr_fused_supported(const mnr_model_desc *d) {
+    ModelLayout m;
+    if (layout_from_desc(d, m) != MNR_OK) return 0;
+    mnr_mlp_io io{};
+    float dummy;
+    io.xyz = &dummy; io.out = &dummy; io.dir = &dummy; io.idx = &dummy; io.rows_per_ray = 1; io.n_rows = 0;   // n_rows = 0: nothing launches
+    io.apply_sh_deg = -1;
+    static float packed_stub;
+    mnr_model_desc dd = *d;
+    float e = 0.f;
+    if (dd.appearance_dim > 0 && !dd.embedding_a) dd.embedding_a = &e;
+    return mlp_forward_impl(&packed_stub, &dd, &io, nullptr, nullptr, 0, 0) == MNR_OK ? 1 : 0;
+}
+
 extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream) {
     return mlp_forward_impl(packed_dev, d, io, stream, nullptr, 0, 0);
 }

@@ -93,7 +93,8 @@ EXPORTS = [
     'mnr_sample_fine', 'mnr_merge_sorted', 'mnr_sort_rows', 'mnr_composite', 'mnr_bg_blend',
     'mnr_tape_floats_per_row', 'mnr_mlp_forward_train', 'mnr_packed_bwd_bytes', 'mnr_pack_model_bwd',
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
-    'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate',
+    'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
+    'mnr_fused_supported',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -158,6 +159,12 @@ def lib() -> C.CDLL:
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mnr_route_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.mnr_fused_supported.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_embed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
+        _lib.mnr_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                         C.c_int64, C.c_int64, C.c_void_p]
+        _lib.mnr_linear.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.mnr_bg_blend_backward.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
     return _lib
 

@@ -114,6 +114,9 @@ class NeRF(nn.Module):
                  n_units_dev: Optional[torch.Tensor] = None, rows_per_unit: int = 0) -> torch.Tensor:
         """Enqueue one fused MLP launch on the current stream (no host sync).  All tensors are raw device
         buffers; see ``mnr_mlp_io`` in include/mnr_api.h for the row/ray addressing."""
+        if not self.fused_supported():
+            return self._evaluate_layerwise(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
+                                            sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit)
         desc, packed = self.packed()
         io = N.MlpIO()
         io.xyz, io.xyz_stride = xyz.data_ptr(), xyz_stride
@@ -135,6 +138,81 @@ class NeRF(nn.Module):
         io.sigma_only = 1 if sigma_only else 0
         io.apply_sh_deg = apply_sh_deg
         N.check(N.lib().mnr_mlp_forward(packed.data_ptr(), C.byref(desc), C.byref(io), N.stream_ptr()))
+        return out
+
+    # ---- generic-width fallback ----------------------------------------------------------------
+    def fused_supported(self) -> bool:
+        """True if the register-chained kernel has an instantiation for this architecture (queried once)."""
+        if getattr(self, '_fused_ok', None) is None:
+            d = self.model_desc()
+            self._fused_ok = bool(N.lib().mnr_fused_supported(C.byref(d)))
+        return self._fused_ok
+
+    def _evaluate_layerwise(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
+                            sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit):
+        """nerf.py:115-160 as one exact-fp32 MFMA GEMM launch per layer (csrc/layerwise.hip); used for widths /
+        architectures without a fused kernel (e.g. configs/nerf: layer_dim 2048)."""
+        lib, st = N.lib(), N.stream_ptr
+        if n_units_dev is not None:
+            n_rows = min(n_rows, int(n_units_dev.item()) * rows_per_unit)      # the fallback sizes launches on the host
+        if n_rows == 0:
+            return out
+        dev = out.device
+        W, D = self.layer_dim, self.xyz_dim
+        E = D * (1 + 2 * self.pos_xyz_dim)
+        ED = 3 * (1 + 2 * self.pos_dir_dim) if self.has_dir else 0
+        A = self.appearance_dim if (self.embedding_a is not None and self.affine is None) else 0
+        ostride = out.stride(0) if out.dim() > 1 else 1
+        act_sigma = 3 if isinstance(self.sigma_activation, ShiftedSoftplus) else 1
+        chunk = max(rows_per_ray, (32768 // rows_per_ray) * rows_per_ray)
+        f4 = 4
+
+        def lin(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer, rows, act, row_add=None):
+            N.check(lib.mnr_linear(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer.weight.data_ptr(), layer.weight.shape[1],
+                                   layer.bias.data_ptr(), row_add, rows, layer.weight.shape[0], act, st()))
+
+        for r0 in range(0, n_rows, chunk):
+            B = min(chunk, n_rows - r0)
+            ray0 = r0 // rows_per_ray
+            emb = torch.empty(B, E, device=dev)
+            N.check(lib.mnr_embed(emb.data_ptr(), E, xyz.data_ptr() + r0 * xyz_stride * f4, xyz_stride, D, self.pos_xyz_dim, 1,
+                                  B, st()))
+            h, ha = torch.empty(B, W, device=dev), torch.empty(B, W, device=dev)
+            cur, K = emb, E
+            for i, enc in enumerate(self.xyz_encodings):
+                if i in self.skip_layers:
+                    lin(ha.data_ptr(), W, emb.data_ptr(), E, E, cur.data_ptr(), K, K, enc[0], B, 1)
+                else:
+                    lin(ha.data_ptr(), W, cur.data_ptr(), K, K, None, 0, 0, enc[0], B, 1)
+                h, ha = ha, h
+                cur, K = h, W
+            o_ptr = out.data_ptr() + r0 * ostride * f4
+            noise_ptr = sigma_noise.data_ptr() + r0 * f4 if sigma_noise is not None else None
+            sig_col = 0 if sigma_only else self.rgb_dim
+            lin(o_ptr + sig_col * f4, ostride, h.data_ptr(), W, W, None, 0, 0, self.sigma, B, act_sigma, noise_ptr)
+            if sigma_only:
+                continue
+            rgb_act = 2 if self.rgb_dim == 3 else 0
+            if self.has_final:
+                f = torch.empty(B, W, device=dev)
+                lin(f.data_ptr(), W, h.data_ptr(), W, W, None, 0, 0, self.xyz_encoding_final, B, 0)
+                side = torch.empty(B, max(ED + A, 1), device=dev)
+                if ED:
+                    N.check(lib.mnr_embed(side.data_ptr(), ED + A, dirs.data_ptr() + ray0 * dir_stride * f4, dir_stride, 3,
+                                          self.pos_dir_dim, rows_per_ray, B, st()))
+                if A:
+                    isz = idx.element_size()
+                    N.check(lib.mnr_gather_rows(side.data_ptr() + ED * f4, ED + A, self.embedding_a.weight.data_ptr(), A,
+                                                self.appearance_count, idx.data_ptr() + ray0 * idx_stride * isz, idx_stride,
+                                                1 if idx.dtype == torch.float32 else 0, rows_per_ray, B, st()))
+                dact = torch.empty(B, W // 2, device=dev)
+                lin(dact.data_ptr(), W // 2, f.data_ptr(), W, W, side.data_ptr() if ED + A else None, ED + A, ED + A,
+                    self.dir_a_encoding[0], B, 1)
+                lin(o_ptr, ostride, dact.data_ptr(), W // 2, W // 2, None, 0, 0, self.rgb, B, rgb_act)
+            else:
+                lin(o_ptr, ostride, h.data_ptr(), W, W, None, 0, 0, self.rgb, B, rgb_act)
+        if not sigma_only and self.rgb_dim > 3 and apply_sh_deg >= 0:
+            raise NotImplementedError('SH colour epilogue is only available in the fused kernel')
         return out
 
     def launch(self, io: 'N.MlpIO') -> None:

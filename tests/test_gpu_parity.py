@@ -562,3 +562,47 @@ def test_psnr_within_0p05_db_of_reference():
     for target in (torch.from_numpy(rng.uniform(0, 1, ref.shape).astype(f32)), (ref + 0.01 * torch.randn_like(ref)).clamp(0, 1)):
         assert abs(psnr(res['rgb_fine'].cpu(), target) - psnr(ref, target)) < 0.05
     assert psnr(res['rgb_fine'].cpu(), ref) > 80.0          # image-level agreement with the reference itself
+
+
+@pytest.mark.parametrize('kw', [dict(layer_dim=96), dict(layer_dim=2048, appearance_dim=0), dict(layer_dim=96, xyz_dim=4),
+                                dict(layer_dim=160, pos_dir_dim=0, appearance_dim=0), dict(layer_dim=96, layers=6, skip_layers=[3])])
+def test_generic_width_fallback_matches_oracle(kw):
+    """Architectures without a fused instantiation (configs/nerf: layer_dim 2048; odd widths / depths) run through the
+    layer-by-layer exact-fp32 MFMA path and still match the oracle."""
+    kw = dict(kw)
+    xyz_dim = kw.pop('xyz_dim', 3)
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, **kw)
+    cfg = common.model_cfg(hp, xyz_dim, hp.layer_dim)
+    w = common.make_weights(cfg, 100, 77, sharpen=False)
+    m = native_nerf(cfg, w)
+    assert not m.fused_supported()
+    rng = np.random.default_rng(9)
+    B = 300
+    cols = [rng.uniform(-1, 1, (B, xyz_dim))]
+    if cfg.pos_dir_dim > 0:
+        cols.append(rng.standard_normal((B, 3)))
+    if cfg.appearance_dim > 0:
+        cols.append(rng.integers(0, 100, (B, 1)).astype(np.float64))
+    x = np.concatenate(cols, 1).astype(f32)
+    noise = rng.uniform(0, 1, (B, 1)).astype(f32)
+    with torch.no_grad():
+        close(m(T(x)), O.nerf_forward(w, cfg, x), 1e-4, 2e-6)
+        close(m(T(x), sigma_noise=T(noise)), O.nerf_forward(w, cfg, x, sigma_noise=noise), 1e-4, 2e-6)
+        close(m(T(x[:, :xyz_dim]).contiguous(), sigma_only=True), O.nerf_forward(w, cfg, x[:, :xyz_dim], sigma_only=True), 1e-4, 2e-6)
+
+
+def test_cascade_render_with_unfused_width():
+    """configs/nerf-shaped render (cascade, no bg, no appearance -> quirk Q8) at a width that has no fused kernel."""
+    from mega_nerf.models.cascade import Cascade
+    from mega_nerf.rendering import render_rays
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, use_cascade=True, appearance_dim=0, layer_dim=96)
+    cfg = common.model_cfg(hp, 3, 96)
+    wc, wf = common.make_weights(cfg, 100, 5), common.make_weights(cfg, 100, 6)
+    g = load('render_cascade_eval')
+    nerf = Cascade(native_nerf(cfg, wc), native_nerf(cfg, wf)).to(DEV).eval()
+    with torch.no_grad():
+        res, _ = render_rays(nerf, None, T(g['rays']), None, Namespace(**vars(hp)), None, None, True, False, True)
+    ores, _ = O.render_rays(O.Model(cfg, cascade=(wc, wf)), None, g['rays'], None, hp, None, None, True, False, True)
+    assert sorted(res) == sorted(ores)
+    for k in ores:
+        np.testing.assert_allclose(res[k].cpu().numpy(), ores[k], rtol=2e-4, atol=2e-5, err_msg=k)
