@@ -303,6 +303,18 @@ int mnr_bg_blend(float *rgb_dev, float *depth_dev, const float *bg_lambda_dev, c
                  const float *bg_rgb_c_dev, const float *bg_depth_c_dev, int64_t N, float *fg_rgb_out,
                  float *bg_rgb_out, float *fg_depth_out, float *bg_depth_out, void *stream);
 
+/* ---- cluster masks (scripts/create_cluster_masks.py:157-187) ------------------------------------------------
+ * Per ray (rays_dev [n_rays][8] = o, d, near, far): n_samples points z = near (1 - t) + far t with t = z_steps_dev[s]
+ * (the CPU torch.linspace(0, 1, n_samples) table), distance of each point to every centroid exactly as torch.cdist
+ * computes it (matmul formulation, :174-175), ratio = dist / (min over centroids + 1e-8) (:184), and the minimum ratio
+ * over the samples of the ray for every centroid.
+ *   ratios_out [n_rays][n_centroids] float (nullable)  == min_dist_ratio, :184
+ *   masks_out  [n_centroids][n_rays] uint8 (nullable)  == ratio <= boundary_margin, :203-204 (one plane per cell)
+ *   centroids_dev [n_centroids][3]; cluster_2d != 0 ignores the altitude axis (:111). At most 64 centroids. */
+int mnr_cluster_min_ratios(float *ratios_out, uint8_t *masks_out, const float *rays_dev, int64_t n_rays,
+                           const float *z_steps_dev, int n_samples, const float *centroids_dev, int n_centroids,
+                           int cluster_2d, float boundary_margin, void *stream);
+
 /* ---- backward of the rendering stages (training; autograd over rendering.py:102-131,336-393) --------- */
 
 /* Gradient of mnr_composite's rgb (and bg_lambda) output w.r.t. the raw MLP outputs. Inputs as in the forward
