@@ -129,6 +129,8 @@ typedef struct mnr_mlp_io {
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
 /* Host-side query (no GPU work): 1 if mnr_mlp_forward has a fused kernel for this architecture, else 0. */
 int mnr_fused_supported(const mnr_model_desc *desc);
+/* ... and 1 if the fused training kernels (mnr_mlp_forward_train / mnr_mlp_backward_*) cover it. */
+int mnr_fused_train_supported(const mnr_model_desc *desc);
 
 /* ---- generic-width fallback (layer_dim > 512 or architectures without a fused instantiation) ---------------
  * One launch per nn.Linear with activations in HBM; same exact-fp32 MFMA arithmetic.  The host sequences them like
@@ -143,6 +145,28 @@ int mnr_gather_rows(float *out_dev, int64_t ldo, const float *table_dev, int wid
 int mnr_linear(float *Y_dev, int64_t ldy, const float *X1_dev, int64_t ldx1, int K1, const float *X2_dev, int64_t ldx2, int K2,
                const float *W_dev, int64_t ldw, const float *bias_dev, const float *row_add_dev, int64_t B, int N, int act,
                void *stream);
+
+/* Adjoint of the layer-by-layer path (training of the generic-width architectures; autograd of nerf.py:115-160).
+ * C[m][n] (op)= sum_k A(m,k) B(n,k) with A(m,k) = A[m sam + k sak], B(n,k) = B[n sbn + k sbk] (exact fp32 MFMA):
+ *   data gradient    dX = G W       : A = G (sam = ldg, sak = 1),  B = W (sbn = 1, sbk = ldw)
+ *   weight gradient  dW += G^T X    : A = G (sam = 1, sak = ldg),  B = X (sbn = 1, sbk = ldx),  K = rows
+ * accumulate 0: C = ..., 1: C += ...; split_k > 1 splits K over workgroups (atomic adds, needs accumulate = 1), 0 = auto */
+int mnr_gemm(float *C_dev, int64_t ldc, const float *A_dev, int64_t sam, int64_t sak, const float *B_dev, int64_t sbn,
+             int64_t sbk, int64_t M, int N, int64_t K, int accumulate, int split_k, void *stream);
+/* G = dY * act'(Y), act' written through the layer output Y (act codes of mnr_linear); G may alias dY */
+int mnr_act_grad(float *G_dev, int64_t ldg, const float *dY_dev, int64_t ldd, const float *Y_dev, int64_t ldy, int64_t R, int N,
+                 int act, void *stream);
+/* out[n] += sum_r G[r][n]  (bias gradients) */
+int mnr_col_sum(float *out_dev, const float *G_dev, int64_t ldg, int64_t R, int N, void *stream);
+/* table_grad[idx[r / rows_per_ray]][0..width) += src[r][0..width)  (gradient of mnr_gather_rows) */
+int mnr_scatter_rows(float *table_grad_dev, int width, int count, const void *idx_dev, int64_t idx_stride, int idx_is_float,
+                     int64_t rows_per_ray, const float *src_dev, int64_t ld_src, int64_t R, void *stream);
+/* Spherical-harmonics colour outside the fused epilogue (rendering.py:300-305, spherical_harmonics.py:55-107):
+ * out[r] = [sigmoid(eval_sh(deg, coef[r] viewed (3, (deg+1)^2), dir[r / rows_per_ray])), coef[r][3 (deg+1)^2]] and its adjoint */
+int mnr_sh_apply(float *out_dev, int64_t ldo, const float *coef_dev, int64_t ldc, const float *dirs_dev, int64_t dir_stride,
+                 int64_t rows_per_ray, int deg, int64_t R, void *stream);
+int mnr_sh_backward(float *d_coef_dev, int64_t ldc, const float *d_out_dev, int64_t ldd, const float *out_dev, int64_t ldo,
+                    const float *dirs_dev, int64_t dir_stride, int64_t rows_per_ray, int deg, int64_t R, void *stream);
 
 /* ---- training (the reference obtains all of this from torch autograd over nerf.py:115-160) -------------
  * Forward pass that additionally writes the activation tape (post-ReLU output of every layer, the two

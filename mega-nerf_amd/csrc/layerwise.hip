@@ -6,7 +6,16 @@
 //   k_gather_rows  appearance-embedding lookup (nerf.py:149)
 //   k_linear       Y = act([X1 | X2] W^T + b (+ per-row noise))      fp32 MFMA GEMM, 128 x 128 tiles
 // The host side (mega_nerf/models/nerf.py::_evaluate_layerwise) sequences them exactly like nerf.py:115-160.
+//
+// Training of those architectures (mega_nerf/models/layerwise_train.py) keeps every layer output in HBM and runs the
+// adjoint layer by layer with
+//   k_gemm          C (op)= A B^T for arbitrarily strided operands: data gradients G W and weight gradients G^T X
+//                   (split over the row dimension, atomics into .grad)
+//   k_act_grad      G = dY * act'(Y)          k_col_sum   bias gradients
+//   k_scatter_rows  appearance-embedding gradient (per-ray pre-reduction, then atomics)
+//   k_sh_apply / k_sh_backward   spherical-harmonics colour (rendering.py:300-305) outside the fused epilogue
 #include "common.h"
+#include "sh_device.h"
 
 namespace mnr {
 
@@ -111,6 +120,148 @@ __global__ __launch_bounds__(256) void k_linear(float *__restrict__ Y, long ldy,
         }
 }
 
+
+// ---- generic strided GEMM:  C[m][n] (op)= sum_k A(m,k) B(n,k),  A(m,k) = A[m sam + k sak],  B(n,k) = B[n sbn + k sbk]
+template <bool KFAST>
+__device__ __forceinline__ void lw_stage(float *S, const float *__restrict__ P, long sm, long sk, long m0, long m_lim, long k0,
+                                         long k_lim) {
+    for (int e = threadIdx.x; e < LW_BM * LW_KT; e += 256) {
+        const int r = KFAST ? e / LW_KT : e % LW_BM, kq = KFAST ? e % LW_KT : e / LW_BM;
+        const long m = m0 + r, k = k0 + kq;
+        S[r * LW_LD + kq] = (m < m_lim && k < k_lim) ? P[m * sm + k * sk] : 0.f;
+    }
+}
+
+// mode 0: store, 1: C += (exclusive owner), 2: atomicAdd (split-K partial sums)
+__global__ __launch_bounds__(256) void k_gemm(float *__restrict__ Cmat, long ldc, const float *__restrict__ A, long sam, long sak,
+                                              const float *__restrict__ B, long sbn, long sbk, long M, int N, long K,
+                                              long k_per_split, int mode) {
+    __shared__ float As[LW_BM * LW_LD], Bs[LW_BN * LW_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i32 = lane & 31, kk = lane >> 5;
+    const long m0 = (long)blockIdx.y * LW_BM;
+    const int n0 = blockIdx.x * LW_BN;
+    const long kb = (long)blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = floatx16(0.f);
+    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
+    for (long k0 = kb; k0 < ke; k0 += LW_KT) {
+        __syncthreads();
+        if (a_kfast) lw_stage<true>(As, A, sam, sak, m0, M, k0, ke); else lw_stage<false>(As, A, sam, sak, m0, M, k0, ke);
+        if (b_kfast) lw_stage<true>(Bs, B, sbn, sbk, n0, N, k0, ke); else lw_stage<false>(Bs, B, sbn, sbk, n0, N, k0, ke);
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < LW_KT; k += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = As[(wr * 64 + a * 32 + i32) * LW_LD + k + kk];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = Bs[(wc * 64 + b * 32 + i32) * LW_LD + k + kk];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wc * 64 + b * 32 + i32;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (row >= M) continue;
+                float *dst = Cmat + row * ldc + n;
+                if (mode == 0) *dst = acc[a][b][r];
+                else if (mode == 1) *dst += acc[a][b][r];
+                else atomicAdd(dst, acc[a][b][r]);
+            }
+        }
+}
+
+// G = dY * act'(Y) expressed through the layer OUTPUT Y (what the forward kept): relu Y > 0, sigmoid Y (1 - Y),
+// shifted softplus 1 - exp(-Y) (= sigmoid of the pre-activation; 1 beyond the threshold in fp32)
+__global__ void k_act_grad(float *__restrict__ G, long ldg, const float *__restrict__ dY, long ldd, const float *__restrict__ Y,
+                           long ldy, long R, int N, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * N) return;
+    const long r = i / N;
+    const int n = (int)(i % N);
+    const float y = Y[r * ldy + n], d = dY[r * ldd + n];
+    float g = d;
+    if (act == 1) g = y > 0.f ? d : 0.f;
+    else if (act == 2) g = d * (y * (1.f - y));
+    else if (act == 3) g = d * (1.f - expf(-y));
+    G[r * ldg + n] = g;
+}
+
+// out[n] += sum_r G[r][n]: 64 columns x 4 row phases per block over a 1024-row slab
+__global__ __launch_bounds__(256) void k_col_sum(float *__restrict__ out, const float *__restrict__ G, long ldg, long R, int N) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * 1024, r1 = min(R, r0 + 1024);
+    float s = 0.f;
+    if (n < N)
+        for (long r = r0 + ph; r < r1; r += 4) s += G[r * ldg + n];
+    part[ph][c] = s;
+    __syncthreads();
+    if (ph == 0 && n < N) atomicAdd(out + n, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+}
+
+// table_grad[idx[ray]][c] += sum over the ray's rows of src[row][c]
+__global__ void k_scatter_rows(float *__restrict__ table_grad, int width, int count, const void *__restrict__ idx, long idx_stride,
+                               int idx_is_float, long rows_per_ray, const float *__restrict__ src, long lds_, long R) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n_rays = (R + rows_per_ray - 1) / rows_per_ray;
+    if (i >= n_rays * width) return;
+    const long ray = i / width;
+    const int c = (int)(i % width);
+    long k = idx_is_float ? (long)reinterpret_cast<const float *>(idx)[ray * idx_stride]
+                          : (long)reinterpret_cast<const int32_t *>(idx)[ray * idx_stride];
+    k = k < 0 ? 0 : (k >= count ? count - 1 : k);
+    float s = 0.f;
+    const long r1 = min(R, (ray + 1) * rows_per_ray);
+    for (long r = ray * rows_per_ray; r < r1; ++r) s += src[r * lds_ + c];
+    atomicAdd(table_grad + k * width + c, s);
+}
+
+// out[r] = [sigmoid(eval_sh(coef[r][c][:], dir(r))) for c in RGB, sigma]   (rendering.py:300-305; coef is channel-major)
+__global__ void k_sh_apply(float *__restrict__ out, long ldo, const float *__restrict__ coef, long ldc, const float *__restrict__ dirs,
+                           long dir_stride, long rows_per_ray, int deg, long R) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int nb = (deg + 1) * (deg + 1);
+    const float *d = dirs + (r / rows_per_ray) * dir_stride;
+    const float *c = coef + r * ldc;
+    for (int ch = 0; ch < 3; ++ch) out[r * ldo + ch] = 1.f / (1.f + expf(-eval_sh_channel(deg, c + ch * nb, d[0], d[1], d[2])));
+    out[r * ldo + 3] = c[3 * nb];
+}
+
+// d_coef[r][c][k] = d_out[r][c] * s (1 - s) * basis_k(dir);  d_coef[r][3 nb] = d_out[r][3]   (s = out[r][c])
+__global__ void k_sh_backward(float *__restrict__ d_coef, long ldc, const float *__restrict__ d_out, long ldd,
+                              const float *__restrict__ out, long ldo, const float *__restrict__ dirs, long dir_stride,
+                              long rows_per_ray, int deg, long R) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int nb = (deg + 1) * (deg + 1);
+    const float *d = dirs + (r / rows_per_ray) * dir_stride;
+    float b[25];
+    sh_basis(deg, d[0], d[1], d[2], b);
+    for (int ch = 0; ch < 3; ++ch) {
+        const float s = out[r * ldo + ch];
+        const float g = d_out[r * ldd + ch] * (s * (1.f - s));
+        for (int k = 0; k < nb; ++k) d_coef[r * ldc + ch * nb + k] = g * b[k];
+    }
+    d_coef[r * ldc + 3 * nb] = d_out[r * ldd + 3];
+}
+
 }  // namespace mnr
 
 using namespace mnr;
@@ -144,4 +295,74 @@ extern "C" int mnr_linear(float *Y, int64_t ldy, const float *X1, int64_t ldx1, 
     hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, as_stream(stream), Y, (long)ldy, X1, (long)ldx1, K1, X2, (long)ldx2, K2, W,
                        (long)ldw, bias, row_add, (long)B, N, act);
     return check_launch("k_linear");
+}
+
+extern "C" int mnr_gemm(float *C, int64_t ldc, const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbn, int64_t sbk,
+                        int64_t M, int N, int64_t K, int accumulate, int split_k, void *stream) {
+    MNR_REQUIRE(C && A && B && M >= 0 && N > 0 && K >= 0 && accumulate >= 0 && accumulate <= 1 && split_k >= 0,
+                "bad arguments to mnr_gemm");
+    if (M == 0) return MNR_OK;
+    const long tiles_m = (M + LW_BM - 1) / LW_BM, tiles_n = (N + LW_BN - 1) / LW_BN;
+    MNR_REQUIRE(tiles_m <= 65535, "too many rows for one mnr_gemm launch (chunk the batch)");
+    long splits = split_k;
+    if (splits == 0) {   // auto: enough workgroups to fill 256 CUs a few times over, at least 512 reduction steps each
+        splits = (2048 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n);
+        const long max_splits = (K + 511) / 512;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    MNR_REQUIRE(splits == 1 || accumulate == 1, "mnr_gemm: split_k > 1 accumulates atomically and needs accumulate = 1");
+    long kps = (K + splits - 1) / splits;
+    kps = (kps + LW_KT - 1) / LW_KT * LW_KT;
+    splits = K > 0 ? (K + kps - 1) / kps : 1;
+    const int mode = accumulate == 0 ? 0 : (splits > 1 ? 2 : 1);
+    hipLaunchKernelGGL(k_gemm, dim3((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)splits), dim3(256), 0, as_stream(stream), C,
+                       (long)ldc, A, (long)sam, (long)sak, B, (long)sbn, (long)sbk, (long)M, N, (long)K, kps, mode);
+    return check_launch("k_gemm");
+}
+
+extern "C" int mnr_act_grad(float *G, int64_t ldg, const float *dY, int64_t ldd, const float *Y, int64_t ldy, int64_t R, int N,
+                            int act, void *stream) {
+    MNR_REQUIRE(G && dY && Y && R >= 0 && N > 0 && act >= 0 && act <= 3, "bad arguments to mnr_act_grad");
+    if (R == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_act_grad, dim3((unsigned)((R * N + 255) / 256)), dim3(256), 0, as_stream(stream), G, (long)ldg, dY,
+                       (long)ldd, Y, (long)ldy, (long)R, N, act);
+    return check_launch("k_act_grad");
+}
+
+extern "C" int mnr_col_sum(float *out, const float *G, int64_t ldg, int64_t R, int N, void *stream) {
+    MNR_REQUIRE(out && G && R >= 0 && N > 0, "bad arguments to mnr_col_sum");
+    if (R == 0) return MNR_OK;
+    MNR_REQUIRE((R + 1023) / 1024 <= 65535, "too many rows for one mnr_col_sum launch");
+    hipLaunchKernelGGL(k_col_sum, dim3((N + 63) / 64, (unsigned)((R + 1023) / 1024)), dim3(256), 0, as_stream(stream), out, G,
+                       (long)ldg, (long)R, N);
+    return check_launch("k_col_sum");
+}
+
+extern "C" int mnr_scatter_rows(float *table_grad, int width, int count, const void *idx, int64_t idx_stride, int idx_is_float,
+                                int64_t rows_per_ray, const float *src, int64_t ld_src, int64_t R, void *stream) {
+    MNR_REQUIRE(table_grad && idx && src && width > 0 && count > 0 && rows_per_ray >= 1 && R >= 0, "bad arguments to mnr_scatter_rows");
+    if (R == 0) return MNR_OK;
+    const long n = (R + rows_per_ray - 1) / rows_per_ray * width;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), table_grad, width, count,
+                       idx, (long)idx_stride, idx_is_float, (long)rows_per_ray, src, (long)ld_src, (long)R);
+    return check_launch("k_scatter_rows");
+}
+
+extern "C" int mnr_sh_apply(float *out, int64_t ldo, const float *coef, int64_t ldc, const float *dirs, int64_t dir_stride,
+                            int64_t rows_per_ray, int deg, int64_t R, void *stream) {
+    MNR_REQUIRE(out && coef && dirs && deg >= 0 && deg <= 4 && rows_per_ray >= 1 && R >= 0, "bad arguments to mnr_sh_apply");
+    if (R == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_sh_apply, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), out, (long)ldo, coef, (long)ldc,
+                       dirs, (long)dir_stride, (long)rows_per_ray, deg, (long)R);
+    return check_launch("k_sh_apply");
+}
+
+extern "C" int mnr_sh_backward(float *d_coef, int64_t ldc, const float *d_out, int64_t ldd, const float *out, int64_t ldo,
+                               const float *dirs, int64_t dir_stride, int64_t rows_per_ray, int deg, int64_t R, void *stream) {
+    MNR_REQUIRE(d_coef && d_out && out && dirs && deg >= 0 && deg <= 4 && rows_per_ray >= 1 && R >= 0, "bad arguments to mnr_sh_backward");
+    if (R == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_sh_backward, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), d_coef, (long)ldc, d_out,
+                       (long)ldd, out, (long)ldo, dirs, (long)dir_stride, (long)rows_per_ray, deg, (long)R);
+    return check_launch("k_sh_backward");
 }

@@ -12,6 +12,7 @@
 // layer, rgb head, sigmoid / shifted softplus -- nothing but the inputs (<= 36 B) and the 16 B result
 // touches HBM.
 #include "mlp_device.h"
+#include "sh_device.h"
 
 namespace mnr {
 
@@ -55,36 +56,6 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
         const int dim = j * P + part;
         if (dim < D) r[dim] = e[2 * NP + j];
     }
-}
-
-// spherical_harmonics.py:55-107 (deg <= 4), coefficients c[k] for one colour channel
-__device__ __forceinline__ float eval_sh_channel(int deg, const float *c, float x, float y, float z) {
-    float r = 0.28209479177387814f * c[0];
-    if (deg > 0) {
-        r = r - 0.4886025119029199f * y * c[1] + 0.4886025119029199f * z * c[2] - 0.4886025119029199f * x * c[3];
-        if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            r = r + 1.0925484305920792f * xy * c[4] + -1.0925484305920792f * yz * c[5] +
-                0.31539156525252005f * (2.0f * zz - xx - yy) * c[6] + -1.0925484305920792f * xz * c[7] +
-                0.5462742152960396f * (xx - yy) * c[8];
-            if (deg > 2) {
-                r = r + -0.5900435899266435f * y * (3 * xx - yy) * c[9] + 2.890611442640554f * xy * z * c[10] +
-                    -0.4570457994644658f * y * (4 * zz - xx - yy) * c[11] +
-                    0.3731763325901154f * z * (2 * zz - 3 * xx - 3 * yy) * c[12] +
-                    -0.4570457994644658f * x * (4 * zz - xx - yy) * c[13] + 1.445305721320277f * z * (xx - yy) * c[14] +
-                    -0.5900435899266435f * x * (xx - 3 * yy) * c[15];
-                if (deg > 3) {
-                    r = r + 2.5033429417967046f * xy * (xx - yy) * c[16] + -1.7701307697799304f * yz * (3 * xx - yy) * c[17] +
-                        0.9461746957575601f * xy * (7 * zz - 1) * c[18] + -0.6690465435572892f * yz * (7 * zz - 3) * c[19] +
-                        0.10578554691520431f * (zz * (35 * zz - 30) + 3) * c[20] +
-                        -0.6690465435572892f * xz * (7 * zz - 3) * c[21] + 0.47308734787878004f * (xx - yy) * (7 * zz - 1) * c[22] +
-                        -1.7701307697799304f * xz * (xx - 3 * yy) * c[23] +
-                        0.6258357354491761f * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)) * c[24];
-                }
-            }
-        }
-    }
-    return r;
 }
 
 template <class C, bool TRAIN>
@@ -310,6 +281,21 @@ extern "C" int mnr_fused_supported(const mnr_model_desc *d) {
     float e = 0.f;
     if (dd.appearance_dim > 0 && !dd.embedding_a) dd.embedding_a = &e;
     return mlp_forward_impl(&packed_stub, &dd, &io, nullptr, nullptr, 0, 0) == MNR_OK ? 1 : 0;
+}
+
+// 1 if mnr_mlp_forward_train / mnr_mlp_backward_* have instantiations for this architecture (host-side query).
+extern "C" int mnr_fused_train_supported(const mnr_model_desc *d) {
+    ModelLayout m;
+    if (layout_from_desc(d, m) != MNR_OK) return 0;
+    mnr_mlp_io io{};
+    float dummy;
+    io.xyz = &dummy; io.out = &dummy; io.dir = &dummy; io.idx = &dummy; io.rows_per_ray = 1; io.n_rows = 0;
+    io.apply_sh_deg = -1;
+    static float packed_stub;
+    mnr_model_desc dd = *d;
+    float e = 0.f;
+    if (dd.appearance_dim > 0 && !dd.embedding_a) dd.embedding_a = &e;
+    return mlp_forward_impl(&packed_stub, &dd, &io, nullptr, &dummy, 0, 0) == MNR_OK ? 1 : 0;
 }
 
 extern "C" int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream) {

@@ -94,7 +94,8 @@ EXPORTS = [
     'mnr_tape_floats_per_row', 'mnr_mlp_forward_train', 'mnr_packed_bwd_bytes', 'mnr_pack_model_bwd',
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
     'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
-    'mnr_fused_supported', 'mnr_cluster_min_ratios',
+    'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
+    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -160,12 +161,24 @@ def lib() -> C.CDLL:
         _lib.mnr_route_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib.mnr_fused_supported.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_fused_train_supported.argtypes = [C.POINTER(ModelDesc)]
         _lib.mnr_embed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
         _lib.mnr_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                          C.c_int64, C.c_int64, C.c_void_p]
         _lib.mnr_linear.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.mnr_bg_blend_backward.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
+        _lib.mnr_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        _lib.mnr_act_grad.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                      C.c_int, C.c_void_p]
+        _lib.mnr_col_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        _lib.mnr_scatter_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                          C.c_int64, C.c_int64, C.c_void_p]
+        _lib.mnr_sh_apply.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                      C.c_int64, C.c_void_p]
+        _lib.mnr_sh_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_int64, C.c_int, C.c_int64, C.c_void_p]
         _lib.mnr_cluster_min_ratios.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_float, C.c_void_p]
     return _lib

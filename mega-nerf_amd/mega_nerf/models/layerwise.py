@@ -1,0 +1,184 @@
+"""Layer-by-layer evaluation and adjoint of the NeRF MLP (reference nerf.py:115-160) for architectures the
+register-chained kernel does not cover (layer_dim 2048 of configs/nerf, spherical-harmonics heads, no appearance
+embedding, ...).  One exact-fp32 MFMA GEMM launch per nn.Linear (csrc/layerwise.hip) with layer outputs in HBM;
+when ``keep`` is set they stay alive as the tape of :meth:`LayerwiseTape.backward`.
+
+Inputs are described like ``mnr_mlp_io``: row r reads xyz[r], dir[r // dir_rows], idx[r // rows_per_ray].
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from mega_nerf import _native as N
+
+_F4 = 4
+
+
+def _act_sigma(model) -> int:
+    from mega_nerf.models.nerf import ShiftedSoftplus
+    return 3 if isinstance(model.sigma_activation, ShiftedSoftplus) else 1
+
+
+class LayerwiseTape:
+    """Forward pass over ``B`` rows; with ``keep`` every layer output is retained for :meth:`backward`."""
+
+    def __init__(self, model, xyz: torch.Tensor, xyz_stride: int, dirs: Optional[torch.Tensor], dir_stride: int,
+                 dir_rows: int, idx: Optional[torch.Tensor], idx_stride: int, rows_per_ray: int, B: int, out: torch.Tensor,
+                 out_stride: int, sigma_noise: Optional[torch.Tensor], sigma_only: bool, sh_deg: int, keep: bool,
+                 sh_dirs: Optional[torch.Tensor] = None, sh_dir_stride: int = 0):
+        lib, st = N.lib(), N.stream_ptr
+        m = self.model = model
+        dev = out.device
+        W, D = m.layer_dim, m.xyz_dim
+        E = self.E = D * (1 + 2 * m.pos_xyz_dim)
+        ED = self.ED = 3 * (1 + 2 * m.pos_dir_dim) if m.has_dir else 0
+        A = self.A = m.appearance_dim if (m.embedding_a is not None and m.affine is None) else 0
+        if m.affine is not None:
+            raise NotImplementedError('affine_appearance is not supported by the MI355X kernels')
+        self.B, self.out, self.out_stride, self.sigma_only = B, out, out_stride, sigma_only
+        self.idx, self.idx_stride, self.rows_per_ray = idx, idx_stride, rows_per_ray
+        self.sh = sh_deg >= 0 and m.rgb_dim > 3 and not sigma_only
+        self.sh_deg, self.sh_dirs, self.sh_dir_stride = sh_deg, sh_dirs, sh_dir_stride
+        if self.sh and sh_dirs is None:
+            raise N.NativeError('spherical-harmonics colour needs the ray directions')
+
+        def lin(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer, act, row_add=None):
+            N.check(lib.mnr_linear(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer.weight.data_ptr(), layer.weight.shape[1],
+                                   layer.bias.data_ptr(), row_add, B, layer.weight.shape[0], act, st()))
+
+        emb = torch.empty(B, E, device=dev)
+        N.check(lib.mnr_embed(emb.data_ptr(), E, xyz.data_ptr(), xyz_stride, D, m.pos_xyz_dim, 1, B, st()))
+        hs = []
+        ping = [torch.empty(B, W, device=dev), torch.empty(B, W, device=dev)] if not keep else None
+        cur, K = emb, E
+        for i, enc in enumerate(m.xyz_encodings):
+            h = torch.empty(B, W, device=dev) if keep else ping[i & 1]
+            if i in m.skip_layers:
+                lin(h.data_ptr(), W, emb.data_ptr(), E, E, cur.data_ptr(), K, K, enc[0], 1)
+            else:
+                lin(h.data_ptr(), W, cur.data_ptr(), K, K, None, 0, 0, enc[0], 1)
+            hs.append(h)
+            cur, K = h, W
+        h = cur
+        # raw head outputs: straight into ``out`` unless an SH epilogue follows (then [B, rgb_dim + 1] coefficients)
+        if self.sh:
+            head = torch.empty(B, m.rgb_dim + 1, device=dev)
+            hp, hs_ = head.data_ptr(), m.rgb_dim + 1
+        else:
+            head, hp, hs_ = None, out.data_ptr(), out_stride
+            if not sigma_only and m.rgb_dim + 1 > out_stride:
+                raise N.NativeError('output rows are too narrow for rgb_dim {} (use the SH epilogue)'.format(m.rgb_dim))
+        sig_col = 0 if sigma_only else m.rgb_dim
+        lin(hp + sig_col * _F4, hs_, h.data_ptr(), W, W, None, 0, 0, m.sigma, _act_sigma(m),
+            sigma_noise.data_ptr() if sigma_noise is not None else None)
+        f = side = dact = None
+        if not sigma_only:
+            rgb_act = 2 if m.rgb_dim == 3 else 0
+            if m.has_final:
+                f = torch.empty(B, W, device=dev)
+                lin(f.data_ptr(), W, h.data_ptr(), W, W, None, 0, 0, m.xyz_encoding_final, 0)
+                side = torch.empty(B, max(ED + A, 1), device=dev)
+                if ED:
+                    N.check(lib.mnr_embed(side.data_ptr(), ED + A, dirs.data_ptr(), dir_stride, 3, m.pos_dir_dim, dir_rows, B, st()))
+                if A:
+                    N.check(lib.mnr_gather_rows(side.data_ptr() + ED * _F4, ED + A, m.embedding_a.weight.data_ptr(), A,
+                                                m.appearance_count, idx.data_ptr(), idx_stride,
+                                                1 if idx.dtype == torch.float32 else 0, rows_per_ray, B, st()))
+                dact = torch.empty(B, W // 2, device=dev)
+                lin(dact.data_ptr(), W // 2, f.data_ptr(), W, W, side.data_ptr() if ED + A else None, ED + A, ED + A,
+                    m.dir_a_encoding[0], 1)
+                lin(hp, hs_, dact.data_ptr(), W // 2, W // 2, None, 0, 0, m.rgb, rgb_act)
+            else:
+                lin(hp, hs_, h.data_ptr(), W, W, None, 0, 0, m.rgb, rgb_act)
+            if self.sh:
+                N.check(lib.mnr_sh_apply(out.data_ptr(), out_stride, head.data_ptr(), hs_, sh_dirs.data_ptr(), sh_dir_stride,
+                                         rows_per_ray, sh_deg, B, st()))
+        if keep:
+            self.emb, self.hs, self.f, self.side, self.dact, self.head = emb, hs, f, side, dact, head
+
+    # ------------------------------------------------------------------------------------------------------------
+    def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: Dict[str, torch.Tensor]) -> None:
+        """Accumulate the parameter gradients for d(loss)/d(out) = ``d_out`` [B, out columns] into ``grads``
+        (zero-initialised tensors shaped like the parameters, keyed by parameter name)."""
+        lib, st = N.lib(), N.stream_ptr
+        m, B = self.model, self.B
+        if self.sigma_only:
+            raise NotImplementedError('sigma_only evaluations are inference-only')
+        dev = d_out.device
+        W, E, ED, A = m.layer_dim, self.E, self.ED, self.A
+
+        def wgrad(name, col0, G, ldg, n_out, X, ldx, k_in):
+            g = grads[name]
+            N.check(lib.mnr_gemm(g.data_ptr() + col0 * _F4, g.shape[1], G, 1, ldg, X, 1, ldx, n_out, k_in, B, 1, 0, st()))
+
+        def bgrad(name, G, ldg, n_out):
+            N.check(lib.mnr_col_sum(grads[name].data_ptr(), G, ldg, B, n_out, st()))
+
+        def dgrad(dX, ldx, G, ldg, n_out, layer, col0, k_in, accumulate=0):
+            N.check(lib.mnr_gemm(dX, ldx, G, ldg, 1, layer.weight.data_ptr() + col0 * _F4, 1, layer.weight.shape[1], B, k_in,
+                                 n_out, accumulate, 1, st()))
+
+        if self.sh:
+            C1 = m.rgb_dim + 1
+            d_head = torch.empty(B, C1, device=dev)
+            N.check(lib.mnr_sh_backward(d_head.data_ptr(), C1, d_out.data_ptr(), d_out_stride, self.out.data_ptr(), self.out_stride,
+                                        self.sh_dirs.data_ptr(), self.sh_dir_stride, self.rows_per_ray, self.sh_deg, B, st()))
+            dh_p, dh_s, y_p, y_s = d_head.data_ptr(), C1, self.head.data_ptr(), C1
+        else:
+            dh_p, dh_s, y_p, y_s = d_out.data_ptr(), d_out_stride, self.out.data_ptr(), self.out_stride
+        h_last = self.hs[-1]
+        # rgb head
+        C = m.rgb_dim
+        g_rgb = torch.empty(B, C, device=dev)
+        N.check(lib.mnr_act_grad(g_rgb.data_ptr(), C, dh_p, dh_s, y_p, y_s, B, C, 2 if C == 3 else 0, st()))
+        src, k_src = (self.dact, W // 2) if m.has_final else (h_last, W)
+        wgrad('rgb.weight', 0, g_rgb.data_ptr(), C, C, src.data_ptr(), k_src, k_src)
+        bgrad('rgb.bias', g_rgb.data_ptr(), C, C)
+        d_src = torch.empty(B, k_src, device=dev)
+        dgrad(d_src.data_ptr(), k_src, g_rgb.data_ptr(), C, C, m.rgb, 0, k_src)
+        if m.has_final:
+            H2 = W // 2
+            N.check(lib.mnr_act_grad(d_src.data_ptr(), H2, d_src.data_ptr(), H2, self.dact.data_ptr(), H2, B, H2, 1, st()))
+            wgrad('dir_a_encoding.0.weight', 0, d_src.data_ptr(), H2, H2, self.f.data_ptr(), W, W)
+            if ED + A:
+                wgrad('dir_a_encoding.0.weight', W, d_src.data_ptr(), H2, H2, self.side.data_ptr(), ED + A, ED + A)
+            bgrad('dir_a_encoding.0.bias', d_src.data_ptr(), H2, H2)
+            if A:
+                d_app = torch.empty(B, A, device=dev)
+                dgrad(d_app.data_ptr(), A, d_src.data_ptr(), H2, H2, m.dir_a_encoding[0], W + ED, A)
+                N.check(lib.mnr_scatter_rows(grads['embedding_a.weight'].data_ptr(), A, m.appearance_count, self.idx.data_ptr(),
+                                             self.idx_stride, 1 if self.idx.dtype == torch.float32 else 0, self.rows_per_ray,
+                                             d_app.data_ptr(), A, B, st()))
+            d_f = torch.empty(B, W, device=dev)
+            dgrad(d_f.data_ptr(), W, d_src.data_ptr(), H2, H2, m.dir_a_encoding[0], 0, W)
+            wgrad('xyz_encoding_final.weight', 0, d_f.data_ptr(), W, W, h_last.data_ptr(), W, W)
+            bgrad('xyz_encoding_final.bias', d_f.data_ptr(), W, W)
+            d_h = torch.empty(B, W, device=dev)
+            dgrad(d_h.data_ptr(), W, d_f.data_ptr(), W, W, m.xyz_encoding_final, 0, W)
+            del d_f
+        else:
+            d_h = d_src
+        # sigma head
+        g_sig = torch.empty(B, 1, device=dev)
+        N.check(lib.mnr_act_grad(g_sig.data_ptr(), 1, dh_p + C * _F4, dh_s, y_p + C * _F4, y_s, B, 1, _act_sigma(m), st()))
+        wgrad('sigma.weight', 0, g_sig.data_ptr(), 1, 1, h_last.data_ptr(), W, W)
+        bgrad('sigma.bias', g_sig.data_ptr(), 1, 1)
+        dgrad(d_h.data_ptr(), W, g_sig.data_ptr(), 1, 1, m.sigma, 0, W, accumulate=1)
+        # trunk
+        spare = None
+        for i in range(m.layers - 1, -1, -1):
+            name = 'xyz_encodings.%d.0.' % i
+            N.check(lib.mnr_act_grad(d_h.data_ptr(), W, d_h.data_ptr(), W, self.hs[i].data_ptr(), W, B, W, 1, st()))
+            off = 0
+            if i == 0 or i in m.skip_layers:
+                wgrad(name + 'weight', 0, d_h.data_ptr(), W, W, self.emb.data_ptr(), E, E)
+                off = E
+            if i > 0:
+                wgrad(name + 'weight', off, d_h.data_ptr(), W, W, self.hs[i - 1].data_ptr(), W, W)
+            bgrad(name + 'bias', d_h.data_ptr(), W, W)
+            if i > 0:
+                nxt = spare if spare is not None else torch.empty(B, W, device=dev)
+                dgrad(nxt.data_ptr(), W, d_h.data_ptr(), W, W, m.xyz_encodings[i][0], off, W)
+                spare, d_h = d_h, nxt

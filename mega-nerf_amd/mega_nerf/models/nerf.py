@@ -16,6 +16,14 @@ from torch import nn
 from mega_nerf import _native as N
 
 
+def _off(t: Optional[torch.Tensor], elements: int) -> Optional[torch.Tensor]:
+    """Flat view of ``t``'s storage starting ``elements`` items after its first element (raw-buffer addressing)."""
+    if t is None:
+        return None
+    return t.as_strided((max(t.untyped_storage().nbytes() // t.element_size() - t.storage_offset() - elements, 0),), (1,),
+                        t.storage_offset() + elements)
+
+
 class ShiftedSoftplus(nn.Module):
     """softplus(x - 1) (reference nerf.py:28-39); selects sigma_activation = 1 in the kernel."""
 
@@ -26,6 +34,54 @@ class ShiftedSoftplus(nn.Module):
 def _linear_act(fin: int, fout: int) -> nn.Sequential:
     # the Sequential wrapper only exists to reproduce the checkpoint key "<name>.0.weight"
     return nn.Sequential(nn.Linear(fin, fout), nn.ReLU(True))
+
+
+class NullTape:
+    """Tape of an evaluation over zero rows."""
+
+    def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: dict) -> None:
+        return None
+
+
+class FusedTape:
+    """One fused training-mode MLP launch (activation tape in HBM) and its hand-written adjoint
+    (csrc/mlp_fwd.hip TRAIN variants, csrc/mlp_bwd.hip)."""
+
+    def __init__(self, model: 'NeRF', xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
+                 sigma_noise, n_units_dev, rows_per_unit):
+        self.model, self.n_rows, self.out = model, n_rows, out
+        self.idx, self.idx_stride, self.rows_per_ray = idx, idx_stride, rows_per_ray
+        self.n_units_dev, self.rows_per_unit = n_units_dev, rows_per_unit
+        self.tape = torch.empty(max(n_rows, 1) * model.tape_floats_per_row(), device=out.device, dtype=torch.float32)
+        io = model.mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out, sigma_noise,
+                          n_units_dev, rows_per_unit)
+        model.evaluate_train(io, self.tape, max(n_rows, 1), 0)
+
+    def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: dict) -> None:
+        m, dev = self.model, d_out.device
+        if self.n_rows == 0:
+            return
+        desc, packed = m.packed()
+        packed_bwd = m.packed_bwd()
+        gtape = torch.empty(self.tape.numel(), device=dev, dtype=torch.float32)
+        dheads = torch.empty(self.n_rows, 4, device=dev, dtype=torch.float32)
+        counter = torch.zeros(1, device=dev, dtype=torch.int32)
+        g = N.MlpGradIO()
+        g.tape, g.gtape, g.tape_rows, g.tape_row0 = self.tape.data_ptr(), gtape.data_ptr(), self.n_rows, 0
+        g.d_out, g.d_out_stride = d_out.data_ptr(), d_out_stride
+        g.out, g.out_stride = self.out.data_ptr(), self.out.stride(0)
+        g.dheads = dheads.data_ptr()
+        if self.idx is not None:
+            g.idx, g.idx_stride = self.idx.data_ptr(), self.idx_stride
+            g.idx_is_float = 1 if self.idx.dtype == torch.float32 else 0
+        g.rows_per_ray = self.rows_per_ray
+        g.n_rows = self.n_rows
+        g.n_units_dev = self.n_units_dev.data_ptr() if self.n_units_dev is not None else None
+        g.rows_per_unit = self.rows_per_unit
+        g.work_counter = counter.data_ptr()
+        g.grad = m.grad_struct(grads)
+        N.check(N.lib().mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(g), N.stream_ptr()))
+        N.check(N.lib().mnr_mlp_backward_weights(C.byref(desc), C.byref(g), N.stream_ptr()))
 
 
 class NeRF(nn.Module):
@@ -149,71 +205,50 @@ class NeRF(nn.Module):
         return self._fused_ok
 
     def _evaluate_layerwise(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
-                            sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit):
-        """nerf.py:115-160 as one exact-fp32 MFMA GEMM launch per layer (csrc/layerwise.hip); used for widths /
-        architectures without a fused kernel (e.g. configs/nerf: layer_dim 2048)."""
-        lib, st = N.lib(), N.stream_ptr
+                            sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit, dir_rows=None):
+        """nerf.py:115-160 as one exact-fp32 MFMA GEMM launch per layer (models/layerwise.py, csrc/layerwise.hip); used
+        for widths / architectures without a fused kernel (e.g. configs/nerf: layer_dim 2048)."""
+        from mega_nerf.models.layerwise import LayerwiseTape
         if n_units_dev is not None:
             n_rows = min(n_rows, int(n_units_dev.item()) * rows_per_unit)      # the fallback sizes launches on the host
         if n_rows == 0:
             return out
-        dev = out.device
-        W, D = self.layer_dim, self.xyz_dim
-        E = D * (1 + 2 * self.pos_xyz_dim)
-        ED = 3 * (1 + 2 * self.pos_dir_dim) if self.has_dir else 0
-        A = self.appearance_dim if (self.embedding_a is not None and self.affine is None) else 0
         ostride = out.stride(0) if out.dim() > 1 else 1
-        act_sigma = 3 if isinstance(self.sigma_activation, ShiftedSoftplus) else 1
         chunk = max(rows_per_ray, (32768 // rows_per_ray) * rows_per_ray)
-        f4 = 4
-
-        def lin(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer, rows, act, row_add=None):
-            N.check(lib.mnr_linear(Y, ldy, X1, ld1, K1, X2, ld2, K2, layer.weight.data_ptr(), layer.weight.shape[1],
-                                   layer.bias.data_ptr(), row_add, rows, layer.weight.shape[0], act, st()))
-
+        dir_rows = rows_per_ray if dir_rows is None else dir_rows
+        sh = apply_sh_deg >= 0 and self.rgb_dim > 3 and not sigma_only
+        mlp_dirs = dirs if self.has_dir else None
         for r0 in range(0, n_rows, chunk):
             B = min(chunk, n_rows - r0)
             ray0 = r0 // rows_per_ray
-            emb = torch.empty(B, E, device=dev)
-            N.check(lib.mnr_embed(emb.data_ptr(), E, xyz.data_ptr() + r0 * xyz_stride * f4, xyz_stride, D, self.pos_xyz_dim, 1,
-                                  B, st()))
-            h, ha = torch.empty(B, W, device=dev), torch.empty(B, W, device=dev)
-            cur, K = emb, E
-            for i, enc in enumerate(self.xyz_encodings):
-                if i in self.skip_layers:
-                    lin(ha.data_ptr(), W, emb.data_ptr(), E, E, cur.data_ptr(), K, K, enc[0], B, 1)
-                else:
-                    lin(ha.data_ptr(), W, cur.data_ptr(), K, K, None, 0, 0, enc[0], B, 1)
-                h, ha = ha, h
-                cur, K = h, W
-            o_ptr = out.data_ptr() + r0 * ostride * f4
-            noise_ptr = sigma_noise.data_ptr() + r0 * f4 if sigma_noise is not None else None
-            sig_col = 0 if sigma_only else self.rgb_dim
-            lin(o_ptr + sig_col * f4, ostride, h.data_ptr(), W, W, None, 0, 0, self.sigma, B, act_sigma, noise_ptr)
-            if sigma_only:
-                continue
-            rgb_act = 2 if self.rgb_dim == 3 else 0
-            if self.has_final:
-                f = torch.empty(B, W, device=dev)
-                lin(f.data_ptr(), W, h.data_ptr(), W, W, None, 0, 0, self.xyz_encoding_final, B, 0)
-                side = torch.empty(B, max(ED + A, 1), device=dev)
-                if ED:
-                    N.check(lib.mnr_embed(side.data_ptr(), ED + A, dirs.data_ptr() + ray0 * dir_stride * f4, dir_stride, 3,
-                                          self.pos_dir_dim, rows_per_ray, B, st()))
-                if A:
-                    isz = idx.element_size()
-                    N.check(lib.mnr_gather_rows(side.data_ptr() + ED * f4, ED + A, self.embedding_a.weight.data_ptr(), A,
-                                                self.appearance_count, idx.data_ptr() + ray0 * idx_stride * isz, idx_stride,
-                                                1 if idx.dtype == torch.float32 else 0, rows_per_ray, B, st()))
-                dact = torch.empty(B, W // 2, device=dev)
-                lin(dact.data_ptr(), W // 2, f.data_ptr(), W, W, side.data_ptr() if ED + A else None, ED + A, ED + A,
-                    self.dir_a_encoding[0], B, 1)
-                lin(o_ptr, ostride, dact.data_ptr(), W // 2, W // 2, None, 0, 0, self.rgb, B, rgb_act)
-            else:
-                lin(o_ptr, ostride, h.data_ptr(), W, W, None, 0, 0, self.rgb, B, rgb_act)
-        if not sigma_only and self.rgb_dim > 3 and apply_sh_deg >= 0:
-            raise NotImplementedError('SH colour epilogue is only available in the fused kernel')
+            LayerwiseTape(self, _off(xyz, r0 * xyz_stride), xyz_stride,
+                          _off(mlp_dirs, (r0 // dir_rows) * dir_stride), dir_stride, dir_rows,
+                          _off(idx, ray0 * idx_stride), idx_stride, rows_per_ray, B, _off(out, r0 * ostride), ostride,
+                          _off(sigma_noise, r0), sigma_only, apply_sh_deg, False,
+                          _off(dirs, ray0 * dir_stride) if sh else None, dir_stride)
         return out
+
+    def fused_train_supported(self) -> bool:
+        """True if the fused training kernels (activation tape + hand-written backward) cover this architecture."""
+        if getattr(self, '_fused_train_ok', None) is None:
+            d = self.model_desc()
+            self._fused_train_ok = bool(N.lib().mnr_fused_train_supported(C.byref(d)))
+        return self._fused_train_ok
+
+    def train_eval(self, xyz, xyz_stride, dirs, dir_stride, dir_rows, idx, idx_stride, rows_per_ray, n_rows, out,
+                   sigma_noise, sh_deg, n_units_dev, rows_per_unit, sh_dirs=None, sh_dir_stride=0):
+        """Training-mode evaluation of ``n_rows`` rows into ``out`` [n_rows, 4]; returns a tape object whose
+        ``backward(d_out, grads)`` accumulates the parameter gradients (``grads``: zero-initialised tensors keyed by
+        this module's parameter names).  Fused kernels when they cover the architecture, else layer by layer."""
+        if self.fused_train_supported() and sh_deg < 0 and dir_rows == rows_per_ray:
+            return FusedTape(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out, sigma_noise,
+                             n_units_dev, rows_per_unit)
+        from mega_nerf.models.layerwise import LayerwiseTape
+        B = n_rows if n_units_dev is None else min(n_rows, int(n_units_dev.item()) * rows_per_unit)
+        if B == 0:
+            return NullTape()
+        return LayerwiseTape(self, xyz, xyz_stride, dirs if self.has_dir else None, dir_stride, dir_rows, idx, idx_stride,
+                             rows_per_ray, B, out, out.stride(0), sigma_noise, False, sh_deg, True, sh_dirs, sh_dir_stride)
 
     def launch(self, io: 'N.MlpIO') -> None:
         """Enqueue one inference launch described by a caller-built ``mnr_mlp_io``."""

@@ -13,6 +13,7 @@ injected (``_randoms``) so that train-mode parity is testable.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from argparse import Namespace
 from typing import Dict, Optional, Tuple
 
@@ -29,7 +30,7 @@ _ERR_TEXT = ('Not all your cameras are bounded by the unit sphere; please make s
 KERNEL_EVENTS = None
 
 _tables: Dict[Tuple[int, str], torch.Tensor] = {}
-_host_cache: Dict[Tuple[int, int], list] = {}
+_host_cache: Dict[int, tuple] = {}          # id(tensor) -> (weakref to it, version, host list)
 
 
 def linspace01(n: int, device: torch.device) -> torch.Tensor:
@@ -44,18 +45,20 @@ def linspace01(n: int, device: torch.device) -> torch.Tensor:
 
 
 def _host_vec(v) -> Optional[list]:
-    """Host copy of a small device tensor (sphere centre/radius), cached so steady-state calls do not sync."""
+    """Host copy of a small device tensor (sphere centre/radius).  Cached per tensor *object* (weakly) and version, so a
+    trainer that keeps its sphere tensors alive never synchronises in steady state; a fresh tensor costs one copy."""
     if v is None:
         return None
     if not isinstance(v, torch.Tensor):
         return [float(x) for x in v]
-    key = (v.data_ptr(), v._version)
-    h = _host_cache.get(key)
-    if h is None:
-        if len(_host_cache) > 64:
-            _host_cache.clear()
-        h = v.detach().float().cpu().tolist()
-        _host_cache[key] = h
+    hit = _host_cache.get(id(v))
+    if hit is not None and hit[0]() is v and hit[1] == v._version:
+        return hit[2]
+    if len(_host_cache) > 64:
+        for k in [k for k, e in _host_cache.items() if e[0]() is None]:
+            del _host_cache[k]
+    h = v.detach().float().cpu().tolist()
+    _host_cache[id(v)] = (weakref.ref(v), v._version, h)
     return h
 
 

@@ -6,9 +6,16 @@ MLP -- has explicit HIP backward kernels; :class:`RenderFunction` exposes them t
 inputs are the model parameters and whose output is ``rgb_fine``, so ``loss.backward()`` / ``optimizer.step()``
 in a reference-style training loop work unchanged.  :class:`TrainStep` is that loop body for the benchmark.
 
-Scope (round 1): the default architecture without cascade / container (single NeRF per branch, 8x256,
-fine_samples > 0).  Importance-sampling weights are detached exactly as in the reference (rendering.py:215),
-so gradients reach the MLP only through the compositing of ``rgb_fine``.
+Two implementations share the stage kernels:
+  * :class:`RenderFunction` -- the tuned path for the default configuration (single 8x256 NeRF per branch, no
+    cascade, fine_samples > 0): one activation tape per branch, coarse + fine rows in one weight-gradient launch;
+  * :class:`GeneralRenderFunction` -- every other configuration of the reference (``use_cascade``, any
+    ``layer_dim``, ``appearance_dim 0``, spherical harmonics): one tape per MLP evaluation
+    (``NeRF.train_eval``: fused kernels where they exist, else the layer-by-layer GEMM path), outputs
+    ``rgb_fine`` and, with cascade, ``rgb_coarse``.
+Importance-sampling weights are detached exactly as in the reference (rendering.py:215), so gradients reach the
+MLP only through the compositing of ``rgb_*``.  Joint training of a routed MegaNeRF (``--train_mega_nerf``) is not
+covered (the per-submodule pipeline trains single models).
 """
 from __future__ import annotations
 
@@ -295,24 +302,297 @@ class RenderFunction(torch.autograd.Function):
         return (None,) * 9 + tuple(out)
 
 
+# =====================================================================================================================
+# general path: cascade / generic widths / no appearance / spherical harmonics
+# =====================================================================================================================
+
+def _train_model_eval(nerf, typ: str, hparams: Namespace, xyz: torch.Tensor, part, S: int, noise):
+    """Training twin of rendering._model_eval_inner: (raw [n, S, 4], tape, parameter-name prefix of the sub-model)."""
+    from mega_nerf.models.cascade import Cascade
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    model, prefix = nerf, ''
+    if isinstance(model, Cascade):
+        model, prefix = (model.coarse, 'coarse.') if typ == 'coarse' else (model.fine, 'fine.')
+    if isinstance(model, MegaNeRF):
+        raise NotImplementedError('joint training of a routed MegaNeRF (--train_mega_nerf / container) is not covered by the '
+                                  'MI355X training path; train the submodules separately')
+    n = xyz.shape[0]
+    out = _f(n, S, 4, device=xyz.device)
+    sh_deg = hparams.sh_deg if (hparams.pos_dir_dim == 0 and hparams.sh_deg is not None) else -1
+    if model.has_dir and model.embedding_a is None:
+        # quirk Q8 (nerf.py:146): the encoded "direction" is [last xyz coordinate, d_x, d_y] of every sample
+        d = part.dirs.view(n, 1, 3).expand(n, S, 3)
+        q = torch.cat([xyz[..., -1:], d[..., :2]], -1).contiguous()
+        tape = model.train_eval(xyz, xyz.shape[-1], q, 3, 1, None, 0, 1, n * S, out.view(-1, 4), noise, sh_deg, part.n_units, S)
+        tape.keepalive = q
+        return out, tape, prefix
+    need_dir = model.has_dir or sh_deg >= 0
+    dirs = part.dirs if need_dir else None
+    dstride = part.dirs.stride(0) if need_dir else 0
+    tape = model.train_eval(xyz, xyz.shape[-1], dirs, dstride, S, part.idx, 1, S, n * S, out.view(-1, 4), noise, sh_deg,
+                            part.n_units, S, dirs if sh_deg >= 0 else None, dstride)
+    return out, tape, prefix
+
+
+def _general_branch_forward(nerf, hparams: Namespace, part, flip: bool, get_bg_lambda: bool, get_depth_variance: bool,
+                            rnd: dict, tag: str) -> _Branch:
+    """rendering._get_results (reference rendering.py:176-248) in training mode, recording what the adjoint needs.
+    ``b.results`` holds rgb_/bg_lambda_/depth_variance_ per pass; ``b.stages[typ]`` the composite inputs + tapes."""
+    lib = N.lib()
+    b = _Branch()
+    dev = part.z.device
+    n, Sc = part.z.shape
+    Nf, cascade = hparams.fine_samples, hparams.use_cascade
+    b.n, b.flip, b.part, b.results, b.stages = n, flip, part, {}, {}
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    if Nf == 0 and not cascade:
+        raise NotImplementedError('fine_samples == 0 without --use_cascade produces no rgb to train on (rendering.py:204)')
+
+    xyz_c, z_c = part.xyz, part.z
+    if flip:
+        xyz_c, z_c = xyz_c.flip(1).contiguous(), z_c.flip(1).contiguous()
+    noise_c = rnd.get(tag + '_noise_coarse') if nerf.training else None
+    if nerf.training and noise_c is None:
+        noise_c = torch.rand(n * Sc, device=dev)
+    raw_c, tape_c, prefix_c = _train_model_eval(nerf, 'coarse', hparams, xyz_c, part, Sc, noise_c)
+    want = set()
+    if Nf > 0:
+        want.add('weights')
+    if cascade:
+        want.add('rgb')
+        if get_bg_lambda:
+            want.add('bg_lambda')
+    if Nf == 0 and get_depth_variance:
+        want.update(('depth', 'depth_var'))
+    comp = R._composite(z_c, raw_c, n, Sc, part, part.last_delta, part.z, flip, part.depth_real, want, dev)
+    if cascade:
+        b.results['rgb_coarse'] = comp['rgb']
+        if get_bg_lambda:
+            b.results['bg_lambda_coarse'] = comp['bg_lambda']
+        b.stages['coarse'] = dict(z=z_c, raw=raw_c, S=Sc, zmax_src=part.z, merged=False, tapes=[(tape_c, prefix_c)])
+    if Nf == 0:
+        if get_depth_variance:
+            b.results['depth_variance_coarse'] = comp['depth_var']
+        return b
+
+    nf = Nf // 2 if flip else Nf
+    det = (hparams.perturb if nerf.training else 0) == 0
+    if det:
+        u = R.linspace01(nf, dev)
+    else:
+        u = rnd.get(tag + '_u')
+        if u is None:
+            u = torch.rand(n, nf, device=dev)
+    z_f = _f(n, nf, device=dev)
+    N.check(lib.mnr_sample_fine(part.z.data_ptr(), comp['weights'].data_ptr(), n, nunits, Sc, nf, int(det), u.data_ptr(),
+                                z_f.data_ptr(), None, N.stream_ptr()))
+    zmax_src = z_f
+    if cascade:
+        z_all = _f(n, Sc + nf, device=dev)
+        N.check(lib.mnr_sort_rows(part.z.data_ptr(), Sc, z_f.data_ptr(), nf, n, nunits, z_all.data_ptr(), N.stream_ptr()))
+        z_f, nf = z_all, Sc + nf
+        zmax_src = z_f
+    xyz_f, dr_f = part.points(z_f)
+    if flip and cascade:
+        xyz_f, z_f = xyz_f.flip(1).contiguous(), z_f.flip(1).contiguous()
+    noise_f = rnd.get(tag + '_noise_fine') if nerf.training else None
+    if nerf.training and noise_f is None:
+        noise_f = torch.rand(n * nf, device=dev)
+    raw_f, tape_f, prefix_f = _timed(tag + '_fine', lambda: _train_model_eval(nerf, 'fine', hparams, xyz_f, part, nf, noise_f))
+    if cascade:
+        z_m, raw_m, dr_m, Sm = z_f, raw_f, dr_f, nf
+        stage = dict(z=z_m, raw=raw_m, S=Sm, zmax_src=zmax_src, merged=False, tapes=[(tape_f, prefix_f)])
+    else:
+        Sm = nf + Sc
+        z_m, raw_m = _f(n, Sm, device=dev), _f(n, Sm, 4, device=dev)
+        dr_m = _f(n, Sm, device=dev) if dr_f is not None else None
+        order = torch.empty(n, Sm, device=dev, dtype=torch.int32)
+        N.check(lib.mnr_merge_sorted(z_f.data_ptr(), raw_f.data_ptr(), N.ptr(dr_f), nf, z_c.data_ptr(), raw_c.data_ptr(),
+                                     N.ptr(part.depth_real), Sc, n, nunits, int(flip), z_m.data_ptr(), raw_m.data_ptr(),
+                                     N.ptr(dr_m), order.data_ptr(), N.stream_ptr()))
+        stage = dict(z=z_m, raw=raw_m, S=Sm, zmax_src=zmax_src, merged=True, order=order, Sf=nf, Sc=Sc,
+                     tapes=[(tape_f, prefix_f), (tape_c, prefix_c)])
+    want = {'rgb'}
+    if get_bg_lambda:
+        want.add('bg_lambda')
+    if get_depth_variance:
+        want.update(('depth', 'depth_var'))
+    comp = R._composite(z_m, raw_m, n, Sm, part, part.last_delta, zmax_src, flip, dr_m, want, dev)
+    b.results['rgb_fine'] = comp['rgb']
+    if get_bg_lambda:
+        b.results['bg_lambda_fine'] = comp['bg_lambda']
+    if get_depth_variance:
+        b.results['depth_variance_fine'] = comp['depth_var']
+    b.stages['fine'] = stage
+    return b
+
+
+def _sub_grads(grads: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    return grads if not prefix else {k[len(prefix):]: v for k, v in grads.items() if k.startswith(prefix)}
+
+
+def _general_branch_backward(b: _Branch, typ: str, d_rgb: torch.Tensor, d_lambda: Optional[torch.Tensor],
+                             grads: Dict[str, torch.Tensor]) -> None:
+    """Adjoint of one pass ('coarse' / 'fine') of a branch: d rgb_typ (+ d bg_lambda_typ) -> parameter gradients."""
+    lib = N.lib()
+    st, part = b.stages[typ], b.part
+    dev = d_rgb.device
+    n, S = b.n, st['S']
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    d_raw = _f(n, S, 4, device=dev)
+    io = N.CompositeGradIO()
+    io.z, io.raw = st['z'].data_ptr(), st['raw'].data_ptr()
+    io.last_delta = part.last_delta.data_ptr() if part.last_delta is not None else None
+    if part.last_delta is not None:
+        io.zmax_src, io.zmax_S = st['zmax_src'].data_ptr(), st['zmax_src'].shape[1]
+    io.flip, io.N, io.S = int(b.flip), n, S
+    io.n_units_dev = nunits
+    io.d_rgb = d_rgb.data_ptr()
+    io.d_bg_lambda = d_lambda.data_ptr() if d_lambda is not None else None
+    io.d_raw = d_raw.data_ptr()
+    N.check(lib.mnr_composite_backward(C.byref(io), N.stream_ptr()))
+    if st['merged']:
+        Sf, Sc = st['Sf'], st['Sc']
+        d_f, d_c = _f(n * Sf, 4, device=dev), _f(n * Sc, 4, device=dev)
+        N.check(lib.mnr_merge_backward(d_raw.data_ptr(), st['order'].data_ptr(), Sf, Sc, n, nunits, d_f.data_ptr(), d_c.data_ptr(),
+                                       N.stream_ptr()))
+        pieces = [d_f, d_c]
+    else:
+        pieces = [d_raw.view(-1, 4)]
+    for (tape, prefix), d in zip(st['tapes'], pieces):
+        _timed('%s_bwd_%s' % (part.tag, typ), lambda: tape.backward(d, 4, _sub_grads(grads, prefix)))
+
+
+class GeneralRenderFunction(torch.autograd.Function):
+    """(rgb_fine?, rgb_coarse?) = render(params...) for every configuration outside the tuned default path."""
+
+    @staticmethod
+    def forward(ctx, nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, ctx_out, *params):
+        N.require_device(rays, 'rays')
+        lib = N.lib()
+        dev = rays.device
+        rays = rays.contiguous().float()
+        n_rays = rays.shape[0]
+        Nc = hparams.coarse_samples
+        if image_indices is not None:
+            if image_indices.dtype not in (torch.float32, torch.int32):
+                image_indices = image_indices.float()
+            image_indices = image_indices.contiguous()
+        perturb = float(hparams.perturb) if nerf.training else 0.0
+        far = last_delta = bg_slot = n_bg = err = None
+        bgb = None
+        get_var = ctx_out.pop('_get_depth_variance', True)
+        if bg_nerf is not None:
+            c, r = R._host_vec(sphere_center), R._host_vec(sphere_radius)
+            far, last_delta = _f(n_rays, device=dev), _f(n_rays, device=dev)
+            bg_list = torch.zeros(max(n_rays, 1), device=dev, dtype=torch.int32)
+            bg_slot = torch.empty(max(n_rays, 1), device=dev, dtype=torch.int32)
+            scal = torch.zeros(2, device=dev, dtype=torch.int32)
+            n_bg, err = scal[0:1], scal[1:2]
+            N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
+                                      last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
+                                      err.data_ptr(), N.stream_ptr()))
+            bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd, dev)
+            bgb = _general_branch_forward(bg_nerf, hparams, bg_part, True, False, False, rnd, 'bg')
+        t_c = R.linspace01(Nc, dev)
+        prnd = None
+        if perturb > 0:
+            prnd = rnd.get('fg_perturb')
+            if prnd is None:
+                prnd = torch.rand(n_rays, Nc, device=dev)
+        z, xyz = _f(n_rays, Nc, device=dev), _f(n_rays, Nc, 3, device=dev)
+        N.check(lib.mnr_fg_samples(rays.data_ptr(), N.ptr(far), n_rays, Nc, t_c.data_ptr(), perturb, N.ptr(prnd),
+                                   z.data_ptr(), xyz.data_ptr(), N.stream_ptr()))
+
+        def fg_points(zf):
+            p = _f(n_rays, zf.shape[1], 3, device=dev)
+            N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), N.stream_ptr()))
+            return p, None
+
+        fg_part = R._Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=rays[:, 3:6],
+                          idx=image_indices, points=fg_points, rays=rays, tag='fg')
+        fgb = _general_branch_forward(nerf, hparams, fg_part, False, bg_nerf is not None, get_var, rnd, 'fg')
+        types = [t for t in ('fine', 'coarse') if 'rgb_' + t in fgb.results]
+        if bgb is not None:
+            for typ in types:
+                # blend in place (rendering.py:102-131); the composite adjoint recomputes what it needs from raw
+                N.check(lib.mnr_bg_blend(fgb.results['rgb_' + typ].data_ptr(), None, fgb.results['bg_lambda_' + typ].data_ptr(),
+                                         bg_slot.data_ptr(), bgb.results['rgb_' + typ].data_ptr(), None, n_rays, None, None, None,
+                                         None, N.stream_ptr()))
+        ctx.fgb, ctx.bgb, ctx.bg_slot, ctx.n_rays, ctx.types = fgb, bgb, bg_slot, n_rays, types
+        ctx.names_fg = [k for k, _ in _param_list(nerf)]
+        ctx.names_bg = [k for k, _ in _param_list(bg_nerf)]
+        ctx.params = params
+        for k, v in fgb.results.items():
+            if not k.startswith('rgb_'):
+                ctx_out[k] = v
+        ctx_out['n_bg'], ctx_out['err'], ctx_out['types'] = n_bg, err, types
+        return tuple(fgb.results['rgb_' + t] for t in types)
+
+    @staticmethod
+    def backward(ctx, *d_rgbs):
+        lib = N.lib()
+        fgb, bgb = ctx.fgb, ctx.bgb
+        n_fg, n_bgp = len(ctx.names_fg), len(ctx.names_bg)
+        grads_fg = _zero_grads(ctx.names_fg, ctx.params[:n_fg])
+        grads_bg = _zero_grads(ctx.names_bg, ctx.params[n_fg:n_fg + n_bgp])
+        for typ, d_rgb in zip(ctx.types, d_rgbs):
+            if d_rgb is None:
+                continue
+            d_rgb = d_rgb.contiguous().float()
+            dev = d_rgb.device
+            d_lambda = None
+            if bgb is not None:
+                d_lambda = _f(ctx.n_rays, device=dev)
+                d_bg_rgb = torch.zeros(bgb.n, 3, device=dev)
+                N.check(lib.mnr_bg_blend_backward(d_rgb.data_ptr(), fgb.results['bg_lambda_' + typ].data_ptr(), ctx.bg_slot.data_ptr(),
+                                                  bgb.results['rgb_' + typ].data_ptr(), ctx.n_rays, d_lambda.data_ptr(),
+                                                  d_bg_rgb.data_ptr(), N.stream_ptr()))
+                _general_branch_backward(bgb, typ, d_bg_rgb, None, grads_bg)
+            _general_branch_backward(fgb, typ, d_rgb, d_lambda, grads_fg)
+        out = [grads_fg[k] for k in ctx.names_fg] + [grads_bg[k] for k in ctx.names_bg]
+        return (None,) * 9 + tuple(out)
+
+
+def _fast_path_ok(nerf, bg_nerf, hparams) -> bool:
+    from mega_nerf.models.nerf import NeRF
+    if hparams.use_cascade or hparams.fine_samples == 0 or (hparams.sh_deg is not None and hparams.pos_dir_dim == 0):
+        return False
+    for m in (nerf, bg_nerf):
+        if m is not None and not (isinstance(m, NeRF) and m.fused_train_supported()):
+            return False
+    return True
+
+
+FORCE_GENERAL = False       # tests: run the default configuration through GeneralRenderFunction as well
+
+
 def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
                       image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
                       get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
     """Differentiable render (training flags of runner.py:349-358).  Returns (results, n_bg_dev, err_dev)."""
-    if hparams.use_cascade or hparams.fine_samples == 0 or hparams.container_path is not None or \
-            getattr(hparams, 'train_mega_nerf', None) is not None:
-        raise NotImplementedError('the MI355X training path covers the single-NeRF, non-cascade configuration')
+    if hparams.container_path is not None or getattr(hparams, 'train_mega_nerf', None) is not None:
+        raise NotImplementedError('the MI355X training path trains single (optionally cascaded) NeRFs per branch; '
+                                  'routed MegaNeRF containers are inference-only')
     if get_depth or get_bg_fg_rgb:
-        raise NotImplementedError('training render returns rgb_fine / depth_variance_fine / bg_lambda_fine only')
+        raise NotImplementedError('training render returns rgb / depth_variance / bg_lambda only')
     rnd = _randoms if _randoms is not None else {}
     params = [p for _, p in _param_list(nerf)] + [p for _, p in _param_list(bg_nerf)]
     aux: Dict[str, torch.Tensor] = {}
-    rgb = RenderFunction.apply(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, aux, *params)
-    results = {'rgb_fine': rgb}
-    if get_depth_variance:
-        results['depth_variance_fine'] = aux['depth_variance_fine']
-    if bg_nerf is not None:
-        results['bg_lambda_fine'] = aux['bg_lambda_fine']
+    if _fast_path_ok(nerf, bg_nerf, hparams) and not FORCE_GENERAL:
+        rgb = RenderFunction.apply(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, aux, *params)
+        results = {'rgb_fine': rgb}
+        if get_depth_variance:
+            results['depth_variance_fine'] = aux['depth_variance_fine']
+        if bg_nerf is not None:
+            results['bg_lambda_fine'] = aux['bg_lambda_fine']
+        return results, aux.get('n_bg'), aux.get('err')
+    aux['_get_depth_variance'] = get_depth_variance
+    rgbs = GeneralRenderFunction.apply(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, rnd, aux, *params)
+    results = {'rgb_' + t: v for t, v in zip(aux['types'], rgbs)}
+    for k, v in aux.items():
+        if k.startswith(('depth_variance_', 'bg_lambda_')):
+            results[k] = v
     return results, aux.get('n_bg'), aux.get('err')
 
 

@@ -310,35 +310,45 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
     save(name, **out)
 
 
-def main():
+def main(only=None):
     torch.set_num_threads(8)
     all_rays = scene_rays()
-    gen_rays()
-    gen_stages(all_rays)
-    gen_mlp()
+    if only is None:
+        gen_rays()
+        gen_stages(all_rays)
+        gen_mlp()
     base = dict(coarse_samples=64, fine_samples=128)
     E = (True, False, True)      # eval flags (runner.py:569-578)
     TR = (False, True, False)    # train flags (runner.py:349-358)
-    run_render('render_fgbg_eval', base, 96, 1, E, all_rays=all_rays)
-    run_render('render_fgbg_train', base, 64, 2, TR, fg_train=True, bg_train=True, all_rays=all_rays, with_grad=True)
-    run_render('render_fgonly_eval', base, 48, 3, E, bg=False, all_rays=all_rays)
-    run_render('render_sh2_eval', dict(base, sh_deg=2, pos_dir_dim=0), 48, 4, E, all_rays=all_rays)
-    run_render('render_cascade_eval', dict(base, use_cascade=True, appearance_dim=0), 32, 5, E, bg=False,
-               cascade=True, all_rays=all_rays, layer_dim=64)
-    run_render('render_cascade_bg_train', dict(base, use_cascade=True), 32, 6, TR, cascade=True, fg_train=True,
-               bg_train=True, all_rays=all_rays, layer_dim=64, bg_layer_dim=64, with_grad=True)
-    run_render('render_q13_eval', base, 48, 7, E, bg_train=True, all_rays=all_rays)
-    run_render('render_container_eval', dict(base, container_path='dummy'), 48, 8, E, container=4, all_rays=all_rays)
-    run_render('render_default_samples_eval', dict(), 8, 9, E, all_rays=all_rays)
-    run_render('render_w512_eval', base, 32, 10, E, all_rays=all_rays, layer_dim=512, bg_layer_dim=512)
+
+    def case(name, *a, **kw):
+        if only is None or name in only:
+            run_render(name, *a, all_rays=all_rays, **kw)
+
+    case('render_fgbg_eval', base, 96, 1, E)
+    case('render_fgbg_train', base, 64, 2, TR, fg_train=True, bg_train=True, with_grad=True)
+    case('render_fgonly_eval', base, 48, 3, E, bg=False)
+    case('render_sh2_eval', dict(base, sh_deg=2, pos_dir_dim=0), 48, 4, E)
+    case('render_cascade_eval', dict(base, use_cascade=True, appearance_dim=0), 32, 5, E, bg=False, cascade=True, layer_dim=64)
+    case('render_cascade_bg_train', dict(base, use_cascade=True), 32, 6, TR, cascade=True, fg_train=True, bg_train=True,
+         layer_dim=64, bg_layer_dim=64, with_grad=True)
+    case('render_q13_eval', base, 48, 7, E, bg_train=True)
+    case('render_container_eval', dict(base, container_path='dummy'), 48, 8, E, container=4)
+    case('render_default_samples_eval', dict(), 8, 9, E)
+    case('render_w512_eval', base, 32, 10, E, layer_dim=512, bg_layer_dim=512)
     # NB: fine_samples=0 with a bg model and no cascade raises KeyError('bg_lambda_coarse') in the reference
     # (rendering.py:109 vs :208), so the coarse-only case has no bg model.
-    run_render('render_coarse_only_eval', dict(coarse_samples=64, fine_samples=0), 32, 11, E, bg=False,
-               all_rays=all_rays)
-    run_render('render_relu_noapp_eval', dict(base, shifted_softplus=False, appearance_dim=0), 32, 12, E,
-               all_rays=all_rays)
+    case('render_coarse_only_eval', dict(coarse_samples=64, fine_samples=0), 32, 11, E, bg=False)
+    case('render_relu_noapp_eval', dict(base, shifted_softplus=False, appearance_dim=0), 32, 12, E)
+    # training of the remaining reference configurations (general / layer-by-layer training path)
+    case('render_sh2_train', dict(base, sh_deg=2, pos_dir_dim=0), 32, 13, TR, fg_train=True, bg_train=True, with_grad=True,
+         layer_dim=128, bg_layer_dim=128)
+    case('render_noapp_train', dict(base, appearance_dim=0, shifted_softplus=False), 32, 14, TR, fg_train=True, bg_train=True,
+         with_grad=True, layer_dim=128, bg_layer_dim=128)
+    case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
+         bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
 
 
 if __name__ == '__main__':
     os.environ.setdefault('OMP_NUM_THREADS', '8')
-    main()
+    main(set(sys.argv[1:]) or None)

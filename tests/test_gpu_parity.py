@@ -518,7 +518,7 @@ def test_train_step_reduces_loss():
     s = common.SCENE
     step = TrainStep(nerf, bg_nerf, Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']))
     rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
-    losses = [float(step(rays, idx, tgt)[0]) for _ in range(8)]
+    losses = [float(step(rays, idx, tgt)[0].detach()) for _ in range(8)]
     assert np.isfinite(losses).all()
     assert losses[-1] < losses[0]
 

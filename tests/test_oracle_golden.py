@@ -128,6 +128,11 @@ RENDER_CASES = {
     'render_w512_eval': dict(hp=dict(layer_dim=512, bg_layer_dim=512), seed=10),
     'render_coarse_only_eval': dict(hp=dict(fine_samples=0), seed=11, bg=False),
     'render_relu_noapp_eval': dict(hp=dict(shifted_softplus=False, appearance_dim=0), seed=12),
+    'render_sh2_train': dict(hp=dict(sh_deg=2, pos_dir_dim=0, layer_dim=128, bg_layer_dim=128), seed=13, fg_train=True, bg_train=True),
+    'render_noapp_train': dict(hp=dict(appearance_dim=0, shifted_softplus=False, layer_dim=128, bg_layer_dim=128), seed=14,
+                               fg_train=True, bg_train=True),
+    'render_nerf_cfg_train': dict(hp=dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0, layer_dim=160),
+                                  seed=15, bg=False, cascade=True, fg_train=True),
 }
 
 
