@@ -61,6 +61,13 @@ class MegaNeRF(nn.Module):
         sub_out = torch.empty(B, ncol, device=dev, dtype=torch.float32)
         blend = self.boundary_margin > 1
         for i, child in enumerate(self.sub_modules):
+            if not child.fused_supported():
+                self._child_gathered(child, lists[i], counts[i:i + 1], xyz, xyz_stride, dirs, dir_stride, idx, idx_stride,
+                                     rows_per_ray, B, sub_out, noise, sigma_only, sh_deg)
+                N.check(lib.mnr_route_accumulate(out.data_ptr(), ncol, sub_out.data_ptr(), ncol, ncol, lists[i].data_ptr(),
+                                                 counts[i:i + 1].data_ptr(), B, weights[i].data_ptr() if blend else None,
+                                                 0 if blend else 1, N.stream_ptr()))
+                continue
             io = child.mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, sub_out, noise,
                               counts[i:i + 1], 1)
             io.row_index = lists[i].data_ptr()
@@ -70,6 +77,26 @@ class MegaNeRF(nn.Module):
             N.check(lib.mnr_route_accumulate(out.data_ptr(), ncol, sub_out.data_ptr(), ncol, ncol, lists[i].data_ptr(),
                                              counts[i:i + 1].data_ptr(), B, weights[i].data_ptr() if blend else None,
                                              0 if blend else 1, N.stream_ptr()))
+
+    @staticmethod
+    def _child_gathered(child, rows_list, count, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, sub_out,
+                        noise, sigma_only, sh_deg) -> None:
+        """Cells without a fused kernel (generic widths): materialise the routed rows and run the layer-by-layer path.
+        Sizes its launches on the host (one device->host read of the row count per cell)."""
+        cnt = int(count.item())
+        if cnt == 0:
+            return
+        rows = rows_list[:cnt].long()
+        rays = rows // rows_per_ray
+        n_rays = (B + rows_per_ray - 1) // rows_per_ray
+        x2 = torch.as_strided(xyz, (B, child.xyz_dim), (xyz_stride, 1), xyz.storage_offset()).index_select(0, rows)
+        d2 = i2 = None
+        if dirs is not None:
+            d2 = torch.as_strided(dirs, (n_rays, 3), (dir_stride, 1), dirs.storage_offset()).index_select(0, rays)
+        if idx is not None:
+            i2 = torch.as_strided(idx, (n_rays,), (idx_stride,), idx.storage_offset()).index_select(0, rays)
+        n2 = noise.index_select(0, rows) if noise is not None else None
+        child.evaluate(x2, child.xyz_dim, d2, 3, i2, 1, 1, cnt, sub_out, n2, sigma_only, sh_deg)
 
     def evaluate_routed(self, xyz: torch.Tensor, part, S: int, out: torch.Tensor, noise, sh_deg: int):
         """Render-path entry: xyz [n, S, 3] (fg) or [n, S, 7] = [xyz_real | sphere point | 1/r] (bg, quirk Q15);

@@ -13,6 +13,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the merged-container format IS a TorchScript archive (reference merge_submodules.py:79); torch 2.10 deprecates the API
+    config.addinivalue_line('filterwarnings', 'ignore:.*torch.jit.*is deprecated.*:DeprecationWarning')
 
 
 def _has_gpu():
