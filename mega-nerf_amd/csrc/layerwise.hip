@@ -52,6 +52,8 @@ __global__ void k_gather_rows(float *__restrict__ out, long ldo, const float *__
 }
 
 constexpr int LW_BM = 128, LW_BN = 128, LW_KT = 32, LW_LD = LW_KT + 1;   // +1: conflict-free column reads
+constexpr int LW_TILE_F = LW_BM * LW_LD;                                 // floats per staged operand tile
+constexpr int LW_LDS_BYTES = 2 * 2 * LW_TILE_F * (int)sizeof(float);     // two buffers x (A, B)
 
 __device__ __forceinline__ float lw_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -60,37 +62,122 @@ __device__ __forceinline__ float lw_act(float v, int act) {
     return v;
 }
 
-// Y[b][n] = act( sum_k Xcat[b][k] * W[n][k] + bias[n] + row_add[b] ),  Xcat = [X1 (K1 cols) | X2 (K2 cols)]
-__global__ __launch_bounds__(256) void k_linear(float *__restrict__ Y, long ldy, const float *__restrict__ X1, long ldx1, int K1,
-                                                const float *__restrict__ X2, long ldx2, int K2, const float *__restrict__ W,
-                                                long ldw, const float *__restrict__ bias, const float *__restrict__ row_add,
-                                                long B, int N, int act) {
-    __shared__ float As[LW_BM * LW_LD], Bs[LW_BN * LW_LD];
+// One GEMM operand: element (r, k) at p[r * sr + k * sk] for r < rows, k < klim (zero outside).  Exactly one of sr / sk
+// is 1 in every use (row-major activations / weights or their transposes); `vec` = 16-byte loads along that unit stride
+// are legal (pointer, the other stride and both extents are multiples of 4).
+struct LwOperand {
+    const float *p;
+    long sr, sk, rows, klim;
+};
+
+// 128 x 32 tile -> 16 registers per thread.  Thread -> element maps keep global loads coalesced along the unit stride.
+template <bool KFAST, bool VEC>
+__device__ __forceinline__ void lw_fetch(float (&v)[16], const LwOperand &o, long r0, long k0) {
+    const int t = threadIdx.x;
+    if (KFAST) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = t + i * 256, r = e >> 3, kq = (e & 7) * 4;
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r0 + r < o.rows && k0 + kq < o.klim) x = *reinterpret_cast<const float4 *>(o.p + (r0 + r) * o.sr + (k0 + kq));
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = t + i * 256, r = e >> 5, kq = e & 31;
+                v[i] = (r0 + r < o.rows && k0 + kq < o.klim) ? o.p[(r0 + r) * o.sr + (k0 + kq)] : 0.f;
+            }
+        }
+    } else {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = t + i * 256, kq = e >> 5, r = (e & 31) * 4;
+                float4 x = {0.f, 0.f, 0.f, 0.f};
+                if (r0 + r < o.rows && k0 + kq < o.klim) x = *reinterpret_cast<const float4 *>(o.p + (r0 + r) + (k0 + kq) * o.sk);
+                v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = t + i * 256, r = e & 127, kq = e >> 7;
+                v[i] = (r0 + r < o.rows && k0 + kq < o.klim) ? o.p[(r0 + r) + (k0 + kq) * o.sk] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool KFAST, bool VEC>
+__device__ __forceinline__ void lw_commit(float *S, const float (&v)[16]) {
+    const int t = threadIdx.x;
+    if (KFAST) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = t + i * 256, r = e >> 3, kq = (e & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[r * LW_LD + kq + j] = v[4 * i + j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = t + i * 256;
+                S[(e >> 5) * LW_LD + (e & 31)] = v[i];
+            }
+        }
+    } else {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = t + i * 256, kq = e >> 5, r = (e & 31) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[(r + j) * LW_LD + kq] = v[4 * i + j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = t + i * 256;
+                S[(e & 127) * LW_LD + (e >> 7)] = v[i];
+            }
+        }
+    }
+}
+
+// acc (2 x 2 blocks of 32 x 32 per wave) += sum over up to two K phases of A_ph(m, k) B_ph(n, k); the K range of a
+// phase is [kb, ke).  Software pipeline: the next tile's global loads are in flight while the MFMAs of the current one
+// run from LDS (two LDS buffers, one barrier per tile).
+template <bool AK, bool BK, bool VEC>
+__device__ __forceinline__ void lw_mainloop(floatx16 (&acc)[2][2], float *lds, const LwOperand (&A)[2], const LwOperand (&B)[2],
+                                            const long (&kb)[2], const long (&ke)[2], int n_phases, long m0, long n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i32 = lane & 31, kk = lane >> 5;
-    const long m0 = (long)blockIdx.y * LW_BM;
-    const int n0 = blockIdx.x * LW_BN;
-    const int K = K1 + K2;
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = floatx16(0.f);
-
-    for (int k0 = 0; k0 < K; k0 += LW_KT) {
-        __syncthreads();
-        // stage the two operand tiles (zero fill outside the matrix): 128 x 32 floats each, 16 per thread
-        for (int e = threadIdx.x; e < LW_BM * LW_KT; e += 256) {
-            const int r = e / LW_KT, k = k0 + e % LW_KT;
-            const long row = m0 + r;
-            float v = 0.f;
-            if (row < B && k < K) v = k < K1 ? X1[row * ldx1 + k] : X2[row * ldx2 + (k - K1)];
-            As[r * LW_LD + e % LW_KT] = v;
-            const int n = n0 + r;
-            Bs[r * LW_LD + e % LW_KT] = (n < N && k < K) ? W[(long)n * ldw + k] : 0.f;
-        }
-        __syncthreads();
+    long tiles[2] = {0, 0};
+    for (int p = 0; p < n_phases; ++p) tiles[p] = (ke[p] - kb[p] + LW_KT - 1) / LW_KT;
+    const long total = tiles[0] + tiles[1];
+    if (total == 0) return;
+    float ra[16], rb[16];
+    auto fetch = [&](long t) {
+        const int p = t < tiles[0] ? 0 : 1;
+        const long k0 = kb[p] + (t - (p ? tiles[0] : 0)) * LW_KT;
+        LwOperand a = A[p], b = B[p];
+        a.klim = min(a.klim, ke[p]); b.klim = min(b.klim, ke[p]);
+        lw_fetch<AK, VEC>(ra, a, m0, k0);
+        lw_fetch<BK, VEC>(rb, b, n0, k0);
+    };
+    auto commit = [&](long, int buf) {
+        lw_commit<AK, VEC>(lds + buf * 2 * LW_TILE_F, ra);
+        lw_commit<BK, VEC>(lds + buf * 2 * LW_TILE_F + LW_TILE_F, rb);
+    };
+    fetch(0);
+    commit(0, 0);
+    __syncthreads();
+    for (long t = 0; t < total; ++t) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < total) fetch(t + 1);
+        const float *As = lds + buf * 2 * LW_TILE_F, *Bs = As + LW_TILE_F;
 #pragma unroll 4
         for (int k = 0; k < LW_KT; k += 2) {
             float af[2], bf[2];
@@ -103,7 +190,41 @@ __global__ __launch_bounds__(256) void k_linear(float *__restrict__ Y, long ldy,
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+        if (t + 1 < total) commit(t + 1, buf ^ 1);
+        __syncthreads();
     }
+}
+
+// 16-byte loads along an operand's unit stride are legal when its base, its other stride and its extent along the unit
+// stride are multiples of 4 floats
+static inline bool lw_aligned(const void *p, long other_stride, long extent_unit) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (other_stride & 3) == 0 && (extent_unit & 3) == 0;
+}
+
+// Y[b][n] = act( sum_k Xcat[b][k] * W[n][k] + bias[n] + row_add[b] ),  Xcat = [X1 (K1 cols) | X2 (K2 cols)]
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void k_linear(float *__restrict__ Y, long ldy, const float *__restrict__ X1, long ldx1, int K1,
+                                                   const float *__restrict__ X2, long ldx2, int K2, const float *__restrict__ W,
+                                                   long ldw, const float *__restrict__ bias, const float *__restrict__ row_add,
+                                                   long B, int N, int act) {
+    extern __shared__ float lw_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i32 = lane & 31, kk = lane >> 5;
+    const long m0 = (long)blockIdx.y * LW_BM;
+    const int n0 = blockIdx.x * LW_BN;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = floatx16(0.f);
+    LwOperand A[2], Bm[2];
+    A[0] = LwOperand{X1, ldx1, 1, B, K1};
+    Bm[0] = LwOperand{W, ldw, 1, N, K1};
+    A[1] = LwOperand{X2, ldx2, 1, B, K2};
+    Bm[1] = LwOperand{W + K1, ldw, 1, N, K2};
+    const long kb[2] = {0, 0}, ke[2] = {K1, K2};
+    lw_mainloop<true, true, VEC>(acc, lw_lds, A, Bm, kb, ke, K2 > 0 ? 2 : 1, m0, n0);
     // C layout: lane -> column (feature) n, registers -> rows
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -120,53 +241,29 @@ __global__ __launch_bounds__(256) void k_linear(float *__restrict__ Y, long ldy,
         }
 }
 
-
 // ---- generic strided GEMM:  C[m][n] (op)= sum_k A(m,k) B(n,k),  A(m,k) = A[m sam + k sak],  B(n,k) = B[n sbn + k sbk]
-template <bool KFAST>
-__device__ __forceinline__ void lw_stage(float *S, const float *__restrict__ P, long sm, long sk, long m0, long m_lim, long k0,
-                                         long k_lim) {
-    for (int e = threadIdx.x; e < LW_BM * LW_KT; e += 256) {
-        const int r = KFAST ? e / LW_KT : e % LW_BM, kq = KFAST ? e % LW_KT : e / LW_BM;
-        const long m = m0 + r, k = k0 + kq;
-        S[r * LW_LD + kq] = (m < m_lim && k < k_lim) ? P[m * sm + k * sk] : 0.f;
-    }
-}
-
 // mode 0: store, 1: C += (exclusive owner), 2: atomicAdd (split-K partial sums)
-__global__ __launch_bounds__(256) void k_gemm(float *__restrict__ Cmat, long ldc, const float *__restrict__ A, long sam, long sak,
-                                              const float *__restrict__ B, long sbn, long sbk, long M, int N, long K,
-                                              long k_per_split, int mode) {
-    __shared__ float As[LW_BM * LW_LD], Bs[LW_BN * LW_LD];
+template <bool AK, bool BK, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm(float *__restrict__ Cmat, long ldc, const float *__restrict__ A, long sam, long sak,
+                                                 const float *__restrict__ B, long sbn, long sbk, long M, int N, long K,
+                                                 long k_per_split, int mode) {
+    extern __shared__ float lw_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i32 = lane & 31, kk = lane >> 5;
     const long m0 = (long)blockIdx.y * LW_BM;
     const int n0 = blockIdx.x * LW_BN;
-    const long kb = (long)blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
     floatx16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = floatx16(0.f);
-    const bool a_kfast = sak == 1, b_kfast = sbk == 1;
-    for (long k0 = kb; k0 < ke; k0 += LW_KT) {
-        __syncthreads();
-        if (a_kfast) lw_stage<true>(As, A, sam, sak, m0, M, k0, ke); else lw_stage<false>(As, A, sam, sak, m0, M, k0, ke);
-        if (b_kfast) lw_stage<true>(Bs, B, sbn, sbk, n0, N, k0, ke); else lw_stage<false>(Bs, B, sbn, sbk, n0, N, k0, ke);
-        __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < LW_KT; k += 2) {
-            float af[2], bf[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = As[(wr * 64 + a * 32 + i32) * LW_LD + k + kk];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = Bs[(wc * 64 + b * 32 + i32) * LW_LD + k + kk];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-    }
+    LwOperand Ao[2], Bo[2];
+    Ao[0] = LwOperand{A, sam, sak, M, K};
+    Bo[0] = LwOperand{B, sbn, sbk, N, K};
+    Ao[1] = Ao[0]; Bo[1] = Bo[0];
+    const long kb[2] = {(long)blockIdx.z * k_per_split, 0}, ke[2] = {min(K, kb[0] + k_per_split), 0};
+    lw_mainloop<AK, BK, VEC>(acc, lw_lds, Ao, Bo, kb, ke, 1, m0, n0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -292,8 +389,15 @@ extern "C" int mnr_linear(float *Y, int64_t ldy, const float *X1, int64_t ldx1, 
     if (B == 0) return MNR_OK;
     const dim3 grid((N + LW_BN - 1) / LW_BN, (unsigned)((B + LW_BM - 1) / LW_BM));
     MNR_REQUIRE(grid.y <= 65535, "too many rows for one mnr_linear launch (chunk the batch)");
-    hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, as_stream(stream), Y, (long)ldy, X1, (long)ldx1, K1, X2, (long)ldx2, K2, W,
-                       (long)ldw, bias, row_add, (long)B, N, act);
+    const bool vec = lw_aligned(X1, ldx1, K1) && lw_aligned(W, ldw, K1) && (K2 == 0 || (lw_aligned(X2, ldx2, K2) && lw_aligned(W + K1, ldw, K2)));
+    auto go = [&](auto kern) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
+        (void)attr;
+        hipLaunchKernelGGL(kern, grid, dim3(256), LW_LDS_BYTES, as_stream(stream), Y, (long)ldy, X1, (long)ldx1, K1, X2, (long)ldx2, K2,
+                           W, (long)ldw, bias, row_add, (long)B, N, act);
+    };
+    if (vec) go(&k_linear<true>); else go(&k_linear<false>);
     return check_launch("k_linear");
 }
 
@@ -316,8 +420,21 @@ extern "C" int mnr_gemm(float *C, int64_t ldc, const float *A, int64_t sam, int6
     kps = (kps + LW_KT - 1) / LW_KT * LW_KT;
     splits = K > 0 ? (K + kps - 1) / kps : 1;
     const int mode = accumulate == 0 ? 0 : (splits > 1 ? 2 : 1);
-    hipLaunchKernelGGL(k_gemm, dim3((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)splits), dim3(256), 0, as_stream(stream), C,
-                       (long)ldc, A, (long)sam, (long)sak, B, (long)sbn, (long)sbk, (long)M, N, (long)K, kps, mode);
+    MNR_REQUIRE((sak == 1 || sam == 1) && (sbk == 1 || sbn == 1), "mnr_gemm operands need a unit stride");
+    const bool ak = sak == 1, bk = sbk == 1;
+    const bool vec = (ak ? lw_aligned(A, sam, K) : lw_aligned(A, sak, M)) && (bk ? lw_aligned(B, sbn, K) : lw_aligned(B, sbk, N));
+    const dim3 grid((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)splits);
+    auto go = [&](auto kern) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
+        (void)attr;
+        hipLaunchKernelGGL(kern, grid, dim3(256), LW_LDS_BYTES, as_stream(stream), C, (long)ldc, A, (long)sam, (long)sak, B, (long)sbn,
+                           (long)sbk, (long)M, N, (long)K, kps, mode);
+    };
+    if (ak && bk) { if (vec) go(&k_gemm<true, true, true>); else go(&k_gemm<true, true, false>); }
+    else if (ak && !bk) { if (vec) go(&k_gemm<true, false, true>); else go(&k_gemm<true, false, false>); }
+    else if (!ak && !bk) { if (vec) go(&k_gemm<false, false, true>); else go(&k_gemm<false, false, false>); }
+    else { if (vec) go(&k_gemm<false, true, true>); else go(&k_gemm<false, true, false>); }
     return check_launch("k_gemm");
 }
 
