@@ -83,39 +83,37 @@ struct MlpBwdArgs {
     long tape_row0;                // tape / gradient-tape row of this launch's row 0
 };
 
-// dZ = dH masked by the stored post-ReLU activation; write dZ to the gradient tape
-template <int P, int NH>
-__device__ __forceinline__ void relu_mask_store(float (&g)[NH], const float *act_row, float *g_row, int part, bool valid) {
+// ReLU masks: the forward pass left the sign bits of every activation packed per lane (TapeLayout mask planes), so a
+// layer's mask is NH/32 words per lane -- loaded before the layer's MFMA loop, consumed after it.
+template <int NH>
+struct MaskBits { uint32_t w[(NH + 31) / 32]; };
+template <int NH>
+__device__ __forceinline__ MaskBits<NH> mask_load(const float *plane, long row, int width, int part) {
+    constexpr int NW = (NH + 31) / 32;
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(plane) + row * width + part * NW;
+    MaskBits<NH> m;
+    if constexpr (NW == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(r); m.w[0] = v.x; m.w[1] = v.y; }
+    else {
 #pragma unroll
-    for (int q = 0; q < NH / 4; ++q) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(act_row + 4 * P * q + 4 * part);
-        g[4 * q + 0] = a4.x > 0.f ? g[4 * q + 0] : 0.f;
-        g[4 * q + 1] = a4.y > 0.f ? g[4 * q + 1] : 0.f;
-        g[4 * q + 2] = a4.z > 0.f ? g[4 * q + 2] : 0.f;
-        g[4 * q + 3] = a4.w > 0.f ? g[4 * q + 3] : 0.f;
-        if (valid)
-            *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        for (int i = 0; i < NW; ++i) m.w[i] = r[i];
     }
+    return m;
 }
-
-// The ReLU masks of the layer about to be produced do not depend on the MFMA results: issue their loads BEFORE the
-// layer's MFMA loop and consume them after it (the values just sit in registers; no use before the loop, so no wait).
-template <int P, int NH>
-__device__ __forceinline__ void mask_prefetch(float4 (&m)[NH / 4], const float *act_row, int part) {
+// dZ = dH masked by ReLU'
+template <int NH>
+__device__ __forceinline__ void mask_apply(float (&g)[NH], const MaskBits<NH> &m) {
 #pragma unroll
-    for (int q = 0; q < NH / 4; ++q) m[q] = *reinterpret_cast<const float4 *>(act_row + 4 * P * q + 4 * part);
+    for (int i = 0; i < NH; ++i) g[i] = (m.w[i / 32] >> (i % 32)) & 1u ? g[i] : 0.f;
 }
+// write dZ to the gradient tape (flat register i <-> feature 4P*(i/4) + 4*part + i%4).  Callers issue this right
+// AFTER a chunk barrier of the next layer: a barrier drains vmcnt, so a store issued just before one would stall the
+// wave for a full HBM write round trip; issued after it, the store has a whole chunk of MFMAs to complete.
 template <int P, int NH>
-__device__ __forceinline__ void mask_apply_store(float (&g)[NH], const float4 (&m)[NH / 4], float *g_row, int part, bool valid) {
+__device__ __forceinline__ void gtape_store(const float (&g)[NH], float *g_row, int part, bool valid) {
+    if (!valid) return;
 #pragma unroll
-    for (int q = 0; q < NH / 4; ++q) {
-        g[4 * q + 0] = m[q].x > 0.f ? g[4 * q + 0] : 0.f;
-        g[4 * q + 1] = m[q].y > 0.f ? g[4 * q + 1] : 0.f;
-        g[4 * q + 2] = m[q].z > 0.f ? g[4 * q + 2] : 0.f;
-        g[4 * q + 3] = m[q].w > 0.f ? g[4 * q + 3] : 0.f;
-        if (valid)
-            *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-    }
+    for (int q = 0; q < NH / 4; ++q)
+        *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
 }
 
 template <int NOB, class AccT>
@@ -177,8 +175,8 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             }
             dd[4 * q] = s.x; dd[4 * q + 1] = s.y; dd[4 * q + 2] = s.z; dd[4 * q + 3] = s.w;
         }
-        relu_mask_store<P>(dd, a.tape + a.tl.dact_off * cap + trow * (W / 2), a.gtape + a.tl.dact_off * cap + trow * (W / 2),
-                           part, valid);
+        const MaskBits<H2> dm = mask_load<H2>(a.tape + a.tl.dmask_off * cap, trow, a.tl.dmask_w, part);
+        mask_apply(dd, dm);
     }
 
     // ---- dir_a^T: d(final features) and d(appearance embedding) -----------------------------------
@@ -187,17 +185,12 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         AccT accd[NOBD];
         zero_acc(accd);
         st.next_chunk();
+        gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap + trow * (W / 2), part, valid);
         run_segment<TILE, NOBD, H2 / 4, GPCD, 0>(accd, dd, st, lane);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-            for (int r = 0; r < RPB; ++r) g[ob * RPB + r] = accd[ob][r];
-        if (valid) {                               // dZ of xyz_encoding_final (no activation)
-            float *gr = a.gtape + a.tl.fin_off * cap + trow * W + 4 * part;
-#pragma unroll
-            for (int q = 0; q < H / 4; ++q)
-                *reinterpret_cast<float4 *>(gr + 4 * P * q) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-        }
+            for (int r = 0; r < RPB; ++r) g[ob * RPB + r] = accd[ob][r];    // dZ of xyz_encoding_final (no activation)
         if constexpr (C::APP > 0) {
             if (a.d_emb_a) {
                 constexpr int NAB = cdiv(C::APP, TILE);          // appearance blocks after the W final-feature rows
@@ -237,25 +230,26 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
                 acc[ob][4 * q + 0] = ds * w4.x; acc[ob][4 * q + 1] = ds * w4.y;
                 acc[ob][4 * q + 2] = ds * w4.z; acc[ob][4 * q + 3] = ds * w4.w;
             }
-        float4 bits[H / 4];
-        mask_prefetch<P, H>(bits, a.tape + a.tl.act_off[C::NL - 1] * cap + trow * W, part);
+        const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[C::NL - 1] * cap, trow, a.tl.mask_w, part);
         st.next_chunk();
+        gtape_store<P>(g, a.gtape + a.tl.fin_off * cap + trow * W, part, valid);
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
-        mask_apply_store<P>(g, bits, a.gtape + a.tl.act_off[C::NL - 1] * cap + trow * W, part, valid);
+        mask_apply(g, bits);
     }
 
     // ---- trunk layers L-1 .. 1 transposed ------------------------------------------------------------
     static_for<0, C::NL - 1>([&](auto jc) {
         constexpr int l = C::NL - 1 - decltype(jc)::value;       // consumes dZ_l, produces dZ_{l-1}
         zero_acc(acc);
-        float4 bits[H / 4];
-        mask_prefetch<P, H>(bits, a.tape + a.tl.act_off[l - 1] * cap + trow * W, part);
+        const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);
         st.next_chunk();
+        gtape_store<P>(g, a.gtape + a.tl.act_off[l] * cap + trow * W, part, valid);       // dZ_l (deferred, see gtape_store)
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
-        mask_apply_store<P>(g, bits, a.gtape + a.tl.act_off[l - 1] * cap + trow * W, part, valid);
+        mask_apply(g, bits);
     });
+    gtape_store<P>(g, a.gtape + a.tl.act_off[0] * cap + trow * W, part, valid);
 }
 
 // =================================================================================================
@@ -281,6 +275,7 @@ struct WgradArgs {
 
 constexpr int WG_KT = 32;                 // rows (K) per LDS tile
 constexpr int WG_THREADS = 512;           // 8 waves: 2 (M) x 4 (N)
+constexpr int WG_MIN_ROWS = 512;          // rows per work item, lower bound (multiple of WG_KT)
 
 // One (M x N) weight-gradient job slice.  Wave (wr, wc) of the 2 x 2 wave grid owns MBW x NBW blocks of 32 x 32.
 // Tiles of WG_KT rows of dZ and IN are streamed global -> LDS with LDS-DMA into a 2-stage ring; the MFMA loop
@@ -294,6 +289,9 @@ __device__ __forceinline__ bool wgrad_decode(const WgradArgs &a, int item, long 
     const WgradJob &J = a.job[job];
     long rps = (n_rows + J.nwg - 1) / J.nwg;
     rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
+    // the item table is sized on the host for the worst-case row count; when the device-side count is much smaller
+    // (background rays), keep items coarse enough that an accumulator flush (up to 64 K atomics) stays amortised
+    if (rps < WG_MIN_ROWS) rps = WG_MIN_ROWS;
     r_begin = (long)(item - J.wg0) * rps;
     r_end = min(n_rows, r_begin + rps);
     return true;
@@ -337,8 +335,10 @@ __device__ __forceinline__ int wgrad_run(const WgradArgs &a, int item, long n_ro
     for (int m = 0; m < MBW; ++m) bsum[m] = 0.f;
 
     int next;
+    bool touched = false;
     for (;;) {
         const long ntiles = (r_end - r_begin + WG_KT - 1) / WG_KT;
+        touched |= ntiles > 0;
         auto issue = [&](long ti) {
             const long r0 = r_begin + ti * WG_KT;
             const int nr = (int)min((long)WG_KT, r_end - r0);
@@ -405,6 +405,7 @@ __device__ __forceinline__ int wgrad_run(const WgradArgs &a, int item, long n_ro
         int njob;
         if (!wgrad_decode(a, next, n_rows, njob, r_begin, r_end) || njob != job) break;
     }
+    if (!touched) return next;                          // only empty row ranges: nothing to add
     // flush: C layout -> atomics into the nn.Parameter gradient
 #pragma unroll
     for (int m = 0; m < MBW; ++m) {
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
         int job;
         long rb, re;
         if (!wgrad_decode(a, item, n_rows, job, rb, re)) return;
+        if (rb >= re) { item = wgrad_pull(a, wlds); continue; }      // row range past the device-side row count
         const WgradJob &J = a.job[job];
         const int NBW = ((J.N + 31) / 32 + 3) / 4;         // column blocks per wave (4 wave columns)
         if (J.M == 256) {

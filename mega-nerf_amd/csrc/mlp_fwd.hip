@@ -40,6 +40,22 @@ __device__ __forceinline__ void tape_store_regs(float *plane, long row, int widt
     for (int q = 0; q < NH / 4; ++q)
         *reinterpret_cast<float4 *>(r + 4 * P * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
 }
+// ReLU sign bits of a C-layout register array, packed per lane (TapeLayout mask planes)
+template <int P, int NH>
+__device__ __forceinline__ void tape_store_mask(float *plane, long row, int width, const float (&h)[NH], int part) {
+    constexpr int NW = (NH + 31) / 32;
+    uint32_t *r = reinterpret_cast<uint32_t *>(plane) + row * width + part * NW;
+    uint32_t w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) w[i / 32] |= h[i] > 0.f ? (1u << (i % 32)) : 0u;
+    if constexpr (NW == 2) *reinterpret_cast<uint2 *>(r) = make_uint2(w[0], w[1]);
+    else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r[i] = w[i];
+    }
+}
 // positional-encoding registers -> reference column order (nerf.py:20-25)
 template <int D, int L, int P, int NE>
 __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width, const float (&e)[NE], int part) {
@@ -100,6 +116,14 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         constexpr int l = decltype(lc)::value;
         init_acc<NOB, RPB>(acc, a.aux + a.bias_off[l] + part * H);
         st.next_chunk();
+        if constexpr (TRAIN && l > 0) {
+            // Tape stores of the previous layer's output are issued right AFTER the chunk barrier: a barrier drains
+            // vmcnt, so stores issued just before one would stall the wave for a full HBM write round trip.
+            if (valid) {
+                tape_store_regs<P>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, row + a.tape_row0, C::W, h, part);
+                tape_store_mask<P>(a.tape + a.tl.mask_off[l - 1] * a.tape_rows, row + a.tape_row0, a.tl.mask_w, h, part);
+            }
+        }
         if constexpr (l == 0) {
             run_segment<TILE, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane);
         } else if constexpr ((C::SKIP >> l) & 1) {
@@ -109,9 +133,6 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
-        if constexpr (TRAIN) {
-            if (valid) tape_store_regs<P>(a.tape + a.tl.act_off[l] * a.tape_rows, row + a.tape_row0, C::W, h, part);
-        }
     });
     li = C::NL;
 
@@ -141,17 +162,23 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     if constexpr (C::HAS_FINAL) {
         init_acc<NOB, RPB>(acc, a.aux + a.bias_off[li] + part * H);
         st.next_chunk();
+        if constexpr (TRAIN) {                                   // deferred store of the last trunk layer (see above)
+            if (valid) {
+                tape_store_regs<P>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, row + a.tape_row0, C::W, h, part);
+                tape_store_mask<P>(a.tape + a.tl.mask_off[C::NL - 1] * a.tape_rows, row + a.tape_row0, a.tl.mask_w, h, part);
+            }
+        }
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
         acc_to_regs<NOB, RPB, false>(h, acc);                    // xyz_encoding_final: no activation
-        if constexpr (TRAIN) {
-            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, row + a.tape_row0, C::W, h, part);
-        }
         ++li;
 
         constexpr int NOB2 = C::NOB2, H2 = C::H2;
         AccT acc2[NOB2];
         init_acc<NOB2, RPB>(acc2, a.aux + a.bias_off[li] + part * H2);
         st.next_chunk();
+        if constexpr (TRAIN) {
+            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, row + a.tape_row0, C::W, h, part);
+        }
         run_segment<TILE, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane);
         if constexpr (C::ED > 0) {
             float dv[3];
@@ -184,7 +211,10 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         float dreg[H2];
         acc_to_regs<NOB2, RPB, true>(dreg, acc2);
         if constexpr (TRAIN) {
-            if (valid) tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, row + a.tape_row0, C::W / 2, dreg, part);
+            if (valid) {
+                tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, row + a.tape_row0, C::W / 2, dreg, part);
+                tape_store_mask<P>(a.tape + a.tl.dmask_off * a.tape_rows, row + a.tape_row0, a.tl.dmask_w, dreg, part);
+            }
         }
 #pragma unroll
         for (int c = 0; c < C::RGB; ++c) {
