@@ -339,6 +339,14 @@ int mnr_cluster_min_ratios(float *ratios_out, uint8_t *masks_out, const float *r
                            const float *z_steps_dev, int n_samples, const float *centroids_dev, int n_centroids,
                            int cluster_2d, float boundary_margin, void *stream);
 
+/* ---- validation metrics (metrics.py:8-10 PSNR, :51-121 SSIM; runner.py:413-436) --------------------------------
+ * pred / target: [H][W][3] fp32 images on the device, rows `row_stride` floats apart (so the right-half views of
+ * runner.py:413-414 need no copy).  filter_dev: the normalised 1-D Gaussian (filter_size taps, odd, <= 33) as metrics.py:77-82
+ * builds it.  Adds to acc_dev[0] the sum of squared errors over H*W*3 values and to acc_dev[1] the sum of the SSIM map
+ * (zero-padded separable blur, variance clamps and covariance limit of :96-111); the caller zeroes acc_dev and divides. */
+int mnr_image_metrics(const float *pred_dev, const float *target_dev, int H, int W, int64_t row_stride, const float *filter_dev,
+                      int filter_size, float max_val, float k1, float k2, double *acc_dev, void *stream);
+
 /* ---- backward of the rendering stages (training; autograd over rendering.py:102-131,336-393) --------- */
 
 /* Gradient of mnr_composite's rgb (and bg_lambda) output w.r.t. the raw MLP outputs. Inputs as in the forward

@@ -33,7 +33,7 @@ from torch.optim.lr_scheduler import ExponentialLR
 from mega_nerf import distributed as mdist
 from mega_nerf.datasets.memory_dataset import MemoryDataset
 from mega_nerf.image_metadata import ImageMetadata
-from mega_nerf.metrics import psnr
+from mega_nerf.metrics import psnr, psnr_ssim
 from mega_nerf.misc_utils import main_print, main_tqdm
 from mega_nerf.models.model_utils import get_bg_nerf, get_nerf
 from mega_nerf.ray_utils import get_ray_directions, get_rays
@@ -165,7 +165,7 @@ class Runner:
                 train_iterations += 1
                 if self.is_master and train_iterations % max(1, min(hp.ckpt_interval, 100)) == 0:
                     main_print('iter {}: psnr {:.3f} loss {:.5f}'.format(train_iterations, metrics['psnr'],
-                                                                        float(metrics['loss'])))
+                                                                        float(metrics['loss'].detach())))
                 if self.is_master and train_iterations % hp.ckpt_interval == 0:
                     self._save_checkpoint(optimizers, None, train_iterations, dataset_index, None)
                 if train_iterations % hp.val_interval == 0:
@@ -225,8 +225,8 @@ class Runner:
         return metrics, bg_present
 
     def _run_validation(self, train_index: int) -> Dict[str, float]:
-        """PSNR over the right half of every validation image (runner.py:413-417); images are split over the
-        ranks and the sums combined with one all_reduce."""
+        """PSNR and SSIM over the right half of every validation image (runner.py:413-436), evaluated on the device in one
+        pass per image (LPIPS is out of scope); images are split over the ranks and the sums combined with one all_reduce."""
         world = int(os.environ.get('WORLD_SIZE', 1)) if self.distributed else 1
         rank = int(os.environ.get('RANK', 0)) if self.distributed else 0
         sums = defaultdict(float)
@@ -239,17 +239,20 @@ class Runner:
             count = 0
             for i in main_tqdm(mdist.images_for_rank(len(self.val_items), rank, world)):
                 item = self.val_items[i]
-                gt = item.load_image().float() / 255.
+                gt = (item.load_image().float() / 255.).to(self.device)
                 results, _ = self.render_image(item)
                 typ = 'fine' if 'rgb_fine' in results else 'coarse'
-                pred = results[f'rgb_{typ}'].view(*gt.shape).cpu()
+                pred = results[f'rgb_{typ}'].view(*gt.shape)
                 half = gt.shape[1] // 2
-                sums['val/psnr'] += psnr(pred[:, half:].reshape(-1, 3), gt[:, half:].reshape(-1, 3))
+                val_psnr, val_ssim = psnr_ssim(pred[:, half:], gt[:, half:], 1.0)     # strided right-half views, no copy
+                sums['val/psnr'] += val_psnr
+                sums['val/ssim'] += val_ssim
                 count += 1
             self.nerf.train(was_training)
             if self.bg_nerf is not None:
                 self.bg_nerf.train(bg_was)
         sums.setdefault('val/psnr', 0.0)
+        sums.setdefault('val/ssim', 0.0)
         total, _ = mdist.all_reduce_metrics(dict(sums), count, self.device)
         return total
 

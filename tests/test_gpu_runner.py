@@ -44,7 +44,10 @@ def test_train_then_eval_entry_points(tmp_path):
     # evaluation of the checkpoint through eval.py reproduces the validation PSNR written after training
     ev.main(parse(['--exp_name', str(exp), '--ckpt_path', str(run0 / 'models' / '40.pt')]))
     m_eval = (exp / '1' / 'metrics.txt').read_text()
-    a = float(m_train.strip().split(':')[1])
-    b = float(m_eval.strip().split(':')[1])
+    def metric(text, key):
+        return float([ln for ln in text.splitlines() if ln.startswith('Average ' + key)][0].split(':')[1])
+
+    a, b = metric(m_train, 'val/psnr'), metric(m_eval, 'val/psnr')
     assert abs(a - b) < 0.05, (a, b)            # north star: PSNR within 0.05 dB
     assert a > 5.0
+    assert abs(metric(m_train, 'val/ssim') - metric(m_eval, 'val/ssim')) < 1e-3 and 0.0 < metric(m_eval, 'val/ssim') <= 1.0
