@@ -58,6 +58,13 @@ int mnr_ray_directions(float *out_dev, int W, int H, float fx, float fy, float c
 int mnr_get_rays(float *out_dev, const float *dirs_dev, int64_t P, int n_dirs_sets, const float *c2w_dev,
                  int n_poses, float near, float far, const float *alt_range_host, void *stream);
 
+/* Rays of a shuffled training chunk (filesystem_dataset.py:96-124): out[t] = ray of pixel pixel_idx[t] (row of the shared
+ * direction table dirs_dev [n_dirs][3]) seen from pose img_idx[t] (c2w_dev [n_poses][12]); same arithmetic as mnr_get_rays.
+ * Out-of-range indices are clamped and set *err_flag_dev (nullable) to 1. */
+int mnr_get_rays_indexed(float *out_dev, const float *dirs_dev, int64_t n_dirs, const int32_t *pixel_idx_dev, const float *c2w_dev,
+                         int n_poses, const int32_t *img_idx_dev, int64_t M, float near, float far, const float *alt_range_host,
+                         int32_t *err_flag_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeRF MLP -- mega_nerf/models/nerf.py:45-160
  * ---------------------------------------------------------------------------------------------- */

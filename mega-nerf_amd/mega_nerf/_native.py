@@ -95,7 +95,7 @@ EXPORTS = [
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
     'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
-    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics',
+    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -179,6 +179,8 @@ def lib() -> C.CDLL:
                                       C.c_int64, C.c_void_p]
         _lib.mnr_sh_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_int64, C.c_int, C.c_int64, C.c_void_p]
+        _lib.mnr_get_rays_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                                              C.c_float, C.c_float, c_float_p, C.c_void_p, C.c_void_p]
         _lib.mnr_image_metrics.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_float,
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib.mnr_cluster_min_ratios.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,

@@ -13,6 +13,18 @@ from mega_nerf.misc_utils import main_print, main_tqdm
 from mega_nerf.ray_utils import get_ray_directions, get_rays
 
 
+_UNIT: Dict[str, torch.Tensor] = {}
+
+
+def unit_rgb(rgb_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 colours -> fp32 in [0, 1] with the values the reference's CPU ``x / 255.`` produces (device division by a
+    scalar is a multiplication by the rounded reciprocal and differs by an ulp for half of the 256 levels): table lookup."""
+    key = str(rgb_u8.device)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.arange(256, dtype=torch.float32) / 255.).to(rgb_u8.device)
+    return _UNIT[key][rgb_u8.long()]
+
+
 def get_rgb_index_mask(metadata: ImageMetadata) -> Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]:
     """Pixels of one image that take part in training (reference dataset_utils.py:8-39): validation images keep
     only their left half; cluster masks select the pixels of this submodule."""
@@ -64,11 +76,11 @@ class MemoryDataset(Dataset):
         return self._rgbs.shape[0]
 
     def __getitem__(self, idx) -> Dict[str, torch.Tensor]:
-        return {'rgbs': self._rgbs[idx].float() / 255., 'rays': self._rays[idx], 'img_indices': self._img_indices[idx]}
+        return {'rgbs': unit_rgb(self._rgbs[idx]), 'rays': self._rays[idx], 'img_indices': self._img_indices[idx]}
 
     def batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
         """One shuffled epoch of device-resident batches."""
         perm = torch.randperm(len(self), generator=generator).to(self._rays.device)
         for i in range(0, len(self), batch_size):
             sel = perm[i:i + batch_size]
-            yield {'rgbs': self._rgbs[sel].float() / 255., 'rays': self._rays[sel], 'img_indices': self._img_indices[sel]}
+            yield {'rgbs': unit_rgb(self._rgbs[sel]), 'rays': self._rays[sel], 'img_indices': self._img_indices[sel]}

@@ -38,7 +38,8 @@ def get_opts_base() -> argparse.ArgumentParser:
     a = p.add_argument
     a('--config_file', type=str, default=None)
     a('--dataset_type', type=str, default='memory', choices=['filesystem', 'memory'],
-      help='the MI355X build keeps the whole ray set resident in HBM; "filesystem" is accepted and treated as "memory"')
+      help='"memory": the whole ray set resident in HBM (default here; the reference defaults to "filesystem"); '
+           '"filesystem": the reference\'s parquet chunk directories (--chunk_paths), one chunk resident at a time')
     a('--chunk_paths', type=str, nargs='+', default=None)
     a('--num_chunks', type=int, default=200)
     a('--disk_flush_size', type=int, default=10000000)

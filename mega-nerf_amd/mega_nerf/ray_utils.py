@@ -56,3 +56,25 @@ def get_rays_batch(directions: torch.Tensor, c2w: torch.Tensor, near: float, far
         N.check(N.lib().mnr_get_rays(out.data_ptr(), d.data_ptr(), P, n, c2w.data_ptr(), n, float(near), float(far),
                                      _alt(ray_altitude_range), N.stream_ptr()))
     return out
+
+
+def get_rays_indexed(directions: torch.Tensor, pixel_indices: torch.Tensor, c2ws: torch.Tensor, img_indices: torch.Tensor,
+                     near: float, far: float, ray_altitude_range: List[float]) -> torch.Tensor:
+    """Rays of the (image, pixel) pairs of a training chunk: directions (P, 3) shared by all images, c2ws (n, 3, 4),
+    int32 index vectors (M,) -> (M, 8).  Replaces the unique/gather dance of filesystem_dataset.py:103-121."""
+    N.require_device(directions, 'directions')
+    dev = directions.device
+    d = directions.contiguous().float()
+    poses = c2ws.to(dev, torch.float32).contiguous()
+    pix = pixel_indices.to(dev, torch.int32).contiguous()
+    img = img_indices.to(dev, torch.int32).contiguous()
+    if pix.shape != img.shape or pix.dim() != 1:
+        raise N.NativeError('pixel_indices and img_indices must be 1-D and of equal length')
+    out = torch.empty(pix.shape[0], 8, device=dev, dtype=torch.float32)
+    err = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        N.check(N.lib().mnr_get_rays_indexed(out.data_ptr(), d.data_ptr(), d.shape[0], pix.data_ptr(), poses.data_ptr(),
+                                             poses.shape[0], img.data_ptr(), pix.shape[0], float(near), float(far),
+                                             _alt(ray_altitude_range), err.data_ptr(), N.stream_ptr()))
+    out._mnr_index_error = err            # checked lazily by the dataset (no sync here)
+    return out

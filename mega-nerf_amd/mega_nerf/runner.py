@@ -137,13 +137,30 @@ class Runner:
                 opt.load_state_dict(sd)
         schedulers = {k: ExponentialLR(o, gamma=hp.lr_decay_factor ** (1 / hp.train_iterations),
                                        last_epoch=train_iterations - 1) for k, o in optimizers.items()}
-        dataset = MemoryDataset(self.train_items, self.near, self.far, self.ray_altitude_range, hp.center_pixels,
-                                self.device)
+        filesystem = hp.dataset_type == 'filesystem'
+        chunk_ready = False
+        if filesystem:
+            # chunked on-disk dataset (runner.py:196-209): same chunk files / checkpoint state as the reference
+            from mega_nerf.datasets.filesystem_dataset import FilesystemDataset
+            if hp.chunk_paths is None:
+                raise Exception('--chunk_paths is required for --dataset_type filesystem')
+            dataset = FilesystemDataset(self.train_items, self.near, self.far, self.ray_altitude_range, hp.center_pixels,
+                                        self.device, [Path(x) for x in sorted(hp.chunk_paths)], hp.num_chunks,
+                                        hp.train_scale_factor, hp.disk_flush_size)
+            if hp.ckpt_path is not None and hp.resume_ckpt_state and 'dataset_state' in ckpt:
+                dataset.set_state(ckpt['dataset_state'])      # resume inside the chunk the checkpoint was taken in
+                chunk_ready = True
+        else:
+            dataset = MemoryDataset(self.train_items, self.near, self.far, self.ray_altitude_range, hp.center_pixels,
+                                    self.device)
         self.nerf.train()
         if self.bg_nerf is not None:
             self.bg_nerf.train()
         dataset_index = 0
         while train_iterations < hp.train_iterations:
+            if filesystem and not chunk_ready:
+                dataset.load_chunk()                      # next chunk (prefetched on its own stream by a worker thread)
+            chunk_ready = False
             for dataset_index, item in enumerate(dataset.batches(hp.batch_size)):
                 image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)
@@ -167,13 +184,14 @@ class Runner:
                     main_print('iter {}: psnr {:.3f} loss {:.5f}'.format(train_iterations, metrics['psnr'],
                                                                         float(metrics['loss'].detach())))
                 if self.is_master and train_iterations % hp.ckpt_interval == 0:
-                    self._save_checkpoint(optimizers, None, train_iterations, dataset_index, None)
+                    self._save_checkpoint(optimizers, None, train_iterations, dataset_index,
+                                          dataset.get_state() if filesystem else None)
                 if train_iterations % hp.val_interval == 0:
                     self._run_validation(train_iterations)
                 if train_iterations >= hp.train_iterations:
                     break
         if self.is_master:
-            self._save_checkpoint(optimizers, None, train_iterations, dataset_index, None)
+            self._save_checkpoint(optimizers, None, train_iterations, dataset_index, dataset.get_state() if filesystem else None)
         if hp.cluster_mask_path is None:
             self._write_final_metrics(self._run_validation(train_iterations))
 
