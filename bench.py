@@ -57,37 +57,57 @@ def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode
     import common
     from oracle import torch_oracle as TO
     s = common.SCENE
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     fg, bg = TO.make_models(hp, fcfg, fw, bcfg, bw, s['appearance_count'])
-    rays, idx, tgt = torch.from_numpy(rays_np[:n_sample]), torch.from_numpy(idx_np[:n_sample]), torch.from_numpy(tgt_np[:n_sample])
     sc, sr = torch.from_numpy(s['sphere_center']), torch.from_numpy(s['sphere_radius'])
     if mode == 'train':
         fg.train(), bg.train()
         opts = [torch.optim.Adam(fg.parameters(), lr=5e-4), torch.optim.Adam(bg.parameters(), lr=5e-4)]
+    else:
+        fg.eval(), bg.eval()
 
-        def fn():
+    def run(n):
+        rays, idx, tgt = torch.from_numpy(rays_np[:n]), torch.from_numpy(idx_np[:n]), torch.from_numpy(tgt_np[:n])
+        t0 = time.perf_counter()
+        if mode == 'train':
             for o in opts:
                 o.zero_grad(set_to_none=True)
             res = TO.render_rays(fg, bg, rays, idx, hp, sc, sr)
             torch.nn.functional.mse_loss(res['rgb_fine'], tgt).backward()
             for o in opts:
                 o.step()
-    else:
-        fg.eval(), bg.eval()
-
-        def fn():
+        else:
             with torch.inference_mode():
                 TO.render_rays(fg, bg, rays, idx, hp, sc, sr)
-    fn()
-    best = 1e30
-    for _ in range(3):
-        t0 = time.perf_counter()
-        fn()
-        best = min(best, time.perf_counter() - t0)
-    return {'value': n_sample / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-            'sample': 'torch-CPU restatement of the reference (%s), %d rays x (64+128) samples of the same batch, '
-                      '%d threads, best of 3 after 1 warm-up' % ('fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n_sample, cores)}
+        return time.perf_counter() - t0
+
+    # bounded sample: a 32-ray probe (also the warm-up) sizes the timed sample to ~5 s per repetition, at most the batch
+    probe = min(run(32), run(32))
+    n = int(max(32, min(n_sample, (5.0 / max(probe / 32, 1e-9)) // 32 * 32)))
+    best = probe if n == 32 else min(run(n) for _ in range(2))
+    return {'value': n / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
+            'sample': 'torch-CPU restatement of the reference (%s), first %d rays x (64+128) samples of the same batch, '
+                      '%d threads, best of 2 after a 32-ray warm-up' % ('fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n, cores)}
+
+
+def usable_cores(cap: int = 32) -> int:
+    """Host threads for the CPU baseline: the affinity mask and the cgroup CPU quota (a container on a 256-thread host may
+    own far fewer), capped -- beyond a few dozen threads these GEMM sizes only thrash."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
 
 
 def main():
@@ -201,7 +221,10 @@ def main():
         traffic_tab = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
 
         def roofline(tag, kernel, flops, key):
-            ms = [a.elapsed_time(b) for t, a, b in ev if t == tag]
+            """tag: one launch tag, or a tuple of tags = every launch of one kernel symbol in a step (then ``flops`` is the
+            mean per launch), so that avg_launch_ms is the same population as the kernel's row in a rocprofv3 trace."""
+            tags = tag if isinstance(tag, tuple) else (tag,)
+            ms = [a.elapsed_time(b) for t, a, b in ev if t in tags]
             if not ms:
                 return None
             avg = sum(ms) / len(ms) * 1e-3
@@ -218,14 +241,19 @@ def main():
             # (algorithmic FLOPs = 2 * rows * sum_l M_l*N_l over the MFMA layers = per-sample forward MACs * 2
             #  minus the two VALU heads)
             wgrad_flops = n_all * (FG_FLOP_PER_SAMPLE - 2 * (256 + 3 * 128))
-            roof = roofline('fg_wgrad', 'k_wgrad (fg, %d rows x 13 layer jobs)' % n_all, wgrad_flops,
-                            'k_wgrad_fg_bytes_per_launch')
+            roof = roofline('fg_wgrad', 'k_wgrad<true> (fg, %d rows x 13 layer jobs; the only launch of this symbol per step)' % n_all,
+                            wgrad_flops, 'k_wgrad_fg_bytes_per_launch')
             extra_roof = {'k_mlp_fwd_train_fg_fine': fwd_fine,
                           'k_mlp_bwd_fg_fine': roofline('fg_bwd_fine', 'k_mlp_bwd<fg> (fine rows)',
                                                         n_fine * (FG_FLOP_PER_SAMPLE - 2 * 80 * 256 - 2 * (27 * 128)),
                                                         'k_mlp_bwd_fg_fine_bytes_per_launch')}
         else:
-            roof, extra_roof = fwd_fine, None
+            # every launch of the fg forward symbol in a step (coarse 64 + fine 128 samples per ray): the population a
+            # rocprofv3 kernel trace averages over; the fine pass alone is reported beside it
+            n_coarse = args.rays * 64
+            roof = roofline(('fg_coarse', 'fg_fine'), 'k_mlp_fwd<fg, false> (coarse %d + fine %d rows: both launches per step)' % (n_coarse, n_fine),
+                            (n_coarse + n_fine) / 2 * FG_FLOP_PER_SAMPLE, 'k_mlp_fwd_fg_all_bytes_per_launch')
+            extra_roof = {'k_mlp_fwd_fg_fine_only': fwd_fine}
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), target.cpu().numpy(), fw, bw, fcfg, bcfg,

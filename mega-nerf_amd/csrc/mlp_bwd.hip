@@ -430,9 +430,12 @@ __device__ __forceinline__ int wgrad_run(const WgradArgs &a, int item, long n_ro
 
 // Persistent workgroups pulling (job, row-range) items from a device-side queue: perfect load balance across
 // jobs of very different shapes, while consecutive items of one job share a single accumulator flush.
+// DENSE = row count known on the host (the foreground's single coarse+fine launch); the device-counted form serves the
+// compacted background rows.  Two symbols so that a kernel trace reports the dominant launch on its own row.
+template <bool DENSE>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
     extern __shared__ float wlds[];
-    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
+    const long n_rows = DENSE ? a.n_rows : (long)(*a.n_units_dev) * a.rows_per_unit;
     int item = wgrad_pull(a, wlds);
     for (;;) {
         int job;
@@ -676,12 +679,15 @@ extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_g
     if (io->n_rows > 0) {
         static size_t lds_enabled = 0;       // raise the dynamic-LDS cap once (monotonic; benign if raced)
         if (lds > 64 * 1024 && lds > lds_enabled) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad): %s", hipGetErrorString(e));
+            for (const void *fn : {reinterpret_cast<const void *>(k_wgrad<true>), reinterpret_cast<const void *>(k_wgrad<false>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad): %s", hipGetErrorString(e));
+            }
             lds_enabled = 160 * 1024;
         }
         if (hipMemsetAsync(io->work_counter, 0, sizeof(int32_t), s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(work_counter)");
-        hipLaunchKernelGGL(k_wgrad, dim3(wg < 256 ? wg : 256), dim3(WG_THREADS), lds, s, wa);
+        if (io->n_units_dev) hipLaunchKernelGGL(k_wgrad<false>, dim3(wg < 256 ? wg : 256), dim3(WG_THREADS), lds, s, wa);
+        else hipLaunchKernelGGL(k_wgrad<true>, dim3(wg < 256 ? wg : 256), dim3(WG_THREADS), lds, s, wa);
         rc = check_launch("k_wgrad");
         if (rc) return rc;
     }
