@@ -135,13 +135,13 @@ def main():
         dist.init_process_group('nccl')            # RCCL on ROCm
     assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
 
-    import common
-    from oracle import nerf_oracle as O
+    import common                      # tests/golden/common.py: the seeded scene / weight generator (no oracle code)
     from mega_nerf import ray_utils, rendering
+    from mega_nerf.opts import get_opts_base
     from mega_nerf.rendering import render_rays_async
 
-    hp_o = O.make_hparams(coarse_samples=64, fine_samples=128)
-    hp = Namespace(**vars(hp_o))
+    # opts.py defaults = configs/mega-nerf (8x256, 12/4 frequency bands, 48-d appearance) at the benchmark's 64+128 samples
+    hp_o = hp = get_opts_base().parse_args(['--coarse_samples', '64', '--fine_samples', '128'])
     s = common.SCENE
     (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp_o, dev, 1000 * (rank + 1))   # one submodule per rank
     sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)

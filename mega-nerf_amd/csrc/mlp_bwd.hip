@@ -583,6 +583,10 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
         rc = launch_bwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(b, m, a, io->n_rows, s);
     MNR_TRY_B(3, 12, 4, 48, 256, 8, 16, 3, 16)
     MNR_TRY_B(4, 12, 4, 48, 256, 8, 16, 3, 16)
+#ifdef MNR_ALL_VARIANTS
+    MNR_TRY_B(3, 12, 4, 0, 256, 8, 16, 3, 16)         // configs/mega-nerf-no-embed
+    MNR_TRY_B(4, 12, 4, 0, 256, 8, 16, 3, 16)
+#endif
 #undef MNR_TRY_B
     if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "
                                                    "default 8x256 fg/bg models)");

@@ -375,6 +375,10 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
     // ... and their training variants (forward pass that also writes the activation tape)
     MNR_TRY_TRAIN(3, 12, 4, 48, 256, 8, 16, 3, 16)
     MNR_TRY_TRAIN(4, 12, 4, 48, 256, 8, 16, 3, 16)
+#ifdef MNR_ALL_VARIANTS
+    MNR_TRY_TRAIN(3, 12, 4, 0, 256, 8, 16, 3, 16)     // configs/mega-nerf-no-embed
+    MNR_TRY_TRAIN(4, 12, 4, 0, 256, 8, 16, 3, 16)
+#endif
     // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
     MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)
     MNR_TRY_T(4, 12, 4, 48, 256, 8, 16, 3, 32)

@@ -561,6 +561,8 @@ def _fast_path_ok(nerf, bg_nerf, hparams) -> bool:
     for m in (nerf, bg_nerf):
         if m is not None and not (isinstance(m, NeRF) and m.fused_train_supported()):
             return False
+        if m is not None and m.has_dir and m.embedding_a is None:
+            return False         # quirk Q8 needs per-sample "directions": handled by the general path
     return True
 
 

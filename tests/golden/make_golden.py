@@ -345,6 +345,7 @@ def main(only=None):
          layer_dim=128, bg_layer_dim=128)
     case('render_noapp_train', dict(base, appearance_dim=0, shifted_softplus=False), 32, 14, TR, fg_train=True, bg_train=True,
          with_grad=True, layer_dim=128, bg_layer_dim=128)
+    case('render_noapp256_train', dict(base, appearance_dim=0), 32, 16, TR, fg_train=True, bg_train=True, with_grad=True)
     case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
          bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
 

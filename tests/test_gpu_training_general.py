@@ -138,7 +138,8 @@ def test_nerf_forward_autograd_matches_fp64():
             assert err < 3e-4, (width, k, err)
 
 
-TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_noapp_train', 'render_nerf_cfg_train']
+TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_noapp_train', 'render_noapp256_train',
+               'render_nerf_cfg_train']
 
 
 @pytest.mark.parametrize('name', TRAIN_CASES)
@@ -157,6 +158,8 @@ def test_general_training_render_and_gradients_match_reference(name):
     flags = [bool(v) for v in g['flags']]
     sc = T(s['sphere_center']) if bg_nerf is not None else None
     sr = T(s['sphere_radius']) if bg_nerf is not None else None
+    if name == 'render_noapp256_train':          # fused training kernels without the appearance input (Q8 directions)
+        assert nerf.fused_train_supported() and bg_nerf.fused_train_supported() and not TRN._fast_path_ok(nerf, bg_nerf, hp)
     TRN.FORCE_GENERAL = True
     try:
         res, present = render_rays(nerf, bg_nerf, T(g['rays']), idx, hp, sc, sr, *flags, _randoms=rnd)

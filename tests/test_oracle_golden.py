@@ -131,6 +131,7 @@ RENDER_CASES = {
     'render_sh2_train': dict(hp=dict(sh_deg=2, pos_dir_dim=0, layer_dim=128, bg_layer_dim=128), seed=13, fg_train=True, bg_train=True),
     'render_noapp_train': dict(hp=dict(appearance_dim=0, shifted_softplus=False, layer_dim=128, bg_layer_dim=128), seed=14,
                                fg_train=True, bg_train=True),
+    'render_noapp256_train': dict(hp=dict(appearance_dim=0), seed=16, fg_train=True, bg_train=True),
     'render_nerf_cfg_train': dict(hp=dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0, layer_dim=160),
                                   seed=15, bg=False, cascade=True, fg_train=True),
 }
