@@ -119,6 +119,9 @@ def main():
                     help='train: fwd+bwd+Adam step (BASELINE metric: train rays/s); eval: render_rays forward only')
     ap.add_argument('--rays', type=int, default=1024, help='rays per batch (BASELINE: 1024)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--container', type=int, default=0, metavar='N',
+                    help='eval mode only: render through a merged N-cell container (MegaNeRF router, boundary_margin 1.15) '
+                         'instead of one submodule -- the "8-submodule Rubble" evaluation shape on ONE GPU')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -144,6 +147,20 @@ def main():
     hp_o = hp = get_opts_base().parse_args(['--coarse_samples', '64', '--fine_samples', '128'])
     s = common.SCENE
     (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp_o, dev, 1000 * (rank + 1))   # one submodule per rank
+    if args.container:
+        assert args.mode == 'eval', '--container is an evaluation shape (routed containers are inference-only)'
+        from mega_nerf.models.mega_nerf import MegaNeRF
+        n = args.container
+        g0 = max(1, int(round(n ** 0.5)) if int(round(n ** 0.5)) ** 2 == n else 2)
+        g1 = n // g0
+        assert g0 * g1 == n, '--container must factor into a grid'
+        cent = torch.stack([torch.zeros(n), torch.linspace(-.45, .45, g0).repeat_interleave(g1),
+                            torch.linspace(-.45, .45, g1).repeat(g0)], 1)
+        cells = [build_models(hp_o, dev, 1000 * (rank + 1) + 7 * j) for j in range(n)]
+        fg = MegaNeRF([c[0][0] for c in cells], cent, hp.boundary_margin, False, False).to(dev)
+        bg = MegaNeRF([c[1][0] for c in cells], cent, hp.boundary_margin, True, False).to(dev)
+        hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
+        args.no_cpu_baseline = True
     sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
 
     # synthetic batch: rays of the 400x400 camera, seeded permutation, ~13 % bg rays
@@ -234,6 +251,8 @@ def main():
                     'avg_launch_ms': round(avg * 1e3, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
         n_fine, n_all = args.rays * 128, args.rays * 192
+        if args.container:
+            ev = []          # routed launches have data-dependent row counts: no per-kernel roofline for this shape
         fwd_fine = roofline('fg_fine', 'k_mlp_fwd<fg> (fine pass, %d rows)' % n_fine, n_fine * FG_FLOP_PER_SAMPLE,
                             'k_mlp_fwd_fg_fine_bytes_per_launch')
         if args.mode == 'train':
@@ -264,13 +283,16 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs/mega-nerf Rubble-shaped fg+bg NeRF (8x256, 12/4 freqs, 48-d appearance), '
-                                   '%d rays x (64+128) samples per step, one submodule per GPU' % args.rays,
+                                   '%d rays x (64+128) samples per step, %s' % (
+                                       args.rays, 'one submodule per GPU' if not args.container else
+                                       'merged %d-cell container (MegaNeRF router, margin 1.15)' % args.container),
                        'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg,
-                       'parallelism': 'submodule-per-gpu x%d' % world},
+                       'parallelism': 'submodule-per-gpu x%d' % world if not args.container else
+                       '%d-cell container routed on one GPU' % args.container},
             'eval_psnr_vs_random_target_db': round(psnr, 4),
             'roofline': roof, 'cpu_baseline': cpu,
         }
-        if extra_roof:
+        if extra_roof and any(v is not None for v in extra_roof.values()):
             line['roofline_other_kernels'] = extra_roof
         if other:
             line[other[0]] = other[1]
