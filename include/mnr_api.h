@@ -134,6 +134,20 @@ typedef struct mnr_mlp_io {
 } mnr_mlp_io;
 
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
+/* All cells of a routed MegaNeRF evaluation in ONE launch (the per-cell launches of mega_nerf.py:28-49 are individually
+ * too small to fill 256 CUs).  cells_dev: DEVICE array; every cell shares the architecture of `desc` (its weight pointers
+ * are ignored).  Cell c evaluates the rows row_index[0 .. *count) of the shared inputs in `io` (xyz / dir / idx / noise,
+ * strides, rows_per_ray, sigma_only, apply_sh_deg; io->n_rows = capacity of every row list) into out[k * io->out_stride]
+ * for its k-th listed row.  io->out, io->row_index and io->n_units_dev are ignored. */
+typedef struct mnr_mlp_cell {
+    const void *packed_dev;        /* mnr_pack_model image of this cell */
+    const float *embedding_a;      /* its appearance table (NULL without appearance input) */
+    const int32_t *row_index;      /* compact list of the rows routed to it (mnr_route) */
+    const int32_t *count;          /* device-side length of that list */
+    float *out;                    /* [>= *count][out_stride] */
+} mnr_mlp_cell;
+int mnr_mlp_forward_cells(const mnr_model_desc *desc, const mnr_mlp_cell *cells_dev, int n_cells, const mnr_mlp_io *io,
+                          void *stream);
 /* Host-side query (no GPU work): 1 if mnr_mlp_forward has a fused kernel for this architecture, else 0. */
 int mnr_fused_supported(const mnr_model_desc *desc);
 /* ... and 1 if the fused training kernels (mnr_mlp_forward_train / mnr_mlp_backward_*) cover it. */

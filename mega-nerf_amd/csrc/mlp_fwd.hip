@@ -26,6 +26,9 @@ struct MlpFwdArgs {
     int32_t bias_off[MAX_MFMA_LAYERS];
     int32_t sigma_off, rgb_off;
     int32_t sigma_act, app_count;
+    const mnr_mlp_cell *cells;   // batched routed evaluation: per-cell weights / row lists / outputs (device array), else NULL
+    int n_cells;
+    long aux_byte_off;           // offset of the aux block inside a packed image (same for all cells of one architecture)
     float *tape;              // training only: activation tape (TapeLayout planes), else NULL
     long tape_rows;           // row capacity of every tape plane
     long tape_row0;           // tape row of this launch's row 0
@@ -81,19 +84,43 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     extern __shared__ float4 lds_ring[];
 
     const mnr_mlp_io &io = a.io;
-    const long n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
-    if ((long)blockIdx.x * C::ROWS_PER_WG >= n_rows) return;   // uniform per workgroup
+    const float4 *chunks = a.chunks;
+    const float *aux = a.aux, *emb_a = a.emb_a;
+    const int32_t *row_index = io.row_index;
+    float *outp = io.out;
+    long n_rows, blk = blockIdx.x;
+    if (a.cells) {
+        // One launch for all cells of a routed evaluation: workgroups are laid out cell after cell, ceil(count_c / rows
+        // per workgroup) each; everything below is uniform per workgroup, so the per-cell pointers stay in SGPRs.
+        int c = 0;
+        n_rows = 0;
+        for (; c < a.n_cells; ++c) {
+            const long n = *a.cells[c].count, t = (n + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+            if (blk < t) { n_rows = n; break; }
+            blk -= t;
+        }
+        if (c == a.n_cells) return;
+        const mnr_mlp_cell cell = a.cells[c];
+        chunks = reinterpret_cast<const float4 *>(cell.packed_dev);
+        aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(cell.packed_dev) + a.aux_byte_off);
+        emb_a = cell.embedding_a;
+        row_index = cell.row_index;
+        outp = cell.out;
+    } else {
+        n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
+        if (blk * C::ROWS_PER_WG >= n_rows) return;             // uniform per workgroup
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
-    const long row = ((long)blockIdx.x * 4 + wave) * TILE + (lane % TILE);
+    const long row = (blk * 4 + wave) * TILE + (lane % TILE);
     const bool valid = row < n_rows;
     const long rc = valid ? row : n_rows - 1;
-    const long src = io.row_index ? (long)io.row_index[rc] : rc;      // gathered evaluation (MegaNeRF router)
+    const long src = row_index ? (long)row_index[rc] : rc;           // gathered evaluation (MegaNeRF router)
     const long ray = src / io.rows_per_ray;
 
     WStream st;
-    st.g = a.chunks + threadIdx.x;
+    st.g = chunks + threadIdx.x;
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();                                   // chunk 0 in flight while we encode
@@ -114,7 +141,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     // ---- trunk: nerf.py:127-130 ------------------------------------------------------------------
     static_for<0, C::NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        init_acc<NOB, RPB>(acc, a.aux + a.bias_off[l] + part * H);
+        init_acc<NOB, RPB>(acc, aux + a.bias_off[l] + part * H);
         st.next_chunk();
         if constexpr (TRAIN && l > 0) {
             // Tape stores of the previous layer's output are issued right AFTER the chunk barrier: a barrier drains
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     // ---- sigma head: nerf.py:132-136 -------------------------------------------------------------
     float sigma;
     {
-        const float *ws = a.aux + a.sigma_off;
+        const float *ws = aux + a.sigma_off;
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
@@ -152,15 +179,15 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
     }
     if (io.sigma_only) {
-        if (valid && part == 0) io.out[row * io.out_stride] = sigma;
+        if (valid && part == 0) outp[row * io.out_stride] = sigma;
         return;
     }
 
     // ---- colour branch: nerf.py:141-152 ----------------------------------------------------------
     float rgbraw[C::RGB];
-    const float *wr = a.aux + a.rgb_off;
+    const float *wr = aux + a.rgb_off;
     if constexpr (C::HAS_FINAL) {
-        init_acc<NOB, RPB>(acc, a.aux + a.bias_off[li] + part * H);
+        init_acc<NOB, RPB>(acc, aux + a.bias_off[li] + part * H);
         st.next_chunk();
         if constexpr (TRAIN) {                                   // deferred store of the last trunk layer (see above)
             if (valid) {
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
 
         constexpr int NOB2 = C::NOB2, H2 = C::H2;
         AccT acc2[NOB2];
-        init_acc<NOB2, RPB>(acc2, a.aux + a.bias_off[li] + part * H2);
+        init_acc<NOB2, RPB>(acc2, aux + a.bias_off[li] + part * H2);
         st.next_chunk();
         if constexpr (TRAIN) {
             if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, row + a.tape_row0, C::W, h, part);
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
             long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
                                        : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
             idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);   // reference would raise; stay in bounds
-            const float *ea = a.emb_a + idx * C::APP + part * (C::APP / P);
+            const float *ea = emb_a + idx * C::APP + part * (C::APP / P);
             float ap[C::AP];
 #pragma unroll
             for (int i = 0; i < C::AP; ++i) ap[i] = (i < C::APP / P) ? ea[i] : 0.f;
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     }
 
     if (!(valid && part == 0)) return;
-    float *o = io.out + row * io.out_stride;
+    float *o = outp + row * io.out_stride;
     if constexpr (C::RGB == 3) {
         o[0] = sigmoidf_(rgbraw[0]); o[1] = sigmoidf_(rgbraw[1]); o[2] = sigmoidf_(rgbraw[2]); o[3] = sigma;
     } else {
@@ -263,7 +290,8 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
 
 template <class C, bool TRAIN = false>
 static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
-                      hipStream_t stream, float *tape = nullptr, long tape_rows = 0, long tape_row0 = 0) {
+                      hipStream_t stream, float *tape = nullptr, long tape_rows = 0, long tape_row0 = 0,
+                      const mnr_mlp_cell *cells = nullptr, int n_cells = 0) {
     // the template's static structure must agree with the runtime layout the packer used
     if (m.tile != C::TILE || m.layer[0].nsteps != C::EX || m.layer[0].gpc != C::GPC || m.has_final != (int)C::HAS_FINAL ||
         m.rgb_in_regs != C::H2 || m.n_mfma_layers != C::NL + (C::HAS_FINAL ? 2 : 0))
@@ -274,6 +302,9 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     a.chunks = reinterpret_cast<const float4 *>(packed);
     a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) + (size_t)m.total_chunks * CHUNK_BYTES);
     a.emb_a = d->embedding_a;
+    a.cells = cells;
+    a.n_cells = n_cells;
+    a.aux_byte_off = (long)m.total_chunks * CHUNK_BYTES;
     a.io = *io;
     for (int i = 0; i < MAX_MFMA_LAYERS; ++i) a.bias_off[i] = i < m.n_mfma_layers ? m.layer[i].bias_off : 0;
     a.sigma_off = m.sigma_off;
@@ -285,8 +316,10 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     a.tape_row0 = tape_row0;
     a.tl = tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
                                 d->appearance_dim, d->rgb_dim, d->mfma_tile});
-    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+    // cells: the worst case (every row routed to every cell); workgroups past the device-side counts exit at once
+    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
+    if (nwg > 0x7fffffffL) return set_err(MNR_E_INVALID, "too many rows for one MLP launch");
     hipLaunchKernelGGL((k_mlp_fwd<C, TRAIN>), dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
     return check_launch("k_mlp_fwd");
 }
@@ -296,7 +329,7 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
 using namespace mnr;
 
 static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
-                            float *tape, long tape_rows, long tape_row0);
+                            float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells = nullptr, int n_cells = 0);
 
 // 1 if mnr_mlp_forward has a register-chained instantiation for this architecture, else 0 (host-side query).
 extern "C" int mnr_fused_supported(const mnr_model_desc *d) {
@@ -347,23 +380,23 @@ extern "C" int64_t mnr_tape_floats_per_row(const mnr_model_desc *d) {
 }
 
 static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
-                            float *tape, long tape_rows, long tape_row0) {
+                            float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells, int n_cells) {
     ModelLayout m;
     int rc = layout_from_desc(d, m);
     if (rc != MNR_OK) return rc;
-    MNR_REQUIRE(packed_dev && io && io->xyz && io->out, "NULL pointer argument");
+    MNR_REQUIRE(io && io->xyz && (cells ? n_cells > 0 : (packed_dev && io->out)), "NULL pointer argument");
     MNR_REQUIRE(io->rows_per_ray >= 1, "rows_per_ray must be >= 1");
     MNR_REQUIRE(io->n_rows >= 0, "negative n_rows");
     const bool need_dir = !io->sigma_only && (d->pos_dir_dim > 0 || (d->rgb_dim > 3 && io->apply_sh_deg >= 0));
     MNR_REQUIRE(!need_dir || io->dir, "dir pointer required");
-    MNR_REQUIRE(d->appearance_dim == 0 || io->sigma_only || (io->idx && d->embedding_a), "idx / embedding_a required");
+    MNR_REQUIRE(d->appearance_dim == 0 || io->sigma_only || (io->idx && (cells || d->embedding_a)), "idx / embedding_a required");
     if (io->apply_sh_deg >= 0) MNR_REQUIRE(3 * (io->apply_sh_deg + 1) * (io->apply_sh_deg + 1) == d->rgb_dim,
                                            "apply_sh_deg does not match rgb_dim");
     hipStream_t s = as_stream(stream);
 #define MNR_TRY_T(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                     \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
         d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL && !tape) \
-        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(m, packed_dev, d, io, s);
+        return launch_fwd<MlpCfg<XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL>>(m, packed_dev, d, io, s, nullptr, 0, 0, cells, n_cells);
 #define MNR_TRY_TRAIN(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                 \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&       \
         d->layer_dim == W && d->layers == NL && d->skip_mask == SKIP && d->rgb_dim == RGB && m.tile == TL && tape) \
@@ -405,4 +438,12 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
                    "layers=%d skip_mask=%d rgb_dim=%d",
                    d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->appearance_dim, d->layer_dim, d->layers,
                    d->skip_mask, d->rgb_dim);
+}
+
+// Routed evaluation of all cells of a MegaNeRF in ONE launch (mega_nerf.py:28-49 evaluates cell after cell): every cell
+// brings its packed weights, appearance table, compact row list (+ device-side count) and output buffer.
+extern "C" int mnr_mlp_forward_cells(const mnr_model_desc *d, const mnr_mlp_cell *cells_dev, int n_cells, const mnr_mlp_io *io,
+                                     void *stream) {
+    MNR_REQUIRE(d && cells_dev && n_cells > 0 && n_cells <= 64 && io, "bad arguments to mnr_mlp_forward_cells");
+    return mlp_forward_impl(nullptr, d, io, stream, nullptr, 0, 0, cells_dev, n_cells);
 }

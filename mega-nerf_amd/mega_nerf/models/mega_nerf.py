@@ -14,6 +14,11 @@ from torch import nn
 from mega_nerf import _native as N
 
 
+def _arch_key(m):
+    return (m.xyz_dim, m.pos_xyz_dim, m.pos_dir_dim, m.layers, tuple(m.skip_layers), m.layer_dim, m.appearance_dim,
+            m.appearance_count, m.rgb_dim, type(m.sigma_activation).__name__, m.mfma_tile)
+
+
 class MegaNeRF(nn.Module):
     def __init__(self, sub_modules: List[nn.Module], centroids: torch.Tensor, boundary_margin: float, xyz_real: bool,
                  cluster_2d: bool, joint_training: bool = False):
@@ -58,8 +63,29 @@ class MegaNeRF(nn.Module):
                               self.cluster_dim_start, float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(),
                               counts.data_ptr(), N.stream_ptr()))
         out.zero_()
-        sub_out = torch.empty(B, ncol, device=dev, dtype=torch.float32)
         blend = self.boundary_margin > 1
+        kids = list(self.sub_modules)
+        same_arch = all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) for c in kids)
+        if same_arch:
+            # one launch for all cells: each cell alone (~1/n of the rows) cannot fill 256 CUs
+            sub_out = torch.empty(n_sub, B, ncol, device=dev, dtype=torch.float32)
+            rows = []
+            for i, child in enumerate(kids):
+                _, packed = child.packed()
+                rows.append([packed.data_ptr(), child.embedding_a.weight.data_ptr() if child.embedding_a is not None else 0,
+                             lists[i].data_ptr(), counts[i:i + 1].data_ptr(), sub_out[i].data_ptr()])
+            cells = torch.tensor(rows, dtype=torch.int64).to(dev)             # mnr_mlp_cell[n_sub]
+            desc, _ = kids[0].packed()
+            io = kids[0].mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, sub_out[0], noise, None, 0)
+            io.sigma_only = 1 if sigma_only else 0
+            io.apply_sh_deg = sh_deg
+            N.check(lib.mnr_mlp_forward_cells(C.byref(desc), cells.data_ptr(), n_sub, C.byref(io), N.stream_ptr()))
+            for i in range(n_sub):
+                N.check(lib.mnr_route_accumulate(out.data_ptr(), ncol, sub_out[i].data_ptr(), ncol, ncol, lists[i].data_ptr(),
+                                                 counts[i:i + 1].data_ptr(), B, weights[i].data_ptr() if blend else None,
+                                                 0 if blend else 1, N.stream_ptr()))
+            return
+        sub_out = torch.empty(B, ncol, device=dev, dtype=torch.float32)
         for i, child in enumerate(self.sub_modules):
             if not child.fused_supported():
                 self._child_gathered(child, lists[i], counts[i:i + 1], xyz, xyz_stride, dirs, dir_stride, idx, idx_stride,

@@ -145,15 +145,35 @@ class NeRF(nn.Module):
             d.embedding_a = self.embedding_a.weight.data_ptr()
         return d
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() replace the parameter tensors: drop everything derived from the old storage
+        self._param_cache = None
+        self._packed_key = self._packed_bwd_key = None
+        self._fused_ok = self._fused_train_ok = None
+        return super()._apply(fn, *args, **kwargs)
+
     def packed(self):
-        """(desc, packed device buffer); re-packs when any parameter storage/version changed."""
-        params = self._all_params()
-        for p in params:
-            N.require_device(p, 'NeRF parameter')
-            if p.dtype != torch.float32 or not p.is_contiguous():
-                raise N.NativeError('NeRF parameters must be contiguous float32')
-        key = tuple((p.data_ptr(), p._version) for p in params) + (self.mfma_tile,)
-        desc = self.model_desc()
+        """(desc, packed device buffer); re-packs when any parameter changed (in-place updates bump ``_version``; storage
+        replacement goes through ``_apply`` / ``load_state_dict`` and is caught by the pointer check).  The steady-state
+        cost is one tuple of 25 version counters -- this runs once per MLP launch, eight cells x four passes per routed
+        render, so it is kept off the per-parameter slow path."""
+        cache = getattr(self, '_param_cache', None)
+        if cache is not None:
+            params = cache[0]
+            ptrs = tuple([p.data_ptr() for p in params])
+            if ptrs != cache[1] or cache[3] != self.mfma_tile:      # storage swapped / tile changed: rebuild the descriptor
+                cache = None
+        if cache is None:
+            params = self._all_params()
+            for p in params:
+                N.require_device(p, 'NeRF parameter')
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise N.NativeError('NeRF parameters must be contiguous float32')
+            ptrs = tuple([p.data_ptr() for p in params])
+            cache = self._param_cache = (params, ptrs, self.model_desc(), self.mfma_tile)
+            self._packed_key = self._packed_bwd_key = None
+        desc = cache[2]
+        key = tuple([p._version for p in params])
         if self._packed is None or key != self._packed_key:
             nbytes = N.lib().mnr_packed_model_bytes(C.byref(desc))
             if nbytes == 0:
