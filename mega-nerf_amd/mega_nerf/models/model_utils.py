@@ -44,35 +44,52 @@ def nerf_from_scripted(sub) -> NeRF:
     return m
 
 
-def _get_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, xyz_dim: int,
-                    weight_key: str) -> nn.Module:
+def _branch_of(xyz_dim: int) -> str:
+    return 'fg' if xyz_dim == 3 else 'bg'
+
+
+def _from_container(hparams: Namespace, xyz_dim: int) -> MegaNeRF:
+    """Routed model over the cells of a merged TorchScript container (native modules rebuilt from the state_dicts)."""
+    archive = torch.jit.load(hparams.container_path, map_location='cpu')
+    stem = {'fg': 'sub_module_', 'bg': 'bg_sub_module_'}[_branch_of(xyz_dim)]
+    cells = [nerf_from_scripted(getattr(archive, stem + str(i))) for i in range(archive.centroids.shape[0])]
+    return MegaNeRF(cells, archive.centroids, hparams.boundary_margin, _branch_of(xyz_dim) == 'bg', archive.cluster_2d)
+
+
+def _load_weights(model: nn.Module, ckpt_path: str, weight_key: str) -> None:
+    state = torch.load(ckpt_path, map_location='cpu', weights_only=False)[weight_key]
+    consume_prefix_in_state_dict_if_present(state, prefix='module.')       # checkpoints written under DDP
+    full = model.state_dict()
+    full.update(state)
+    model.load_state_dict(full)
+
+
+def _get_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, xyz_dim: int, weight_key: str) -> nn.Module:
+    """Model selection of the reference (model_utils.py:20-54): container > cascade > jointly trained cells > single NeRF,
+    then optional weights from ``--ckpt_path`` (never for a container: it carries its own)."""
     if hparams.container_path is not None:
-        container = torch.jit.load(hparams.container_path, map_location='cpu')
-        prefix = 'sub_module_{}' if xyz_dim == 3 else 'bg_sub_module_{}'
-        subs = [nerf_from_scripted(getattr(container, prefix.format(i))) for i in range(len(container.centroids))]
-        return MegaNeRF(subs, container.centroids, hparams.boundary_margin, xyz_dim == 4, container.cluster_2d)
-    elif hparams.use_cascade:
-        nerf = Cascade(_get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim),
-                       _get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim))
+        return _from_container(hparams, xyz_dim)
+
+    def single() -> NeRF:
+        return _get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim)
+
+    if hparams.use_cascade:
+        model: nn.Module = Cascade(single(), single())
     elif hparams.train_mega_nerf is not None:
-        meta = torch.load(hparams.train_mega_nerf, map_location='cpu', weights_only=False)
-        centroids = meta['centroids']
-        nerf = MegaNeRF([_get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim)
-                         for _ in range(len(centroids))], centroids, 1, xyz_dim == 4, meta['cluster_2d'], True)
+        clustering = torch.load(hparams.train_mega_nerf, map_location='cpu', weights_only=False)
+        model = MegaNeRF([single() for _ in clustering['centroids']], clustering['centroids'], 1, _branch_of(xyz_dim) == 'bg',
+                         clustering['cluster_2d'], True)
     else:
-        nerf = _get_single_nerf_inner(hparams, appearance_count, layer_dim, xyz_dim)
-
+        model = single()
     if hparams.ckpt_path is not None:
-        state_dict = torch.load(hparams.ckpt_path, map_location='cpu', weights_only=False)[weight_key]
-        consume_prefix_in_state_dict_if_present(state_dict, prefix='module.')
-        merged = nerf.state_dict()
-        merged.update(state_dict)
-        nerf.load_state_dict(merged)
-    return nerf
+        _load_weights(model, hparams.ckpt_path, weight_key)
+    return model
 
 
-def _get_single_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, xyz_dim: int) -> nn.Module:
-    rgb_dim = 3 * ((hparams.sh_deg + 1) ** 2) if hparams.sh_deg is not None else 3
-    return NeRF(hparams.pos_xyz_dim, hparams.pos_dir_dim, hparams.layers, hparams.skip_layers, layer_dim,
-                hparams.appearance_dim, hparams.affine_appearance, appearance_count, rgb_dim, xyz_dim,
-                ShiftedSoftplus() if hparams.shifted_softplus else nn.ReLU())
+def _get_single_nerf_inner(hparams: Namespace, appearance_count: int, layer_dim: int, xyz_dim: int) -> NeRF:
+    colour_outputs = 3 if hparams.sh_deg is None else 3 * (hparams.sh_deg + 1) ** 2
+    density_activation = ShiftedSoftplus() if hparams.shifted_softplus else nn.ReLU()
+    return NeRF(pos_xyz_dim=hparams.pos_xyz_dim, pos_dir_dim=hparams.pos_dir_dim, layers=hparams.layers,
+                skip_layers=hparams.skip_layers, layer_dim=layer_dim, appearance_dim=hparams.appearance_dim,
+                affine_appearance=hparams.affine_appearance, appearance_count=appearance_count, rgb_dim=colour_outputs,
+                xyz_dim=xyz_dim, sigma_activation=density_activation)

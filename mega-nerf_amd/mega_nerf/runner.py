@@ -349,3 +349,21 @@ class Runner:
         exp_dir.mkdir(parents=True, exist_ok=True)
         versions = [int(x.name) for x in exp_dir.iterdir() if x.name.isdigit()]
         return exp_dir / str(0 if not versions else max(versions) + 1)
+
+
+# ---- command-line entry shared by train.py and eval.py ------------------------------------------------------------
+def cli_options(argv: Optional[List[str]] = None) -> Namespace:
+    """The reference's train/eval flag set: opts.get_opts_base() plus --exp_name and --dataset_path."""
+    from mega_nerf.opts import get_opts_base
+    parser = get_opts_base()
+    for flag, text in (('--exp_name', 'experiment name'), ('--dataset_path', 'dataset root (train/, val/, coordinates.pt)')):
+        parser.add_argument(flag, type=str, required=True, help=text)
+    return parser.parse_args(argv)
+
+
+def run_cli(hparams: Namespace, action: str) -> None:
+    """Run ``Runner(hparams).train()`` / ``.eval()``, under autograd anomaly detection when --detect_anomalies is set."""
+    from contextlib import nullcontext
+    guard = torch.autograd.detect_anomaly() if hparams.detect_anomalies else nullcontext()
+    with guard:
+        getattr(Runner(hparams), action)()

@@ -1,25 +1,16 @@
-"""``python -m mega_nerf.train --config_file ... --exp_name ... --dataset_path ...`` (reference: mega_nerf/train.py)."""
+"""Training entry point: ``python -m mega_nerf.train --config_file ... --exp_name ... --dataset_path ...``.
+Same flags and behaviour as the reference's mega_nerf/train.py; both entry points share mega_nerf.runner.run_cli."""
 from argparse import Namespace
 
-import torch
-
-from mega_nerf.opts import get_opts_base
-from mega_nerf.runner import Runner
+from mega_nerf.runner import cli_options, run_cli
 
 
 def _get_train_opts() -> Namespace:
-    parser = get_opts_base()
-    parser.add_argument('--exp_name', type=str, required=True, help='experiment name')
-    parser.add_argument('--dataset_path', type=str, required=True)
-    return parser.parse_args()
+    return cli_options()
 
 
 def main(hparams: Namespace) -> None:
-    if hparams.detect_anomalies:
-        with torch.autograd.detect_anomaly():
-            Runner(hparams).train()
-    else:
-        Runner(hparams).train()
+    run_cli(hparams, 'train')
 
 
 if __name__ == '__main__':
