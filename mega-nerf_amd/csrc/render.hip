@@ -795,6 +795,36 @@ __global__ void k_route_accumulate(float *__restrict__ out, long out_stride, con
     }
 }
 
+// ---- one-pass blend of all cells (replaces n_sub k_route_accumulate launches) ----------------------------------------
+// pos[i][row] = index of `row` in cell i's compact list (or -1): the inverse of the lists k_route appended
+__global__ void k_route_invert(int32_t *__restrict__ pos, const int32_t *__restrict__ lists, const int32_t *__restrict__ counts,
+                               long B, int n_sub) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / B);
+    const long k = t % B;
+    if (i >= n_sub || k >= counts[i]) return;
+    pos[(long)i * B + lists[(long)i * B + k]] = (int32_t)k;
+}
+// out[row] = sum over the cells in index order of w_i[row] * sub_i[pos_i[row]]  (same order and roundings as applying
+// k_route_accumulate cell after cell to a zeroed output: mega_nerf.py:43-49)
+__global__ void k_route_combine(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long cell_stride,
+                                long sub_stride, int n_cols, const int32_t *__restrict__ pos, const float *__restrict__ weights,
+                                int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit) {
+    const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    float acc[32];
+    for (int c = 0; c < n_cols; ++c) acc[c] = 0.f;
+    for (int i = 0; i < n_sub; ++i) {
+        const int32_t p = pos[(long)i * B + row];
+        if (p < 0) continue;
+        const float w = weights ? weights[(long)i * B + row] : 1.f;
+        const float *src = sub + i * cell_stride + p * sub_stride;
+        for (int c = 0; c < n_cols; ++c) acc[c] = acc[c] + src[c] * w;
+    }
+    for (int c = 0; c < n_cols; ++c) out[row * out_stride + c] = acc[c];
+}
+
 }  // namespace mnr
 
 extern "C" int mnr_route(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
@@ -824,4 +854,22 @@ extern "C" int mnr_route_accumulate(float *out, int64_t out_stride, const float 
     hipLaunchKernelGGL(k_route_accumulate, dim3(nblk(B_max, 256)), dim3(256), 0, as_stream(stream), out, (long)out_stride, sub,
                        (long)sub_stride, n_cols, list, count, weights, assign);
     return check_launch("k_route_accumulate");
+}
+
+extern "C" int mnr_route_combine(float *out, int64_t out_stride, const float *sub_all, int64_t cell_stride, int64_t sub_stride,
+                                 int n_cols, const int32_t *lists, const int32_t *counts, const float *weights, int n_sub, int64_t B,
+                                 const int32_t *n_dev, int rows_per_unit, int32_t *pos_scratch, void *stream) {
+    MNR_REQUIRE(out && sub_all && lists && counts && pos_scratch && n_cols > 0 && n_cols <= 32 && B >= 0,
+                "bad arguments to mnr_route_combine");
+    MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
+    if (B == 0) return MNR_OK;
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(pos_scratch, 0xFF, sizeof(int32_t) * (size_t)n_sub * (size_t)B, s) != hipSuccess)
+        return set_err(MNR_E_LAUNCH, "hipMemsetAsync(pos)");
+    hipLaunchKernelGGL(k_route_invert, dim3(nblk((long)n_sub * B, 256)), dim3(256), 0, s, pos_scratch, lists, counts, (long)B, n_sub);
+    int rc = check_launch("k_route_invert");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_route_combine, dim3(nblk(B, 256)), dim3(256), 0, s, out, (long)out_stride, sub_all, (long)cell_stride,
+                       (long)sub_stride, n_cols, pos_scratch, weights, n_sub, (long)B, n_dev, rows_per_unit);
+    return check_launch("k_route_combine");
 }

@@ -95,7 +95,7 @@ EXPORTS = [
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
     'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
-    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells',
+    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -161,6 +161,8 @@ def lib() -> C.CDLL:
         _lib.mnr_route_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib.mnr_fused_supported.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_route_combine.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.mnr_mlp_forward_cells.argtypes = [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.POINTER(MlpIO), C.c_void_p]
         _lib.mnr_fused_train_supported.argtypes = [C.POINTER(ModelDesc)]
         _lib.mnr_embed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]

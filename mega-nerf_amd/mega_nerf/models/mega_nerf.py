@@ -80,10 +80,10 @@ class MegaNeRF(nn.Module):
             io.sigma_only = 1 if sigma_only else 0
             io.apply_sh_deg = sh_deg
             N.check(lib.mnr_mlp_forward_cells(C.byref(desc), cells.data_ptr(), n_sub, C.byref(io), N.stream_ptr()))
-            for i in range(n_sub):
-                N.check(lib.mnr_route_accumulate(out.data_ptr(), ncol, sub_out[i].data_ptr(), ncol, ncol, lists[i].data_ptr(),
-                                                 counts[i:i + 1].data_ptr(), B, weights[i].data_ptr() if blend else None,
-                                                 0 if blend else 1, N.stream_ptr()))
+            pos_scratch = torch.empty(n_sub, B, device=dev, dtype=torch.int32)
+            N.check(lib.mnr_route_combine(out.data_ptr(), ncol, sub_out.data_ptr(), B * ncol, ncol, ncol, lists.data_ptr(),
+                                          counts.data_ptr(), weights.data_ptr() if blend else None, n_sub, B, N.ptr(n_units),
+                                          rows_per_unit, pos_scratch.data_ptr(), N.stream_ptr()))
             return
         sub_out = torch.empty(B, ncol, device=dev, dtype=torch.float32)
         for i, child in enumerate(self.sub_modules):
