@@ -19,6 +19,21 @@ def _arch_key(m):
             m.appearance_count, m.rgb_dim, type(m.sigma_activation).__name__, m.mfma_tile)
 
 
+class RoutedTape:
+    """Tapes of one routed training evaluation: per cell (parameter prefix, cell tape, routed rows, blend weights)."""
+
+    def __init__(self):
+        self.cells = []
+
+    def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: dict) -> None:
+        d2 = d_out.view(-1, d_out_stride)
+        for prefix, cell_tape, rows, w, _keepalive in self.cells:
+            d_sub = d2.index_select(0, rows)
+            if w is not None:
+                d_sub = d_sub * w[:, None]
+            cell_tape.backward(d_sub.contiguous(), d_sub.shape[1], {k[len(prefix):]: v for k, v in grads.items() if k.startswith(prefix)})
+
+
 class MegaNeRF(nn.Module):
     def __init__(self, sub_modules: List[nn.Module], centroids: torch.Tensor, boundary_margin: float, xyz_real: bool,
                  cluster_2d: bool, joint_training: bool = False):
@@ -123,6 +138,54 @@ class MegaNeRF(nn.Module):
             i2 = torch.as_strided(idx, (n_rays,), (idx_stride,), idx.storage_offset()).index_select(0, rays)
         n2 = noise.index_select(0, rows) if noise is not None else None
         child.evaluate(x2, child.xyz_dim, d2, 3, i2, 1, 1, cnt, sub_out, n2, sigma_only, sh_deg)
+
+    def train_eval_routed(self, xyz: torch.Tensor, part, S: int, out: torch.Tensor, noise, sh_deg: int) -> 'RoutedTape':
+        """Training-mode twin of :meth:`evaluate_routed` (``--train_mega_nerf``: all cells trained in one process,
+        mega_nerf.py:28-59): rows are routed on the device, every cell evaluates its gathered rows with its own tape
+        (``NeRF.train_eval``), and the tape of the whole evaluation replays the cells backwards.  Sizes its per-cell
+        launches on the host (one read of the row counts per evaluation)."""
+        lib = N.lib()
+        dev = out.device
+        n, ncol_in = xyz.shape[0], xyz.shape[-1]
+        B, n_sub = n * S, len(self.sub_modules)
+        if part.n_units is not None:
+            B = min(B, int(part.n_units.item()) * S)
+        flat = xyz.view(-1, ncol_in)
+        out2 = out.view(-1, out.shape[-1])
+        tape = RoutedTape()
+        if B == 0:
+            return tape
+        weights = torch.empty(n_sub, B, device=dev, dtype=torch.float32)
+        lists = torch.empty(n_sub, B, device=dev, dtype=torch.int32)
+        counts = torch.empty(n_sub, device=dev, dtype=torch.int32)
+        N.check(lib.mnr_route(flat.data_ptr(), ncol_in, B, None, 0, self._centroids_host(), n_sub, self.cluster_dim_start,
+                              float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(), counts.data_ptr(), N.stream_ptr()))
+        host_counts = counts.cpu().tolist()
+        out2[:B].zero_()
+        blend = self.boundary_margin > 1
+        x_in = flat[:, 3:] if self.xyz_real else flat
+        for i, child in enumerate(self.sub_modules):
+            cnt = host_counts[i]
+            if cnt == 0:
+                continue
+            rows = lists[i, :cnt].long()
+            rays = rows // S
+            xi = x_in.index_select(0, rows).contiguous()
+            dirs_i = idx_i = None
+            if child.has_dir and child.embedding_a is None:              # quirk Q8 (nerf.py:146)
+                dirs_i = torch.cat([xi[:, -1:], part.dirs.index_select(0, rays)[:, :2]], -1).contiguous()
+            elif child.has_dir or sh_deg >= 0:
+                dirs_i = part.dirs.index_select(0, rays).contiguous()
+            if child.embedding_a is not None:
+                idx_i = part.idx.index_select(0, rays).contiguous()
+            noise_i = noise.index_select(0, rows) if noise is not None else None
+            sub = torch.empty(cnt, out2.shape[1], device=dev, dtype=torch.float32)
+            cell_tape = child.train_eval(xi, xi.shape[1], dirs_i if child.has_dir else None, 3, 1, idx_i, 1, 1, cnt, sub, noise_i,
+                                         sh_deg, None, 0, dirs_i if sh_deg >= 0 else None, 3)
+            w = weights[i].index_select(0, rows) if blend else None
+            out2.index_add_(0, rows, sub * w[:, None] if blend else sub)
+            tape.cells.append(('sub_modules.%d.' % i, cell_tape, rows, w, (xi, dirs_i, idx_i, noise_i, sub)))
+        return tape
 
     def evaluate_routed(self, xyz: torch.Tensor, part, S: int, out: torch.Tensor, noise, sh_deg: int):
         """Render-path entry: xyz [n, S, 3] (fg) or [n, S, 7] = [xyz_real | sphere point | 1/r] (bg, quirk Q15);

@@ -14,8 +14,9 @@ Two implementations share the stage kernels:
     (``NeRF.train_eval``: fused kernels where they exist, else the layer-by-layer GEMM path), outputs
     ``rgb_fine`` and, with cascade, ``rgb_coarse``.
 Importance-sampling weights are detached exactly as in the reference (rendering.py:215), so gradients reach the
-MLP only through the compositing of ``rgb_*``.  Joint training of a routed MegaNeRF (``--train_mega_nerf``) is not
-covered (the per-submodule pipeline trains single models).
+MLP only through the compositing of ``rgb_*``.  ``--train_mega_nerf`` (all cells of a MegaNeRF trained in one process,
+rows routed hard to the nearest centroid) goes through the general path with per-cell tapes
+(``MegaNeRF.train_eval_routed``).
 """
 from __future__ import annotations
 
@@ -313,12 +314,12 @@ def _train_model_eval(nerf, typ: str, hparams: Namespace, xyz: torch.Tensor, par
     model, prefix = nerf, ''
     if isinstance(model, Cascade):
         model, prefix = (model.coarse, 'coarse.') if typ == 'coarse' else (model.fine, 'fine.')
-    if isinstance(model, MegaNeRF):
-        raise NotImplementedError('joint training of a routed MegaNeRF (--train_mega_nerf / container) is not covered by the '
-                                  'MI355X training path; train the submodules separately')
     n = xyz.shape[0]
     out = _f(n, S, 4, device=xyz.device)
     sh_deg = hparams.sh_deg if (hparams.pos_dir_dim == 0 and hparams.sh_deg is not None) else -1
+    if isinstance(model, MegaNeRF):
+        # --train_mega_nerf: every cell trained in this process, rows routed hard to their nearest centroid
+        return out, model.train_eval_routed(xyz, part, S, out, noise, sh_deg), prefix
     if model.has_dir and model.embedding_a is None:
         # quirk Q8 (nerf.py:146): the encoded "direction" is [last xyz coordinate, d_x, d_y] of every sample
         d = part.dirs.view(n, 1, 3).expand(n, S, 3)
@@ -573,9 +574,9 @@ def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
                       image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
                       get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
     """Differentiable render (training flags of runner.py:349-358).  Returns (results, n_bg_dev, err_dev)."""
-    if hparams.container_path is not None or getattr(hparams, 'train_mega_nerf', None) is not None:
-        raise NotImplementedError('the MI355X training path trains single (optionally cascaded) NeRFs per branch; '
-                                  'routed MegaNeRF containers are inference-only')
+    if hparams.container_path is not None:
+        raise NotImplementedError('merged containers are inference-only (rendering.py never trains one either: '
+                                  'model_utils.py:22-29 loads them as frozen TorchScript)')
     if get_depth or get_bg_fg_rgb:
         raise NotImplementedError('training render returns rgb / depth_variance / bg_lambda only')
     rnd = _randoms if _randoms is not None else {}

@@ -239,7 +239,7 @@ def gen_mlp():
 
 
 def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train=False, cascade=False,
-               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256):
+               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256, joint=False):
     s = common.SCENE
     hp = Namespace(**vars(make_hparams(layer_dim=layer_dim, bg_layer_dim=bg_layer_dim, **hp_kw)))
     rays, idx = common.pick_rays(all_rays, N, seed)
@@ -256,8 +256,12 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
         extra['centroids'] = cent
         subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
         bsubs = [ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500 + i), A) for i in range(n_sub)]
-        nerf = MegaNeRF(subs, T(cent), hp.boundary_margin, False, False)
-        bg_nerf = MegaNeRF(bsubs, T(cent), hp.boundary_margin, True, False)
+        if joint:        # --train_mega_nerf: model_utils.py:37-42 (hard routing, joint_training flag)
+            nerf = MegaNeRF(subs, T(cent), 1, False, False, True)
+            bg_nerf = MegaNeRF(bsubs, T(cent), 1, True, False, True)
+        else:
+            nerf = MegaNeRF(subs, T(cent), hp.boundary_margin, False, False)
+            bg_nerf = MegaNeRF(bsubs, T(cent), hp.boundary_margin, True, False)
     elif cascade:
         nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
                        ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
@@ -346,6 +350,8 @@ def main(only=None):
     case('render_noapp_train', dict(base, appearance_dim=0, shifted_softplus=False), 32, 14, TR, fg_train=True, bg_train=True,
          with_grad=True, layer_dim=128, bg_layer_dim=128)
     case('render_noapp256_train', dict(base, appearance_dim=0), 32, 16, TR, fg_train=True, bg_train=True, with_grad=True)
+    case('render_joint_train', dict(base, train_mega_nerf='dummy'), 32, 17, TR, container=4, joint=True, fg_train=True, bg_train=True,
+         with_grad=True, layer_dim=64, bg_layer_dim=64)
     case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
          bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
 

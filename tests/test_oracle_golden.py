@@ -132,6 +132,8 @@ RENDER_CASES = {
     'render_noapp_train': dict(hp=dict(appearance_dim=0, shifted_softplus=False, layer_dim=128, bg_layer_dim=128), seed=14,
                                fg_train=True, bg_train=True),
     'render_noapp256_train': dict(hp=dict(appearance_dim=0), seed=16, fg_train=True, bg_train=True),
+    'render_joint_train': dict(hp=dict(train_mega_nerf='dummy', layer_dim=64, bg_layer_dim=64), seed=17, container=4, joint=True,
+                               fg_train=True, bg_train=True),
     'render_nerf_cfg_train': dict(hp=dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0, layer_dim=160),
                                   seed=15, bg=False, cascade=True, fg_train=True),
 }
@@ -153,10 +155,11 @@ def build_case(name):
         n = c['container']
         g = load(name)
         cent = g['centroids']
+        margin = 1.0 if c.get('joint') else hp.boundary_margin          # --train_mega_nerf routes hard (model_utils.py:37-42)
         nerf = O.Model(fcfg, subs=[common.make_weights(fcfg, A, seed * 1000 + i) for i in range(n)], centroids=cent,
-                       boundary_margin=hp.boundary_margin, xyz_real=False, training=ft)
+                       boundary_margin=margin, xyz_real=False, training=ft)
         bg_nerf = O.Model(bcfg, subs=[common.make_weights(bcfg, A, seed * 1000 + 500 + i) for i in range(n)],
-                          centroids=cent, boundary_margin=hp.boundary_margin, xyz_real=True, training=bt)
+                          centroids=cent, boundary_margin=margin, xyz_real=True, training=bt)
     elif c.get('cascade'):
         nerf = O.Model(fcfg, cascade=(common.make_weights(fcfg, A, seed * 1000),
                                       common.make_weights(fcfg, A, seed * 1000 + 1)), training=ft)
