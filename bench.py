@@ -22,8 +22,10 @@ import time
 from argparse import Namespace
 from pathlib import Path
 
-import numpy as np
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: required for RCCL across processes on this host driver
+
+import numpy as np    # noqa: E402
+import torch          # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT, ROOT / 'mega-nerf_amd', ROOT / 'tests', ROOT / 'tests' / 'golden'):
@@ -135,7 +137,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')            # RCCL on ROCm
+        dist.init_process_group('nccl', device_id=dev)            # RCCL on ROCm, communicator bound to this rank's GPU
     assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
 
     import common                      # tests/golden/common.py: the seeded scene / weight generator (no oracle code)
