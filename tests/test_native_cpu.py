@@ -73,3 +73,25 @@ def test_product_path_refuses_cpu_tensors():
         ray_utils.get_ray_directions(4, 4, 1., 1., 2., 2., True, torch.device('cpu'))
     with pytest.raises(Exception, match='Unexpected input shape'):
         m(torch.zeros(4, 5))
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """sizeof() of every structure in include/mnr_api.h, as a plain C compiler sees it, equals the ctypes mirror's
+    (a field missing on either side would make the library read garbage)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from mega_nerf import _native as N
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    names = {'mnr_model_desc': N.ModelDesc, 'mnr_mlp_io': N.MlpIO, 'mnr_composite_io': N.CompositeIO, 'mnr_model_grads': N.ModelGrads,
+             'mnr_mlp_grad_io': N.MlpGradIO, 'mnr_composite_grad_io': N.CompositeGradIO}
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "mnr_api.h"\nint main(void) {\n' +
+                   ''.join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in list(names) + ['mnr_mlp_cell']) + '  return 0;\n}\n')
+    exe = tmp_path / 'sizes'
+    subprocess.run(['gcc', '-std=c99', '-I', str(ROOT / 'include'), str(src), '-o', str(exe)], check=True)
+    sizes = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n, cls in names.items():
+        assert int(sizes[n]) == ctypes.sizeof(cls), (n, sizes[n], ctypes.sizeof(cls))
+    assert int(sizes['mnr_mlp_cell']) == 5 * 8            # MegaNeRF._routed packs cells as rows of five int64
