@@ -223,7 +223,15 @@ typedef struct mnr_mlp_grad_io {
     const int32_t *n_units_dev;  int32_t rows_per_unit;
     int32_t *work_counter;       /* scratch: one device int32 (item queue head of the weight-gradient launch) */
     mnr_model_grads grad;
+    const float *dd_in;          /* models whose colour head is not 3 sigmoid outputs (spherical harmonics, rgb_dim > 3):
+                                    dL/d(output of dir_a_encoding) [n_rows][layer_dim/2], produced by the caller from the
+                                    colour epilogue (mnr_sh_backward) and the rgb layer (mnr_gemm); the chain then starts
+                                    there and the rgb.* gradients are the caller's.  NULL for rgb_dim == 3. */
 } mnr_mlp_grad_io;
+
+/* Offset (in floats per row; plane base = tape + offset * tape_rows) of a tape plane: which = 0: post-ReLU output of
+ * dir_a_encoding (width layer_dim/2), 1: output of xyz_encoding_final, 2: post-ReLU output of the last trunk layer.  < 0 on error. */
+int64_t mnr_tape_plane_offset(const mnr_model_desc *desc, int which);
 
 /* Backward, step 1: data-gradient chain (fused, register-chained like the forward) for the rows of one
  * forward pass; fills gtape / dheads rows [tape_row0, tape_row0 + n_rows) and accumulates the appearance

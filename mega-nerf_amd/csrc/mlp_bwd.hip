@@ -81,6 +81,7 @@ struct MlpBwdArgs {
     long n_rows;
     const int32_t *n_units_dev;  int rows_per_unit;
     long tape_row0;                // tape / gradient-tape row of this launch's row 0
+    const float *dd_in;            // rgb_dim != 3: dL/d(dir_a output) [n_rows][W/2] supplied by the caller (see mnr_mlp_grad_io)
 };
 
 // ReLU masks: the forward pass left the sign bits of every activation packed per lane (TapeLayout mask planes), so a
@@ -125,7 +126,7 @@ __device__ __forceinline__ void zero_acc(AccT (&acc)[NOB]) {
 template <class C>
 __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_bwd(MlpBwdArgs a) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB, H2 = C::H2, W = C::W;
-    static_assert(C::HAS_FINAL && C::RGB == 3, "backward kernel covers the dir/appearance architecture");
+    static_assert(C::HAS_FINAL, "backward kernel covers the dir/appearance architecture");
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
     // dir_a^T produces W final-feature rows + APP appearance rows, padded to a multiple of 4 blocks
     constexpr int ROWS_D = cdiv(W + C::APP, 4 * TILE) * 4 * TILE, NOBD = ROWS_D / TILE;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     {
         const float *go = a.d_out + rc * a.d_out_stride, *o = a.out + rc * a.out_stride;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dr[c] = valid ? go[c] * o[c] * (1.f - o[c]) : 0.f;        // sigmoid'
+        for (int c = 0; c < 3; ++c) dr[c] = (valid && C::RGB == 3) ? go[c] * o[c] * (1.f - o[c]) : 0.f;        // sigmoid'
         const float sg = o[3];
         const float da = a.sigma_act ? (1.f - expf(-sg)) : (sg > 0.f ? 1.f : 0.f);           // softplus' = 1 - e^-softplus
         ds = valid ? go[3] * da : 0.f;
@@ -163,17 +164,28 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     // ---- rgb head backward -> dZ of dir_a ---------------------------------------------------------
     float dd[H2];
     {
-        const float *wr = a.aux + a.rgb_off;
+        if constexpr (C::RGB == 3) {
+            const float *wr = a.aux + a.rgb_off;
 #pragma unroll
-        for (int q = 0; q < H2 / 4; ++q) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < H2 / 4; ++q) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H2 + 4 * q);
-                s.x = fmaf(dr[c], w4.x, s.x); s.y = fmaf(dr[c], w4.y, s.y);
-                s.z = fmaf(dr[c], w4.z, s.z); s.w = fmaf(dr[c], w4.w, s.w);
+                for (int c = 0; c < 3; ++c) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H2 + 4 * q);
+                    s.x = fmaf(dr[c], w4.x, s.x); s.y = fmaf(dr[c], w4.y, s.y);
+                    s.z = fmaf(dr[c], w4.z, s.z); s.w = fmaf(dr[c], w4.w, s.w);
+                }
+                dd[4 * q] = s.x; dd[4 * q + 1] = s.y; dd[4 * q + 2] = s.z; dd[4 * q + 3] = s.w;
             }
-            dd[4 * q] = s.x; dd[4 * q + 1] = s.y; dd[4 * q + 2] = s.z; dd[4 * q + 3] = s.w;
+        } else {
+            // colour epilogue + rgb layer were differentiated by the caller: pick up dL/d(dir_a output) in C layout
+            const float *src = a.dd_in + rc * (W / 2) + 4 * part;
+#pragma unroll
+            for (int q = 0; q < H2 / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + 4 * P * q);
+                dd[4 * q] = valid ? v.x : 0.f; dd[4 * q + 1] = valid ? v.y : 0.f;
+                dd[4 * q + 2] = valid ? v.z : 0.f; dd[4 * q + 3] = valid ? v.w : 0.f;
+            }
         }
         const MaskBits<H2> dm = mask_load<H2>(a.tape + a.tl.dmask_off * cap, trow, a.tl.dmask_w, part);
         mask_apply(dd, dm);
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
                                                     const float *__restrict__ dact, int W2, long row0, long n_rows,
                                                     const int32_t *__restrict__ n_units_dev, int rows_per_unit,
                                                     float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
-                                                    float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b) {
+                                                    float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb) {
     const long n = n_units_dev ? (long)(*n_units_dev) * rows_per_unit : n_rows;
     const long per = (n + gridDim.x - 1) / gridDim.x;
     const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
             atomicAdd(d_sigma_w + f, (s0 + s1) + (s2 + s3));
         }
     }
-    for (int f0 = 0; f0 < W2; f0 += 256) {                 // rgb head
+    for (int f0 = 0; with_rgb && f0 < W2; f0 += 256) {     // rgb head (3 sigmoid outputs; other heads: the caller's GEMMs)
         const int f = f0 + t;
         if (f < W2) {
             float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
             atomicAdd(d_rgb_w + 2 * W2 + f, s[0][2] + s[1][2]);
         }
     }
-    if (t < 4) {                                           // biases
+    if (t < 4 && (with_rgb || t == 3)) {                   // biases
         float s = 0.f;
         for (long r = r0; r < r1; ++r) s += dheads[r * 4 + t];
         atomicAdd(t < 3 ? d_rgb_b + t : d_sigma_b, s);
@@ -576,6 +588,8 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     a.rows_per_ray = io->rows_per_ray; a.app_count = d->appearance_count; a.sigma_act = d->sigma_activation;
     a.n_rows = io->n_rows; a.n_units_dev = io->n_units_dev; a.rows_per_unit = io->rows_per_unit;
     a.tape_row0 = io->tape_row0;
+    a.dd_in = io->dd_in;
+    MNR_REQUIRE(d->rgb_dim == 3 || io->dd_in, "rgb_dim != 3: dd_in (gradient at the dir_a output) is required");
     rc = MNR_E_UNSUPPORTED;
 #define MNR_TRY_B(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                      \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&        \
@@ -586,6 +600,8 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 #ifdef MNR_ALL_VARIANTS
     MNR_TRY_B(3, 12, 4, 0, 256, 8, 16, 3, 16)         // configs/mega-nerf-no-embed
     MNR_TRY_B(4, 12, 4, 0, 256, 8, 16, 3, 16)
+    MNR_TRY_B(3, 12, 0, 48, 256, 8, 16, 27, 16)       // configs/mega-nerf-sh-3
+    MNR_TRY_B(4, 12, 0, 48, 256, 8, 16, 27, 16)
 #endif
 #undef MNR_TRY_B
     if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "
@@ -599,7 +615,7 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     const int W = d->layer_dim;
     hipLaunchKernelGGL(k_head_grads, dim3(1024), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
                        io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
-                       io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b);
+                       io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b, d->rgb_dim == 3 ? 1 : 0);
     return check_launch("k_head_grads");
 }
 

@@ -379,6 +379,18 @@ extern "C" int64_t mnr_tape_floats_per_row(const mnr_model_desc *d) {
                                 d->appearance_dim, d->rgb_dim, d->mfma_tile}).floats_per_row;
 }
 
+extern "C" int64_t mnr_tape_plane_offset(const mnr_model_desc *d, int which) {
+    ModelLayout m;
+    if (layout_from_desc(d, m) != MNR_OK) return -1;
+    const TapeLayout t = tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
+                                              d->appearance_dim, d->rgb_dim, d->mfma_tile});
+    if (which == 0) return t.dact_off;
+    if (which == 1) return t.fin_off;
+    if (which == 2) return t.act_off[d->layers - 1];
+    set_err(MNR_E_INVALID, "unknown tape plane %d", which);
+    return -1;
+}
+
 static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
                             float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells, int n_cells) {
     ModelLayout m;
@@ -411,6 +423,8 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
 #ifdef MNR_ALL_VARIANTS
     MNR_TRY_TRAIN(3, 12, 4, 0, 256, 8, 16, 3, 16)     // configs/mega-nerf-no-embed
     MNR_TRY_TRAIN(4, 12, 4, 0, 256, 8, 16, 3, 16)
+    MNR_TRY_TRAIN(3, 12, 0, 48, 256, 8, 16, 27, 16)   // configs/mega-nerf-sh-3 (colour epilogue + rgb layer adjoint: caller)
+    MNR_TRY_TRAIN(4, 12, 0, 48, 256, 8, 16, 27, 16)
 #endif
     // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
     MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)

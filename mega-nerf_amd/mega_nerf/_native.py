@@ -76,7 +76,7 @@ class MlpGradIO(C.Structure):
                 ('d_out', C.c_void_p), ('d_out_stride', C.c_int64), ('out', C.c_void_p), ('out_stride', C.c_int64),
                 ('dheads', C.c_void_p), ('idx', C.c_void_p), ('idx_stride', C.c_int64), ('idx_is_float', C.c_int32),
                 ('rows_per_ray', C.c_int32), ('n_rows', C.c_int64), ('n_units_dev', C.c_void_p),
-                ('rows_per_unit', C.c_int32), ('work_counter', C.c_void_p), ('grad', ModelGrads)]
+                ('rows_per_unit', C.c_int32), ('work_counter', C.c_void_p), ('grad', ModelGrads), ('dd_in', C.c_void_p)]
 
 
 class CompositeGradIO(C.Structure):
@@ -95,7 +95,7 @@ EXPORTS = [
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
     'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
-    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine',
+    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -145,6 +145,8 @@ def lib() -> C.CDLL:
         _lib.mnr_bg_blend.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_void_p] * 5
         _lib.mnr_tape_floats_per_row.restype = C.c_int64
         _lib.mnr_tape_floats_per_row.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_tape_plane_offset.restype = C.c_int64
+        _lib.mnr_tape_plane_offset.argtypes = [C.POINTER(ModelDesc), C.c_int]
         _lib.mnr_mlp_forward_train.argtypes = [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(MlpIO), C.c_void_p, C.c_int64,
                                                C.c_int64, C.c_void_p]
         _lib.mnr_packed_bwd_bytes.restype = C.c_size_t

@@ -45,17 +45,43 @@ class NullTape:
 
 class FusedTape:
     """One fused training-mode MLP launch (activation tape in HBM) and its hand-written adjoint
-    (csrc/mlp_fwd.hip TRAIN variants, csrc/mlp_bwd.hip)."""
+    (csrc/mlp_fwd.hip TRAIN variants, csrc/mlp_bwd.hip).  Spherical-harmonics models (rgb_dim > 3, ``sh_deg`` >= 0): the
+    colour epilogue and the rgb layer are differentiated here with the small stand-alone kernels (mnr_sh_backward,
+    mnr_gemm, mnr_col_sum) and the fused chain picks up at the output of dir_a_encoding (``dd_in``)."""
 
     def __init__(self, model: 'NeRF', xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
-                 sigma_noise, n_units_dev, rows_per_unit):
+                 sigma_noise, n_units_dev, rows_per_unit, sh_deg: int = -1):
         self.model, self.n_rows, self.out = model, n_rows, out
         self.idx, self.idx_stride, self.rows_per_ray = idx, idx_stride, rows_per_ray
         self.n_units_dev, self.rows_per_unit = n_units_dev, rows_per_unit
-        self.tape = torch.empty(max(n_rows, 1) * model.tape_floats_per_row(), device=out.device, dtype=torch.float32)
+        self.sh_deg, self.dirs, self.dir_stride = sh_deg, dirs, dir_stride
+        self.tape_rows = max(n_rows, 1)
+        self.tape = torch.empty(self.tape_rows * model.tape_floats_per_row(), device=out.device, dtype=torch.float32)
         io = model.mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out, sigma_noise,
                           n_units_dev, rows_per_unit)
-        model.evaluate_train(io, self.tape, max(n_rows, 1), 0)
+        io.apply_sh_deg = sh_deg
+        model.evaluate_train(io, self.tape, self.tape_rows, 0)
+
+    def _colour_head_backward(self, d_out: torch.Tensor, d_out_stride: int, grads: dict) -> torch.Tensor:
+        """SH models: d_out -> (rgb.* gradients, dL/d(dir_a output) [n_rows][W/2])."""
+        m, dev, lib, st = self.model, d_out.device, N.lib(), N.stream_ptr
+        rows = self.n_rows if self.n_units_dev is None else min(self.n_rows, int(self.n_units_dev.item()) * self.rows_per_unit)
+        half, n_coef, C1 = m.layer_dim // 2, m.rgb_dim, m.rgb_dim + 1
+        dd = torch.zeros(self.tape_rows, half, device=dev, dtype=torch.float32)
+        if rows == 0:
+            return dd
+        d_coef = torch.empty(rows, C1, device=dev, dtype=torch.float32)
+        N.check(lib.mnr_sh_backward(d_coef.data_ptr(), C1, d_out.data_ptr(), d_out_stride, self.out.data_ptr(), self.out.stride(0),
+                                    self.dirs.data_ptr(), self.dir_stride, self.rows_per_ray, self.sh_deg, rows, st()))
+        w = m.rgb.weight
+        N.check(lib.mnr_gemm(dd.data_ptr(), half, d_coef.data_ptr(), C1, 1, w.data_ptr(), 1, w.shape[1], rows, half, n_coef, 0, 1, st()))
+        desc = m.model_desc()
+        dact = self.tape.data_ptr() + int(lib.mnr_tape_plane_offset(C.byref(desc), 0)) * self.tape_rows * 4
+        gw = grads['rgb.weight']
+        N.check(lib.mnr_gemm(gw.data_ptr(), gw.shape[1], d_coef.data_ptr(), 1, C1, dact, 1, half, n_coef, half, rows, 1, 0, st()))
+        N.check(lib.mnr_col_sum(grads['rgb.bias'].data_ptr(), d_coef.data_ptr(), C1, rows, n_coef, st()))
+        self._keep = d_coef
+        return dd
 
     def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: dict) -> None:
         m, dev = self.model, d_out.device
@@ -67,7 +93,7 @@ class FusedTape:
         dheads = torch.empty(self.n_rows, 4, device=dev, dtype=torch.float32)
         counter = torch.zeros(1, device=dev, dtype=torch.int32)
         g = N.MlpGradIO()
-        g.tape, g.gtape, g.tape_rows, g.tape_row0 = self.tape.data_ptr(), gtape.data_ptr(), self.n_rows, 0
+        g.tape, g.gtape, g.tape_rows, g.tape_row0 = self.tape.data_ptr(), gtape.data_ptr(), self.tape_rows, 0
         g.d_out, g.d_out_stride = d_out.data_ptr(), d_out_stride
         g.out, g.out_stride = self.out.data_ptr(), self.out.stride(0)
         g.dheads = dheads.data_ptr()
@@ -80,6 +106,10 @@ class FusedTape:
         g.rows_per_unit = self.rows_per_unit
         g.work_counter = counter.data_ptr()
         g.grad = m.grad_struct(grads)
+        dd = None
+        if m.rgb_dim > 3:
+            dd = self._colour_head_backward(d_out, d_out_stride, grads)
+            g.dd_in = dd.data_ptr()
         N.check(N.lib().mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(g), N.stream_ptr()))
         N.check(N.lib().mnr_mlp_backward_weights(C.byref(desc), C.byref(g), N.stream_ptr()))
 
@@ -260,7 +290,11 @@ class NeRF(nn.Module):
         """Training-mode evaluation of ``n_rows`` rows into ``out`` [n_rows, 4]; returns a tape object whose
         ``backward(d_out, grads)`` accumulates the parameter gradients (``grads``: zero-initialised tensors keyed by
         this module's parameter names).  Fused kernels when they cover the architecture, else layer by layer."""
-        if self.fused_train_supported() and sh_deg < 0 and dir_rows == rows_per_ray:
+        sh = sh_deg >= 0 and self.rgb_dim > 3
+        if self.fused_train_supported() and dir_rows == rows_per_ray and (sh or (self.rgb_dim == 3 and sh_deg < 0)):
+            if sh:       # the kernel's colour epilogue reads the ray directions through the direction input
+                return FusedTape(self, xyz, xyz_stride, sh_dirs, sh_dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
+                                 sigma_noise, n_units_dev, rows_per_unit, sh_deg)
             return FusedTape(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out, sigma_noise,
                              n_units_dev, rows_per_unit)
         from mega_nerf.models.layerwise import LayerwiseTape

@@ -349,6 +349,7 @@ def main(only=None):
          layer_dim=128, bg_layer_dim=128)
     case('render_noapp_train', dict(base, appearance_dim=0, shifted_softplus=False), 32, 14, TR, fg_train=True, bg_train=True,
          with_grad=True, layer_dim=128, bg_layer_dim=128)
+    case('render_sh2_256_train', dict(base, sh_deg=2, pos_dir_dim=0), 32, 18, TR, fg_train=True, bg_train=True, with_grad=True)
     case('render_noapp256_train', dict(base, appearance_dim=0), 32, 16, TR, fg_train=True, bg_train=True, with_grad=True)
     case('render_joint_train', dict(base, train_mega_nerf='dummy'), 32, 17, TR, container=4, joint=True, fg_train=True, bg_train=True,
          with_grad=True, layer_dim=64, bg_layer_dim=64)

@@ -66,17 +66,23 @@ LW_VARIANTS = dict(
     sh2=dict(xyz_dim=3, layer_dim=128, sh_deg=2, pos_dir_dim=0),
     w320_skip2=dict(xyz_dim=3, layer_dim=320, layers=5, skip_layers=[2]),
 )
+# architectures whose training runs on the fused register-chained kernels (tape + hand-written chain)
+FUSED_VARIANTS = dict(
+    fused_sh2=dict(xyz_dim=3, layer_dim=256, sh_deg=2, pos_dir_dim=0),
+    fused_sh2_bg=dict(xyz_dim=4, layer_dim=256, sh_deg=2, pos_dir_dim=0),
+    fused_noapp=dict(xyz_dim=4, layer_dim=256, appearance_dim=0),
+)
 
 
-@pytest.mark.parametrize('name', list(LW_VARIANTS))
+@pytest.mark.parametrize('name', list(LW_VARIANTS) + list(FUSED_VARIANTS))
 def test_layerwise_backward_against_fp64_autograd(name):
-    v = dict(LW_VARIANTS[name])
+    v = dict(LW_VARIANTS[name] if name in LW_VARIANTS else FUSED_VARIANTS[name])
     xyz_dim = v.pop('xyz_dim')
     hp = O.make_hparams(coarse_samples=64, fine_samples=128, **v)
     cfg = common.model_cfg(hp, xyz_dim, hp.layer_dim)
     w = common.make_weights(cfg, 100, 900 + len(name), sharpen=False)
     m = native_nerf(cfg, w)
-    assert not m.fused_train_supported()
+    assert m.fused_train_supported() == (name in FUSED_VARIANTS)
     rng = np.random.default_rng(5)
     S, n_ray = 12, 29
     B = S * n_ray
@@ -138,7 +144,8 @@ def test_nerf_forward_autograd_matches_fp64():
             assert err < 3e-4, (width, k, err)
 
 
-TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_noapp_train', 'render_noapp256_train',
+TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_sh2_256_train', 'render_noapp_train',
+               'render_noapp256_train',
                'render_nerf_cfg_train', 'render_joint_train']
 
 

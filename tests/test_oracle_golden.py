@@ -131,6 +131,7 @@ RENDER_CASES = {
     'render_sh2_train': dict(hp=dict(sh_deg=2, pos_dir_dim=0, layer_dim=128, bg_layer_dim=128), seed=13, fg_train=True, bg_train=True),
     'render_noapp_train': dict(hp=dict(appearance_dim=0, shifted_softplus=False, layer_dim=128, bg_layer_dim=128), seed=14,
                                fg_train=True, bg_train=True),
+    'render_sh2_256_train': dict(hp=dict(sh_deg=2, pos_dir_dim=0), seed=18, fg_train=True, bg_train=True),
     'render_noapp256_train': dict(hp=dict(appearance_dim=0), seed=16, fg_train=True, bg_train=True),
     'render_joint_train': dict(hp=dict(train_mega_nerf='dummy', layer_dim=64, bg_layer_dim=64), seed=17, container=4, joint=True,
                                fg_train=True, bg_train=True),
