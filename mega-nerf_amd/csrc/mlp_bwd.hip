@@ -478,41 +478,48 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
     if (rb >= re) return;
     const long r0 = row0 + rb, r1 = row0 + re;
     const int t = threadIdx.x;
-    // 4 independent accumulators per output so that 4 row loads are in flight per thread (latency-bound otherwise)
-    for (int f0 = 0; f0 < W; f0 += 256) {                  // sigma head: thread t <-> feature f0 + t
-        const int f = f0 + t;
-        if (f < W) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            long r = r0;
-            for (; r + 3 < r1; r += 4) {
-                s0 = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s0);
-                s1 = fmaf(dheads[(r + 1) * 4 + 3], a_last[(r + 1) * W + f], s1);
-                s2 = fmaf(dheads[(r + 2) * 4 + 3], a_last[(r + 2) * W + f], s2);
-                s3 = fmaf(dheads[(r + 3) * 4 + 3], a_last[(r + 3) * W + f], s3);
+    // One pass over the rows, 8 at a time with every load issued before the first use (the kernel is pure streaming:
+    // 1.5 KB per row, latency-bound unless many loads are in flight).  Thread t owns sigma-head feature t (W == 256 ==
+    // blockDim) and rgb-head feature t & 127 for the rows of parity t >> 7 (W2 == 128).
+    const int f2 = t & (W2 - 1), par = t >> 7;
+    float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sr[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    long r = r0;
+    for (; r + 7 < r1; r += 8) {
+        float al[8], hs[8], da[4];
+        float4 h4[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { al[j] = a_last[(r + j) * W + t]; hs[j] = dheads[(r + j) * 4 + 3]; }
+        if (with_rgb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long row = r + 2 * j + par;
+                da[j] = dact[row * W2 + f2];
+                h4[j] = *reinterpret_cast<const float4 *>(dheads + row * 4);
             }
-            for (; r < r1; ++r) s0 = fmaf(dheads[r * 4 + 3], a_last[r * W + f], s0);
-            atomicAdd(d_sigma_w + f, (s0 + s1) + (s2 + s3));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss[j] = fmaf(hs[j], al[j], ss[j]);
+        if (with_rgb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sr[j][0] = fmaf(h4[j].x, da[j], sr[j][0]); sr[j][1] = fmaf(h4[j].y, da[j], sr[j][1]);
+                sr[j][2] = fmaf(h4[j].z, da[j], sr[j][2]);
+            }
         }
     }
-    for (int f0 = 0; with_rgb && f0 < W2; f0 += 256) {     // rgb head (3 sigmoid outputs; other heads: the caller's GEMMs)
-        const int f = f0 + t;
-        if (f < W2) {
-            float s[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-            long r = r0;
-            for (; r + 1 < r1; r += 2) {
-                const float da = dact[r * W2 + f], db = dact[(r + 1) * W2 + f];
-                const float4 ha = *reinterpret_cast<const float4 *>(dheads + r * 4), hb = *reinterpret_cast<const float4 *>(dheads + (r + 1) * 4);
-                s[0][0] = fmaf(ha.x, da, s[0][0]); s[0][1] = fmaf(ha.y, da, s[0][1]); s[0][2] = fmaf(ha.z, da, s[0][2]);
-                s[1][0] = fmaf(hb.x, db, s[1][0]); s[1][1] = fmaf(hb.y, db, s[1][1]); s[1][2] = fmaf(hb.z, db, s[1][2]);
-            }
-            for (; r < r1; ++r) {
-                const float d = dact[r * W2 + f];
-                s[0][0] = fmaf(dheads[r * 4 + 0], d, s[0][0]); s[0][1] = fmaf(dheads[r * 4 + 1], d, s[0][1]);
-                s[0][2] = fmaf(dheads[r * 4 + 2], d, s[0][2]);
-            }
-            atomicAdd(d_rgb_w + f, s[0][0] + s[1][0]); atomicAdd(d_rgb_w + W2 + f, s[0][1] + s[1][1]);
-            atomicAdd(d_rgb_w + 2 * W2 + f, s[0][2] + s[1][2]);
+    for (; r < r1; ++r) {                                   // ragged tail of the row range
+        ss[0] = fmaf(dheads[r * 4 + 3], a_last[r * W + t], ss[0]);
+        if (with_rgb && ((r - r0) & 1) == par) {
+            const float d = dact[r * W2 + f2];
+            sr[0][0] = fmaf(dheads[r * 4 + 0], d, sr[0][0]); sr[0][1] = fmaf(dheads[r * 4 + 1], d, sr[0][1]);
+            sr[0][2] = fmaf(dheads[r * 4 + 2], d, sr[0][2]);
         }
+    }
+    atomicAdd(d_sigma_w + t, ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7])));
+    if (with_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(d_rgb_w + c * W2 + f2, (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]));
     }
     if (t < 4 && (with_rgb || t == 3)) {                   // biases
         float s = 0.f;
@@ -613,6 +620,7 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     const TapeLayout &tl = a.tl;
     const long cap = io->tape_rows;
     const int W = d->layer_dim;
+    MNR_REQUIRE(W == 256, "head-gradient kernel is written for layer_dim 256 (one thread per sigma-head feature)");
     hipLaunchKernelGGL(k_head_grads, dim3(1024), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
                        io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
                        io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b, d->rgb_dim == 3 ? 1 : 0);
