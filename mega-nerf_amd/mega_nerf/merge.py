@@ -129,4 +129,31 @@ def merge_in_job(hparams: Namespace, local: Dict[int, Tuple[nn.Module, Optional[
     return container_from_models(hparams, fg, bg, centroid_metadata)
 
 
-__all__ = ['merge_from_checkpoints', 'merge_in_job', 'save_container', 'find_checkpoint', 'models_from_checkpoint']
+def single_cell_container(hparams: Namespace, checkpoint: Path) -> MegaNeRFContainer:
+    """One trained model wrapped as a 1-cell container (reference scripts/convert_to_container.py:20-51): centroid at
+    the origin, unit bounds, 3-D clustering -- so that single-model runs feed the same downstream tools as merged ones."""
+    fg, bg = models_from_checkpoint(hparams, checkpoint)
+    clustering = {'centroids': torch.zeros(1, 3), 'grid_dim': [1, 1], 'min_position': torch.zeros(3), 'max_position': torch.ones(3),
+                  'cluster_2d': False}
+    return container_from_models(hparams, [fg], [bg] if bg is not None else [], clustering)
+
+
+def check_container_on_device(hparams: Namespace, path: str) -> None:
+    """Read an archive back the way eval.py does and evaluate one sample per branch on the device (the smoke check at the
+    end of merge_submodules.py:82-100 / convert_to_container.py:53-72); skipped with a notice on a host without a HIP device."""
+    archive = torch.jit.load(path, map_location='cpu')
+    has_bg = any(name.startswith('bg_sub_module_') for name, _ in archive.named_children())
+    if not torch.cuda.is_available():
+        print('container written to {}; skipping the test evaluation (no HIP device)'.format(path))
+        return
+    device = torch.device('cuda')
+    hp = Namespace(**vars(hparams))
+    hp.container_path, hp.ckpt_path = path, None
+    width = 3 + (3 if hparams.pos_dir_dim > 0 else 0) + (1 if hparams.appearance_dim > 0 else 0)
+    print('fg test eval: {}'.format(get_nerf(hp, 0).to(device).eval()(torch.ones(1, width, device=device))))
+    if has_bg:
+        print('bg test eval: {}'.format(get_bg_nerf(hp, 0).to(device).eval()(torch.ones(1, width + 4, device=device))))
+
+
+__all__ = ['merge_from_checkpoints', 'merge_in_job', 'save_container', 'find_checkpoint', 'models_from_checkpoint',
+           'single_cell_container', 'check_container_on_device']

@@ -9,8 +9,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
-from mega_nerf.merge import merge_from_checkpoints, save_container   # noqa: E402
-from mega_nerf.models.model_utils import get_bg_nerf, get_nerf       # noqa: E402
+from mega_nerf.merge import merge_from_checkpoints, save_container, check_container_on_device   # noqa: E402
 from mega_nerf.opts import get_opts_base                             # noqa: E402
 
 
@@ -24,22 +23,8 @@ def _get_merge_opts() -> Namespace:
 
 @torch.inference_mode()
 def main(hparams: Namespace) -> None:
-    container = merge_from_checkpoints(hparams)
-    save_container(container, hparams.output)
-    n_bg = sum(1 for name, _ in container.named_children() if name.startswith('bg_sub_module_'))
-    # read the archive back the way eval.py does and evaluate one sample per branch (:82-100)
-    if not torch.cuda.is_available():
-        print('container written to {}; skipping the test evaluation (no HIP device)'.format(hparams.output))
-        return
-    device = torch.device('cuda')
-    hp = Namespace(**vars(hparams))
-    hp.container_path, hp.ckpt_path = hparams.output, None
-    width = 3 + (3 if hparams.pos_dir_dim > 0 else 0) + (1 if hparams.appearance_dim > 0 else 0)
-    nerf = get_nerf(hp, 0).to(device).eval()
-    print('fg test eval: {}'.format(nerf(torch.ones(1, width, device=device))))
-    if n_bg > 0:
-        bg_nerf = get_bg_nerf(hp, 0).to(device).eval()
-        print('bg test eval: {}'.format(bg_nerf(torch.ones(1, width + 4, device=device))))
+    save_container(merge_from_checkpoints(hparams), hparams.output)
+    check_container_on_device(hparams, hparams.output)          # read back + one sample per branch (:82-100)
 
 
 if __name__ == '__main__':

@@ -115,6 +115,29 @@ def test_merge_from_checkpoints_script(tmp_path):
         mod.main(h)
 
 
+def test_convert_single_checkpoint_to_container(tmp_path):
+    import importlib.util
+    if torch.cuda.is_available():
+        pytest.skip('the device-side test evaluation of this script is covered by test_gpu_merge_script_end_to_end')
+    hp, fcfg, bcfg, fw, bw = G.seeded_weights()
+    ckpt = tmp_path / 'one.pt'
+    torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in fw[0].items()},
+                'bg_model_state_dict': {k: torch.from_numpy(v) for k, v in bw[0].items()}}, ckpt)
+    spec = importlib.util.spec_from_file_location('convert_to_container', ROOT / 'mega-nerf_amd' / 'scripts' / 'convert_to_container.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    h = Namespace(**vars(hp))
+    h.ckpt_path, h.output = str(ckpt), str(tmp_path / 'single.pt')
+    mod.main(h)
+    c = torch.jit.load(h.output, map_location='cpu')
+    assert c.centroids.shape == (1, 3) and not c.cluster_2d and c.need_viewdir and c.need_appearance_embedding
+    assert c.grid_dim.tolist() == [1, 1] and torch.equal(c.max_position, torch.ones(3))
+    for k, v in fw[0].items():
+        assert np.array_equal(c.sub_module_0.state_dict()[k].numpy(), v), k
+    for k, v in bw[0].items():
+        assert np.array_equal(c.bg_sub_module_0.state_dict()[k].numpy(), v), k
+
+
 def _port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
