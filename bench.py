@@ -19,12 +19,10 @@ import json
 import os
 import sys
 import time
-from argparse import Namespace
 from pathlib import Path
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: required for RCCL across processes on this host driver
 
-import numpy as np    # noqa: E402
 import torch          # noqa: E402
 
 ROOT = Path(__file__).resolve().parent

@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 from argparse import Namespace
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 from torch import nn
