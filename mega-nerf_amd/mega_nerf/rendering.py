@@ -298,6 +298,28 @@ def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_ra
     return _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
 
 
+def _empty_results(hparams: Namespace, has_bg: bool, get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool,
+                   dev: torch.device) -> Dict[str, torch.Tensor]:
+    """The result dict of a zero-ray batch: the keys render_rays produces for these flags, with empty tensors."""
+    Nf = hparams.fine_samples
+    types = ['fine' if Nf > 0 else 'coarse'] + (['coarse'] if (hparams.use_cascade and Nf > 0) else [])
+    out: Dict[str, torch.Tensor] = {}
+    for typ in types:
+        out['rgb_' + typ] = _f(0, 3, device=dev)
+        main_pass = typ == types[0]
+        if get_depth and main_pass:
+            out['depth_' + typ] = _f(0, device=dev)
+        if get_depth_variance and main_pass:
+            out['depth_variance_' + typ] = _f(0, device=dev)
+        if has_bg:
+            out['bg_lambda_' + typ] = _f(0, device=dev)
+            if get_bg_fg_rgb:
+                out['fg_rgb_' + typ], out['bg_rgb_' + typ] = _f(0, 3, device=dev), _f(0, 3, device=dev)
+                if get_depth and main_pass:
+                    out['fg_depth_' + typ], out['bg_depth_' + typ] = _f(0, device=dev), _f(0, device=dev)
+    return out
+
+
 def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
                       image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
                       get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
@@ -324,6 +346,8 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
         image_indices = image_indices.contiguous()
     perturb = float(hparams.perturb) if nerf.training else 0.0
     dirs = rays[:, 3:6]
+    if n_rays == 0:
+        return _empty_results(hparams, bg_nerf is not None, get_depth, get_depth_variance, get_bg_fg_rgb, dev), None, None
 
     n_bg = err = bg_slot = bg_join = bg_prologue_done = None
     far = None

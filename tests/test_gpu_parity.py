@@ -608,3 +608,30 @@ def test_cascade_render_with_unfused_width():
     assert sorted(res) == sorted(ores)
     for k in ores:
         np.testing.assert_allclose(res[k].cpu().numpy(), ores[k], rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+def test_render_edge_batches_no_background_rays_and_empty():
+    """A bg model is present but no ray of the batch leaves the ellipsoid before `far` (the reference returns
+    bg_nerf_rays_present == False and zero bg terms, rendering.py:33-45,102-139); and an empty batch."""
+    from mega_nerf.rendering import render_rays
+    g = load('render_fgbg_eval')
+    hp, nerf, bg_nerf = native_models('render_fgbg_eval')
+    hp = Namespace(**vars(hp))
+    s = common.SCENE
+    rays = g['rays'].copy()
+    rays[:, 7] = np.minimum(rays[:, 7], 0.3)              # far well inside the sphere for every ray
+    idx = g['idx'].astype(f32)
+    ohp, onerf, obg = build_case('render_fgbg_eval')
+    want, present = O.render_rays(onerf, obg, rays, idx, ohp, s['sphere_center'], s['sphere_radius'], True, False, True)
+    assert not present
+    with torch.no_grad():
+        res, got_present = render_rays(nerf, bg_nerf, T(rays), T(idx), hp, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    assert got_present is False
+    assert sorted(res) == sorted(want)
+    for k in want:
+        np.testing.assert_allclose(res[k].cpu().numpy(), want[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    assert float(res['bg_rgb_fine'].abs().max()) == 0.0
+    # empty batch: shapes only
+    with torch.no_grad():
+        res0, p0 = render_rays(nerf, bg_nerf, T(rays[:0]), T(idx[:0]), hp, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    assert p0 is False and res0['rgb_fine'].shape == (0, 3)
