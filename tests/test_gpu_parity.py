@@ -635,3 +635,55 @@ def test_render_edge_batches_no_background_rays_and_empty():
     with torch.no_grad():
         res0, p0 = render_rays(nerf, bg_nerf, T(rays[:0]), T(idx[:0]), hp, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
     assert p0 is False and res0['rgb_fine'].shape == (0, 3)
+
+
+def test_training_step_without_background_rays():
+    """Train-mode render + backward when no ray of the batch has a background segment: the bg branch runs over zero rows,
+    bg gradients are exactly zero, fg gradients equal those of the same batch rendered without a bg model."""
+    from mega_nerf.rendering import render_rays
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays = g['rays'].copy()
+    rays[:, 7] = np.minimum(rays[:, 7], 0.3)
+    idx, tgt = T(g['idx'].astype(np.int32)), T(g['target'])
+    rnd = {k[4:]: T(v).reshape(-1) if 'noise' in k else T(v) for k, v in g.items() if k.startswith('rnd_fg')}
+    grads = []
+    for with_bg in (True, False):
+        hp, nerf, bg_nerf = native_models('render_fgbg_train')
+        hp = Namespace(**vars(hp))
+        res, present = render_rays(nerf, bg_nerf if with_bg else None, T(rays), idx, hp, T(s['sphere_center']) if with_bg else None,
+                                   T(s['sphere_radius']) if with_bg else None, False, True, False, _randoms=dict(rnd))
+        assert present is False
+        torch.nn.functional.mse_loss(res['rgb_fine'], tgt).backward()
+        if with_bg:
+            assert all(float(p.grad.abs().max()) == 0.0 for p in bg_nerf.parameters())
+            assert 'bg_lambda_fine' in res
+        grads.append({k: p.grad.clone() for k, p in nerf.named_parameters()})
+        assert all(torch.isfinite(v).all() for v in grads[-1].values())
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-20), k
+
+
+def test_render_accepts_views_and_int64_indices_and_no_altitude_range():
+    """Callers hand in slices of larger tensors and int64 index vectors (runner.py:570, dataset_utils.py:39);
+    get_rays without an altitude range keeps the constant bounds (ray_utils.py:44-62)."""
+    from mega_nerf import ray_utils as RU
+    from mega_nerf.rendering import render_rays
+    g = load('render_fgbg_eval')
+    hp, nerf, bg_nerf = native_models('render_fgbg_eval')
+    hp = Namespace(**vars(hp))
+    s = common.SCENE
+    big = torch.zeros(g['rays'].shape[0] + 7, 11, device=DEV)
+    big[3:-4, 2:10] = T(g['rays'])
+    view = big[3:-4, 2:10]                                   # non-contiguous, storage offset
+    with torch.no_grad():
+        a, _ = render_rays(nerf, bg_nerf, view, T(g['idx'].astype(np.int64)), hp, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+        b, _ = render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), hp, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    d = RU.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, torch.device(DEV))
+    r = RU.get_rays(d, T(s['c2w']), 0.05, 7.0, None)
+    want = O.get_rays(O.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True), s['c2w'], 0.05, 7.0, None)
+    np.testing.assert_allclose(r.cpu().numpy(), want, rtol=2e-6, atol=2e-7)
+    assert float(r[..., 6].min()) == float(r[..., 6].max()) == np.float32(0.05) and float(r[..., 7].max()) == 7.0
