@@ -136,3 +136,51 @@ def test_gpu_cluster_masks_large_image_properties():
     sub = rays.view(-1, 8)[pick.to(dev)].cpu().numpy()
     want = O.cluster_min_dist_ratios(sub, g['centroids'], O.linspace01(1000), True)
     assert np.array_equal(r115.view(-1, 8)[pick.to(dev)].cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_gpu_script_segmentation_masks_and_resume(tmp_path):
+    """--segmentation_path ANDs an external per-image mask into every cell mask (create_cluster_masks.py:194-208);
+    --resume regenerates only images whose mask files are missing or unreadable (:118-139)."""
+    import importlib.util
+    from argparse import Namespace
+    from mega_nerf.cluster_masks import read_mask, write_mask
+    g = load('masks_2x2_3d')
+    data, out, seg = tmp_path / 'data', tmp_path / 'masks', tmp_path / 'seg'
+    seg.mkdir()
+    names = [str(s) for s in g['names']]
+    rng = np.random.default_rng(0)
+    seg_masks = {}
+    for i, nm in enumerate(names):
+        sub, stem = nm.split('/')
+        (data / sub / 'metadata').mkdir(parents=True, exist_ok=True)
+        torch.save({'W': int(g['W']), 'H': int(g['H']), 'c2w': torch.from_numpy(g['c2w'][i]), 'intrinsics': torch.from_numpy(g['intr'])},
+                   data / sub / 'metadata' / (stem + '.pt'))
+        seg_masks[stem] = torch.from_numpy(rng.uniform(size=(int(g['H']), int(g['W']))) > 0.4)
+        write_mask(seg / (stem + '.pt'), seg_masks[stem])
+    torch.save({'origin_drb': torch.from_numpy(g['origin_drb']), 'pose_scale_factor': float(g['psf'])}, data / 'coordinates.pt')
+    spec = importlib.util.spec_from_file_location('create_cluster_masks', ROOT / 'mega-nerf_amd' / 'scripts' / 'create_cluster_masks.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def hp(resume):
+        return Namespace(ray_altitude_range=[float(v) for v in g['hp_altitude']], output=str(out), resume=resume, dataset_path=str(data),
+                         grid_dim=[int(v) for v in g['grid_dim']], near=float(g['hp_near']), far=None, cluster_2d=bool(g['cluster_2d']),
+                         ray_samples=int(g['ray_samples']), center_pixels=True, segmentation_path=str(seg),
+                         boundary_margin=float(g['margin']))
+
+    mod.main(hp(False))
+    for i, nm in enumerate(names):
+        stem = nm.split('/')[1]
+        for j in range(g['masks'].shape[1]):
+            want = np.logical_and(g['masks'][i, j], seg_masks[stem].numpy())
+            assert np.array_equal(read_mask(out / str(j) / (stem + '.pt')).numpy(), want), (nm, j)
+    # damage one file, delete another: --resume repairs exactly those images
+    stem0, stem1 = names[0].split('/')[1], names[1].split('/')[1]
+    (out / '1' / (stem0 + '.pt')).write_bytes(b'not a zip')
+    (out / '2' / (stem1 + '.pt')).unlink()
+    keep = (out / '0' / (names[2].split('/')[1] + '.pt')).stat().st_mtime_ns
+    mod.main(hp(True))
+    assert np.array_equal(read_mask(out / '1' / (stem0 + '.pt')).numpy(), np.logical_and(g['masks'][0, 1], seg_masks[stem0].numpy()))
+    assert (out / '2' / (stem1 + '.pt')).exists()
+    assert (out / '0' / (names[2].split('/')[1] + '.pt')).stat().st_mtime_ns == keep          # untouched

@@ -155,3 +155,28 @@ def test_gpu_runner_trains_from_chunks(tmp_path):
     assert len(list((tmp_path / 'chunks').glob('*.parquet'))) == 4
     ck = torch.load(tmp_path / 'exp' / '0' / 'models' / '12.pt', map_location='cpu', weights_only=False)
     assert Path(ck['dataset_state']).parent == tmp_path / 'chunks' and ck['iteration'] == 12
+
+
+@pytest.mark.gpu
+def test_gpu_differing_intrinsics_store_rays_in_the_chunks(tmp_path):
+    """Images with different intrinsics cannot share a direction table: the chunks then carry rays_0..7 instead of pixel
+    indices (filesystem_dataset.py:37-52,165-176,213-222) and metadata.pt records the ray bounds."""
+    import pyarrow.parquet as pq
+    from mega_nerf.datasets.filesystem_dataset import FilesystemDataset
+    its = items(tmp_path)
+    its[1].intrinsics = its[1].intrinsics * torch.tensor([1.1, 1.1, 1.0, 1.0])
+    ds = FilesystemDataset(its, float(G['near']), float(G['far']), [float(v) for v in G['alt']], True, torch.device('cuda'),
+                           [tmp_path / 'rays_chunks'], 2, 1, 10 ** 6)
+    t = pq.read_table(sorted((tmp_path / 'rays_chunks').glob('*.parquet'))[0])
+    assert t.schema.names == ['img_indices', 'rgbs_0', 'rgbs_1', 'rgbs_2'] + ['rays_%d' % i for i in range(8)]
+    meta = torch.load(tmp_path / 'rays_chunks' / 'metadata.pt', weights_only=False)
+    assert meta['near'] == float(G['near']) and meta['far'] == float(G['far']) and meta['center_pixels'] is True
+    total = 0
+    for _ in range(2):
+        ds.load_chunk()
+        total += len(ds)
+        rays, img = ds._loaded_rays.cpu().numpy(), ds._loaded_img_indices.cpu().numpy()
+        assert np.array_equal(rays[:, 0:3], G['c2w'][img][:, :, 3])
+        np.testing.assert_allclose(np.linalg.norm(rays[:, 3:6], axis=1), 1.0, rtol=1e-5)
+    assert total == len(expected_rows())
+    ds.close()
