@@ -62,3 +62,36 @@ def test_reference_config_files_parse():
         for k, v in want.items():
             assert getattr(hp, k) == v, (text, k, getattr(hp, k))
         assert hp.batch_size == 2048                       # command line wins over the file
+
+
+REFERENCE_FLAGS = ['--config_file', '--dataset_type', '--chunk_paths', '--num_chunks', '--disk_flush_size', '--train_every',
+                   '--cluster_mask_path', '--ckpt_path', '--container_path', '--near', '--far', '--ray_altitude_range', '--coarse_samples',
+                   '--fine_samples', '--train_scale_factor', '--val_scale_factor', '--pos_xyz_dim', '--pos_dir_dim', '--layers',
+                   '--skip_layers', '--layer_dim', '--bg_layer_dim', '--appearance_dim', '--affine_appearance', '--use_cascade',
+                   '--train_mega_nerf', '--boundary_margin', '--all_val', '--cluster_2d', '--sh_deg', '--no_center_pixels',
+                   '--no_shifted_softplus', '--batch_size', '--image_pixel_batch_size', '--model_chunk_size', '--perturb', '--noise_std',
+                   '--lr', '--lr_decay_factor', '--no_bg_nerf', '--ellipse_scale_factor', '--no_ellipse_bounds', '--train_iterations',
+                   '--val_interval', '--ckpt_interval', '--no_resume_ckpt_state', '--no_amp', '--detect_anomalies', '--random_seed']
+
+
+def test_flag_set_is_the_reference_flag_set():
+    """Every flag of the reference's opts.get_opts_base() (names restated above) exists here, and nothing else does, so
+    command lines and config files carry over; the defaults that define "the Rubble config" are the reference's."""
+    from mega_nerf.opts import get_opts_base
+    parser = get_opts_base()
+    mine = sorted(s for a in parser._actions for s in a.option_strings if s.startswith('--') and s != '--help')
+    assert mine == sorted(REFERENCE_FLAGS)
+    hp = parser.parse_args([])
+    assert (hp.coarse_samples, hp.fine_samples, hp.layer_dim, hp.bg_layer_dim, hp.layers, hp.skip_layers) == (256, 512, 256, 256, 8, [4])
+    assert (hp.pos_xyz_dim, hp.pos_dir_dim, hp.appearance_dim, hp.batch_size, hp.boundary_margin) == (12, 4, 48, 1024, 1.15)
+    assert hp.bg_nerf and hp.ellipse_bounds and hp.center_pixels and hp.shifted_softplus and hp.sh_deg is None
+    assert (hp.lr, hp.lr_decay_factor, hp.train_iterations, hp.random_seed, hp.perturb) == (5e-4, 0.1, 500000, 42, 1.0)
+
+
+def test_filesystem_dataset_refuses_a_cpu_device(tmp_path):
+    import pytest
+    import torch
+    from mega_nerf import _native as N
+    from mega_nerf.datasets.filesystem_dataset import FilesystemDataset
+    with pytest.raises(N.NativeError, match='no CPU fallback'):
+        FilesystemDataset([], 0.1, 1.0, None, True, torch.device('cpu'), [tmp_path / 'c'], 1, 1, 10)
