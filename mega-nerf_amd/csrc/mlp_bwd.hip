@@ -678,7 +678,7 @@ extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_g
     // LDS-DMA fill time, plus a fixed barrier/latency term); ~6 items per CU keep the tail short.
     auto env_d = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };
     const double fill_bpc = env_d("MNR_WGRAD_FILL_BPC", 6.0), fixed = env_d("MNR_WGRAD_FIXED", 2500.0);
-    const int budget = (int)env_d("MNR_WGRAD_ITEMS", 1536.0);
+    const int budget = (int)env_d("MNR_WGRAD_ITEMS", 1024.0);     // tools/sweep_wgrad.py: 768-1024 is the (flat) optimum
     double cost[WGRAD_MAX_JOBS], tot = 0;
     for (int i = 0; i < nj; ++i) {
         const WgradJob &J = wa.job[i];
