@@ -226,3 +226,36 @@ def test_gpu_merge_script_end_to_end(tmp_path):
     ref = torch.jit.load(str(GOLD / 'container_ref.pt'), map_location='cpu')
     for k, v in ref.sub_module_1.state_dict().items():
         assert torch.equal(merged.sub_module_1.state_dict()[k], v), k
+
+
+def test_merge_without_appearance_and_without_background(tmp_path):
+    """Checkpoints of a `--no_bg_nerf --appearance_dim 0` run (configs/nerf-style): no bg_sub_module_* members, no
+    embedding table, need_appearance_embedding False; the archive still scripts and reads back."""
+    import common
+    from oracle.nerf_oracle import make_hparams
+    from mega_nerf.merge import merge_from_checkpoints, save_container
+    from mega_nerf.models.model_utils import get_nerf
+    hp = Namespace(**vars(make_hparams(coarse_samples=64, fine_samples=128, layer_dim=32, appearance_dim=0)))
+    cfg = common.model_cfg(hp, 3, 32)
+    ws = [common.make_weights(cfg, 0, 9100 + i, sharpen=False) for i in range(2)]
+    for i, w in enumerate(ws):
+        d = tmp_path / 'run-{}'.format(i) / '0' / 'models'
+        d.mkdir(parents=True)
+        torch.save({'model_state_dict': {k: torch.from_numpy(v) for k, v in w.items()}}, d / '5.pt')
+    meta = G.centroid_metadata()
+    meta['cluster_2d'] = True
+    torch.save(meta, tmp_path / 'params.pt')
+    hp.ckpt_prefix, hp.centroid_path, hp.output, hp.train_iterations = str(tmp_path / 'run-'), str(tmp_path / 'params.pt'), \
+        str(tmp_path / 'merged.pt'), 5
+    save_container(merge_from_checkpoints(hp), hp.output)
+    c = torch.jit.load(hp.output, map_location='cpu')
+    assert sorted(n for n, _ in c.named_children()) == ['sub_module_0', 'sub_module_1']
+    assert c.cluster_2d is True and c.need_appearance_embedding is False and c.need_viewdir is True
+    assert 'embedding_a.weight' not in c.sub_module_0.state_dict()
+    x = torch.rand(9, 6)
+    assert c.sub_module_1(x).shape == (9, 4) and c.sub_module_1(x[:, :3], True).shape == (9, 1)
+    hp.container_path = hp.output
+    routed = get_nerf(hp, 0)                                   # native modules rebuilt from the archive (no device needed yet)
+    assert routed.cluster_dim_start == 1 and len(routed.sub_modules) == 2 and routed.sub_modules[0].embedding_a is None
+    for k, v in ws[1].items():
+        assert np.array_equal(routed.sub_modules[1].state_dict()[k].numpy(), v), k
