@@ -242,6 +242,28 @@ int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev
  * launch (so several forward passes that share a tape are reduced together).  d_out/out/idx are not read. */
 int mnr_mlp_backward_weights(const mnr_model_desc *desc, const mnr_mlp_grad_io *io, void *stream);
 
+/* Backward, step 2, batched: the weight + bias gradients of SEVERAL models (foreground + background of one training step)
+ * in ONE launch + one reduction launch.  Each region names a model's tape / gradient tape and up to two row ranges of them
+ * (coarse rows, fine rows; device-side counts for the compacted background).  Contract: every range starts on a multiple of
+ * 4 rows, the tape capacity covers the range padded to 32 rows, and padding rows hold dZ = 0 and finite activations (the
+ * fused forward / data-gradient kernels write whole 64-row tiles that way).  workspace_dev: mnr_wgrad_workspace_bytes()
+ * bytes of scratch (partial-sum slabs; no initialisation needed).  Gradients are ACCUMULATED into region.grad. */
+typedef struct mnr_wgrad_region {
+    const mnr_model_desc *desc;
+    const float *tape;
+    const float *gtape;
+    int64_t tape_rows;
+    int32_t n_ranges;
+    int64_t row0[2];
+    int64_t n_rows[2];
+    const int32_t *n_units_dev[2];
+    int32_t rows_per_unit[2];
+    mnr_model_grads grad;
+} mnr_wgrad_region;
+size_t mnr_wgrad_workspace_bytes(void);
+int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev, size_t workspace_bytes,
+                                   void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Volume rendering stages -- mega_nerf/rendering.py
  * ---------------------------------------------------------------------------------------------- */

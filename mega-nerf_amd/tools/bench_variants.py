@@ -33,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', type=int, default=1024 * 192)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--only', default='', help='comma-separated arch names (default: all)')
     a = ap.parse_args()
     dev = torch.device('cuda')
     torch.manual_seed(0)
@@ -46,6 +47,8 @@ def main():
     cases = [('w256', dict(layer_dim=256)), ('w512', dict(layer_dim=512)), ('w2048_noapp', dict(layer_dim=2048, appearance_dim=0)),
              ('sh2_w256', dict(layer_dim=256, pos_dir_dim=0, rgb_dim=27))]
     for name, kw in cases:
+        if a.only and name not in a.only.split(','):
+            continue
         W, app, pd, rgb = kw['layer_dim'], kw.get('appearance_dim', 48), kw.get('pos_dir_dim', 4), kw.get('rgb_dim', 3)
         m = NeRF(12, pd, 8, [4], W, app, False, 100, rgb, 3, ShiftedSoftplus()).to(dev)
         fl = flops_per_sample(m)

@@ -13,6 +13,7 @@ from mega_nerf.models.nerf import NeRF, ShiftedSoftplus   # noqa: E402
 
 
 def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dev = torch.device('cuda')
     torch.manual_seed(0)
     m = NeRF(12, 4, 8, [4], 256, 48, False, 100, 3, 3, ShiftedSoftplus()).to(dev)
@@ -23,7 +24,7 @@ def main():
         idx = torch.randint(0, 100, (n_rays,), device=dev).float()
         out = torch.empty(rows, 4, device=dev)
         d_out = torch.randn(rows, 4, device=dev)
-        for _ in range(3):
+        for _ in range(reps):
             with torch.no_grad():
                 m.evaluate(xyz, 3, dirs, 3, idx, 1, S, rows, out)
             grads = {k: torch.zeros_like(p) for k, p in m.named_parameters()}
