@@ -197,6 +197,19 @@ int64_t mnr_tape_floats_per_row(const mnr_model_desc *desc);
 int mnr_mlp_forward_train(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, float *tape_dev,
                           int64_t tape_rows, int64_t tape_row0, void *stream);
 
+/* Several independent MLP evaluations in ONE launch (the foreground and the background model of one pass of a training /
+ * rendering step; the compacted background rows alone cannot fill 256 CUs).  Every segment is what mnr_mlp_forward (tape_dev
+ * NULL) or mnr_mlp_forward_train would take; all segments of a call are of the same kind.  Covers the default 8x256
+ * foreground / background architectures (MNR_E_UNSUPPORTED otherwise: launch the segments one by one). */
+typedef struct mnr_mlp_launch {
+    const void *packed_dev;
+    const mnr_model_desc *desc;
+    const mnr_mlp_io *io;
+    float *tape_dev;                 /* training: activation tape of this segment's model, else NULL */
+    int64_t tape_rows, tape_row0;
+} mnr_mlp_launch;
+int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream);
+
 /* Transposed weight image for the data-gradient chain (re-pack after every optimiser step). */
 size_t mnr_packed_bwd_bytes(const mnr_model_desc *desc);
 int mnr_pack_model_bwd(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
@@ -238,6 +251,17 @@ int64_t mnr_tape_plane_offset(const mnr_model_desc *desc, int which);
  * embedding gradient.  No gradient w.r.t. xyz / directions is produced (rays are data). */
 int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev, const mnr_model_desc *desc,
                           const mnr_mlp_grad_io *io, void *stream);
+/* Backward, step 1, batched: the data-gradient chains of several segments (coarse + fine rows of the foreground and the
+ * background model of a training step) in ONE launch, followed by the head gradients of every segment.  Each segment is what
+ * mnr_mlp_backward_data would take.  Default 8x256 fg / bg architectures (MNR_E_UNSUPPORTED otherwise). */
+typedef struct mnr_mlp_grad_launch {
+    const void *packed_fwd_dev;
+    const void *packed_bwd_dev;
+    const mnr_model_desc *desc;
+    const mnr_mlp_grad_io *io;
+} mnr_mlp_grad_launch;
+int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream);
+
 /* Backward, step 2: weight + bias gradients of every layer over tape rows [tape_row0, tape_row0 + n_rows) in one
  * launch (so several forward passes that share a tape are reduced together).  d_out/out/idx are not read. */
 int mnr_mlp_backward_weights(const mnr_model_desc *desc, const mnr_mlp_grad_io *io, void *stream);

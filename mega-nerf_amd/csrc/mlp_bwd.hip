@@ -124,7 +124,7 @@ __device__ __forceinline__ void zero_acc(AccT (&acc)[NOB]) {
 }
 
 template <class C>
-__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_bwd(MlpBwdArgs a) {
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB, H2 = C::H2, W = C::W;
     static_assert(C::HAS_FINAL, "backward kernel covers the dir/appearance architecture");
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     extern __shared__ float4 lds_ring[];
 
     const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
-    if ((long)blockIdx.x * C::ROWS_PER_WG >= n_rows) return;
+    if (blk * C::ROWS_PER_WG >= n_rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
-    const long row = ((long)blockIdx.x * 4 + wave) * TILE + (lane % TILE);
+    const long row = (blk * 4 + wave) * TILE + (lane % TILE);
     const bool valid = row < n_rows;
     const long rc = valid ? row : n_rows - 1;
     const long cap = a.tape_rows;
@@ -262,6 +262,27 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
         mask_apply(g, bits);
     });
     gtape_store<P>(g, a.gtape + a.tl.act_off[0] * cap + trow * W, part, valid);
+}
+
+template <class C>
+__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_bwd(MlpBwdArgs a) {
+    mlp_bwd_body<C>(a, blockIdx.x);
+}
+
+// The data-gradient chains of several forward passes (coarse + fine rows of the foreground and of the background model) in
+// ONE launch: workgroups [wg0[s], wg0[s+1]) belong to segment s, which runs configuration CA or CB.
+constexpr int MLP_BWD_MAX_SEGS = 4;
+struct MlpBwdMulti {
+    MlpBwdArgs seg[MLP_BWD_MAX_SEGS];
+    int32_t wg0[MLP_BWD_MAX_SEGS + 1];
+    int32_t is_b[MLP_BWD_MAX_SEGS];
+};
+template <class CA, class CB>
+__global__ __launch_bounds__(256, 2) void k_mlp_bwd_multi(MlpBwdMulti m) {
+    const int blk = blockIdx.x;
+    const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
+    if (m.is_b[s]) mlp_bwd_body<CB>(m.seg[s], blk - m.wg0[s]);
+    else mlp_bwd_body<CA>(m.seg[s], blk - m.wg0[s]);
 }
 
 // =================================================================================================
@@ -572,20 +593,14 @@ static int check_grad_io(const mnr_model_desc *d, const mnr_mlp_grad_io *io) {
     return MNR_OK;
 }
 
-extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev, const mnr_model_desc *d,
-                                     const mnr_mlp_grad_io *io, void *stream) {
-    ModelLayout m;
-    BwdLayout b;
-    int rc = layout_from_desc(d, m);
-    if (rc != MNR_OK) return rc;
-    rc = bwd_layout_from_desc(d, b);
-    if (rc != MNR_OK) return rc;
-    rc = check_grad_io(d, io);
+// host side of one data-gradient segment: argument block of the chain kernel
+static int fill_bwd_args(MlpBwdArgs &a, const ModelLayout &m, const void *packed_fwd_dev, const void *packed_bwd_dev,
+                         const mnr_model_desc *d, const mnr_mlp_grad_io *io) {
+    int rc = check_grad_io(d, io);
     if (rc != MNR_OK) return rc;
     MNR_REQUIRE(packed_fwd_dev && packed_bwd_dev && io->d_out && io->out, "NULL argument");
     MNR_REQUIRE(d->appearance_dim == 0 || io->idx, "image indices required");
-    hipStream_t s = as_stream(stream);
-    MlpBwdArgs a{};
+    a = MlpBwdArgs{};
     a.chunks = reinterpret_cast<const float4 *>(packed_bwd_dev);
     a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed_fwd_dev) + (size_t)m.total_chunks * CHUNK_BYTES);
     a.tape = io->tape; a.gtape = io->gtape; a.tape_rows = io->tape_rows; a.tl = tape_layout(arch_of(d));
@@ -596,7 +611,42 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     a.n_rows = io->n_rows; a.n_units_dev = io->n_units_dev; a.rows_per_unit = io->rows_per_unit;
     a.tape_row0 = io->tape_row0;
     a.dd_in = io->dd_in;
+    a.sigma_off = m.sigma_off;
+    a.rgb_off = m.rgb_off;
     MNR_REQUIRE(d->rgb_dim == 3 || io->dd_in, "rgb_dim != 3: dd_in (gradient at the dir_a output) is required");
+    return MNR_OK;
+}
+
+// sigma / rgb head weight gradients of the rows of one segment (dheads was just written by the chain kernel)
+static int launch_head_grads(const mnr_model_desc *d, const mnr_mlp_grad_io *io, hipStream_t s) {
+    if (io->n_rows == 0) return MNR_OK;
+    const mnr_model_grads &G = io->grad;
+    MNR_REQUIRE(G.sigma_w && G.sigma_b && G.rgb_w && G.rgb_b, "missing head gradient pointers");
+    const TapeLayout tl = tape_layout(arch_of(d));
+    const long cap = io->tape_rows;
+    const int W = d->layer_dim;
+    MNR_REQUIRE(W == 256, "head-gradient kernel is written for layer_dim 256 (one thread per sigma-head feature)");
+    // every block ends with 644 atomics on the same addresses: few, long blocks (round 1 launched 1024 per segment and spent
+    // 60-125 us per launch mostly there)
+    const long blocks = io->n_units_dev ? 48 : (io->n_rows + 767) / 768;
+    hipLaunchKernelGGL(k_head_grads, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks))), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
+                       io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
+                       io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b, d->rgb_dim == 3 ? 1 : 0);
+    return check_launch("k_head_grads");
+}
+
+extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *packed_bwd_dev, const mnr_model_desc *d,
+                                     const mnr_mlp_grad_io *io, void *stream) {
+    ModelLayout m;
+    BwdLayout b;
+    int rc = layout_from_desc(d, m);
+    if (rc != MNR_OK) return rc;
+    rc = bwd_layout_from_desc(d, b);
+    if (rc != MNR_OK) return rc;
+    MlpBwdArgs a;
+    rc = fill_bwd_args(a, m, packed_fwd_dev, packed_bwd_dev, d, io);
+    if (rc != MNR_OK) return rc;
+    hipStream_t s = as_stream(stream);
     rc = MNR_E_UNSUPPORTED;
 #define MNR_TRY_B(XYZ, LX, LD, APP, W, NL, SKIP, RGB, TL)                                                      \
     if (d->xyz_dim == XYZ && d->pos_xyz_dim == LX && d->pos_dir_dim == LD && d->appearance_dim == APP &&        \
@@ -613,18 +663,56 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 #undef MNR_TRY_B
     if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "
                                                    "default 8x256 fg/bg models)");
-    if (rc != MNR_OK || io->n_rows == 0) return rc;
-    // sigma / rgb head weight gradients of the same rows (dheads was just written by the chain kernel)
-    const mnr_model_grads &G = io->grad;
-    MNR_REQUIRE(G.sigma_w && G.sigma_b && G.rgb_w && G.rgb_b, "missing head gradient pointers");
-    const TapeLayout &tl = a.tl;
-    const long cap = io->tape_rows;
-    const int W = d->layer_dim;
-    MNR_REQUIRE(W == 256, "head-gradient kernel is written for layer_dim 256 (one thread per sigma-head feature)");
-    hipLaunchKernelGGL(k_head_grads, dim3(1024), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
-                       io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
-                       io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b, d->rgb_dim == 3 ? 1 : 0);
-    return check_launch("k_head_grads");
+    if (rc != MNR_OK) return rc;
+    return launch_head_grads(d, io, s);
+}
+
+// Data-gradient chains of several segments (coarse + fine rows of the foreground and background models) in ONE launch,
+// then the head gradients of every segment.  Default 8x256 fg / bg architectures only (MNR_E_UNSUPPORTED otherwise).
+extern "C" int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+    using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
+    using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
+    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
+    MlpBwdMulti mm{};
+    long wg = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const mnr_mlp_grad_launch &L = segs[i];
+        MNR_REQUIRE(L.desc && L.io, "segment %d: NULL argument", i);
+        const mnr_model_desc *d = L.desc;
+        ModelLayout m;
+        BwdLayout b;
+        int rc = layout_from_desc(d, m);
+        if (rc != MNR_OK) return rc;
+        const bool common = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 256 &&
+                            d->layers == 8 && d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
+        if (!common || (d->xyz_dim != 3 && d->xyz_dim != 4))
+            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_backward_data_multi covers the default 8x256 fg / bg models");
+        rc = bwd_layout_from_desc(d, b);
+        if (rc != MNR_OK) return rc;
+        rc = fill_bwd_args(mm.seg[i], m, L.packed_fwd_dev, L.packed_bwd_dev, d, L.io);
+        if (rc != MNR_OK) return rc;
+        mm.is_b[i] = d->xyz_dim == 4 ? 1 : 0;
+        mm.wg0[i] = (int32_t)wg;
+        wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
+        MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one launch");
+    }
+    for (int i = n_segs; i <= MLP_BWD_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
+    if (wg == 0) return MNR_OK;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL((k_mlp_bwd_multi<CfgFG, CfgBG>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    int rc = check_launch("k_mlp_bwd_multi");
+    // head gradients: segments that continue each other in one tape (coarse + fine rows of the foreground) go out as one launch
+    for (int i = 0; i < n_segs && rc == MNR_OK; ++i) {
+        mnr_mlp_grad_io io = *segs[i].io;
+        while (i + 1 < n_segs && !io.n_units_dev && !segs[i + 1].io->n_units_dev && segs[i + 1].io->tape == io.tape &&
+               segs[i + 1].io->dheads == io.dheads && segs[i + 1].io->tape_row0 == io.tape_row0 + io.n_rows &&
+               segs[i + 1].io->grad.sigma_w == io.grad.sigma_w) {
+            io.n_rows += segs[i + 1].io->n_rows;
+            ++i;
+        }
+        rc = launch_head_grads(segs[i].desc, &io, s);
+    }
+    return rc;
 }
 
 extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_grad_io *io, void *stream) {

@@ -78,7 +78,7 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
 }
 
 template <class C, bool TRAIN>
-__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_fwd(MlpFwdArgs a) {
+__device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
     extern __shared__ float4 lds_ring[];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     const float *aux = a.aux, *emb_a = a.emb_a;
     const int32_t *row_index = io.row_index;
     float *outp = io.out;
-    long n_rows, blk = blockIdx.x;
+    long n_rows;
     if (a.cells) {
         // One launch for all cells of a routed evaluation: workgroups are laid out cell after cell, ceil(count_c / rows
         // per workgroup) each; everything below is uniform per workgroup, so the per-cell pointers stay in SGPRs.
@@ -288,17 +288,38 @@ __global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_m
     }
 }
 
-template <class C, bool TRAIN = false>
-static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
-                      hipStream_t stream, float *tape = nullptr, long tape_rows = 0, long tape_row0 = 0,
-                      const mnr_mlp_cell *cells = nullptr, int n_cells = 0) {
+template <class C, bool TRAIN>
+__global__ __launch_bounds__(256, C::TILE == 16 && C::W <= 256 ? 2 : 1) void k_mlp_fwd(MlpFwdArgs a) {
+    mlp_fwd_body<C, TRAIN>(a, blockIdx.x);
+}
+
+// Several independent evaluations (the foreground and the background model of one pass of a training / rendering step) in
+// ONE launch: workgroups [wg0[s], wg0[s+1]) belong to segment s, which runs configuration CA or CB.  The compacted
+// background rows alone fill half the chip at best; side by side with the foreground rows they only lengthen its tail.
+constexpr int MLP_MAX_SEGS = 4;
+struct MlpFwdMulti {
+    MlpFwdArgs seg[MLP_MAX_SEGS];
+    int32_t wg0[MLP_MAX_SEGS + 1];
+    int32_t is_b[MLP_MAX_SEGS];
+    int32_t nseg;
+};
+template <class CA, class CB, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void k_mlp_fwd_multi(MlpFwdMulti m) {
+    const int blk = blockIdx.x;
+    const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
+    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN>(m.seg[s], blk - m.wg0[s]);
+    else mlp_fwd_body<CA, TRAIN>(m.seg[s], blk - m.wg0[s]);
+}
+
+template <class C>
+static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
+                         float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells, int n_cells) {
     // the template's static structure must agree with the runtime layout the packer used
     if (m.tile != C::TILE || m.layer[0].nsteps != C::EX || m.layer[0].gpc != C::GPC || m.has_final != (int)C::HAS_FINAL ||
         m.rgb_in_regs != C::H2 || m.n_mfma_layers != C::NL + (C::HAS_FINAL ? 2 : 0))
         return set_err(MNR_E_INVALID, "internal: kernel template / layout mismatch");
     if (C::HAS_FINAL && m.layer[C::NL + 1].nsteps != C::H + C::ED + C::AP)
         return set_err(MNR_E_INVALID, "internal: dir_a layer layout mismatch");
-    MlpFwdArgs a;
     a.chunks = reinterpret_cast<const float4 *>(packed);
     a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) + (size_t)m.total_chunks * CHUNK_BYTES);
     a.emb_a = d->embedding_a;
@@ -316,6 +337,16 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     a.tape_row0 = tape_row0;
     a.tl = tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
                                 d->appearance_dim, d->rgb_dim, d->mfma_tile});
+    return MNR_OK;
+}
+
+template <class C, bool TRAIN = false>
+static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
+                      hipStream_t stream, float *tape = nullptr, long tape_rows = 0, long tape_row0 = 0,
+                      const mnr_mlp_cell *cells = nullptr, int n_cells = 0) {
+    MlpFwdArgs a;
+    const int rc = fill_fwd_args<C>(a, m, packed, d, io, tape, tape_rows, tape_row0, cells, n_cells);
+    if (rc != MNR_OK) return rc;
     // cells: the worst case (every row routed to every cell); workgroups past the device-side counts exit at once
     const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
@@ -326,6 +357,9 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
 
 }  // namespace mnr
 
+#ifdef MNR_PROBE_TRAIN      // codegen probe (not part of the library): only the foreground training kernel
+template __global__ void mnr::k_mlp_fwd<mnr::MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, true>(mnr::MlpFwdArgs);
+#else
 using namespace mnr;
 
 static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, void *stream,
@@ -461,3 +495,48 @@ extern "C" int mnr_mlp_forward_cells(const mnr_model_desc *d, const mnr_mlp_cell
     MNR_REQUIRE(d && cells_dev && n_cells > 0 && n_cells <= 64 && io, "bad arguments to mnr_mlp_forward_cells");
     return mlp_forward_impl(nullptr, d, io, stream, nullptr, 0, 0, cells_dev, n_cells);
 }
+
+// The foreground / background pair of the reference's default configuration (configs/mega-nerf/*.yaml).
+using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
+using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
+
+static bool desc_is(const mnr_model_desc *d, int xyz) {
+    return d->xyz_dim == xyz && d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 256 &&
+           d->layers == 8 && d->skip_mask == 16 && d->rgb_dim == 3;
+}
+
+extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {
+    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_MAX_SEGS, "1..%d segments per launch", MLP_MAX_SEGS);
+    MlpFwdMulti mm{};
+    const bool train = segs[0].tape_dev != nullptr;
+    long wg = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const mnr_mlp_launch &L = segs[i];
+        MNR_REQUIRE(L.packed_dev && L.desc && L.io && L.io->xyz && L.io->out, "segment %d: NULL pointer argument", i);
+        MNR_REQUIRE((L.tape_dev != nullptr) == train, "segments must be all training or all inference launches");
+        MNR_REQUIRE(!L.io->row_index && !L.io->sigma_only && L.io->apply_sh_deg < 0, "segment %d: gather / sigma_only / SH are single-launch features", i);
+        MNR_REQUIRE(L.io->rows_per_ray >= 1 && L.io->n_rows >= 0, "segment %d: bad row counts", i);
+        MNR_REQUIRE(L.io->dir && L.io->idx && L.desc->embedding_a, "segment %d: dir / idx / embedding_a required", i);
+        if (train) MNR_REQUIRE(L.tape_row0 >= 0 && L.tape_rows >= L.tape_row0 + L.io->n_rows, "segment %d: tape buffer too small", i);
+        ModelLayout m;
+        int rc = layout_from_desc(L.desc, m);
+        if (rc != MNR_OK) return rc;
+        const bool is_fg = desc_is(L.desc, 3) && m.tile == 16, is_bg = desc_is(L.desc, 4) && m.tile == 16;
+        if (!is_fg && !is_bg) return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_forward_multi covers the default 8x256 fg / bg models");
+        rc = is_fg ? fill_fwd_args<CfgFG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0)
+                   : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0);
+        if (rc != MNR_OK) return rc;
+        mm.is_b[i] = is_bg ? 1 : 0;
+        mm.wg0[i] = (int32_t)wg;
+        wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
+        MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
+    }
+    for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
+    mm.nseg = n_segs;
+    if (wg == 0) return MNR_OK;
+    hipStream_t s = as_stream(stream);
+    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    return check_launch("k_mlp_fwd_multi");
+}
+#endif   // MNR_PROBE_TRAIN

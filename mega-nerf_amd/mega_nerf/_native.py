@@ -79,6 +79,18 @@ class MlpGradIO(C.Structure):
                 ('rows_per_unit', C.c_int32), ('work_counter', C.c_void_p), ('grad', ModelGrads), ('dd_in', C.c_void_p)]
 
 
+class MlpLaunch(C.Structure):
+    """struct mnr_mlp_launch"""
+    _fields_ = [('packed_dev', C.c_void_p), ('desc', C.POINTER(ModelDesc)), ('io', C.POINTER(MlpIO)), ('tape_dev', C.c_void_p),
+                ('tape_rows', C.c_int64), ('tape_row0', C.c_int64)]
+
+
+class MlpGradLaunch(C.Structure):
+    """struct mnr_mlp_grad_launch"""
+    _fields_ = [('packed_fwd_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p), ('desc', C.POINTER(ModelDesc)),
+                ('io', C.POINTER(MlpGradIO))]
+
+
 class WgradRegion(C.Structure):
     """struct mnr_wgrad_region"""
     _fields_ = [('desc', C.POINTER(ModelDesc)), ('tape', C.c_void_p), ('gtape', C.c_void_p), ('tape_rows', C.c_int64),
@@ -103,7 +115,7 @@ EXPORTS = [
     'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
     'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
-    'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi',
+    'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -163,6 +175,8 @@ def lib() -> C.CDLL:
         _lib.mnr_mlp_backward_data.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.POINTER(MlpGradIO),
                                                C.c_void_p]
         _lib.mnr_mlp_backward_weights.argtypes = [C.POINTER(ModelDesc), C.POINTER(MlpGradIO), C.c_void_p]
+        _lib.mnr_mlp_forward_multi.argtypes = [C.POINTER(MlpLaunch), C.c_int, C.c_void_p]
+        _lib.mnr_mlp_backward_data_multi.argtypes = [C.POINTER(MlpGradLaunch), C.c_int, C.c_void_p]
         _lib.mnr_wgrad_workspace_bytes.restype = C.c_size_t
         _lib.mnr_wgrad_workspace_bytes.argtypes = []
         _lib.mnr_mlp_backward_weights_multi.argtypes = [C.POINTER(WgradRegion), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]

@@ -278,6 +278,13 @@ class NeRF(nn.Module):
                           _off(dirs, ray0 * dir_stride) if sh else None, dir_stride)
         return out
 
+    def is_default_arch(self) -> bool:
+        """True for the reference's default foreground / background architectures (configs/mega-nerf/*.yaml: 8 x 256, 12 / 4
+        frequency bands, 48-d appearance, skip at 4, rgb head) -- the pair the multi-segment launches are instantiated for."""
+        return (self.xyz_dim in (3, 4) and self.pos_xyz_dim == 12 and self.pos_dir_dim == 4 and self.layers == 8 and
+                list(self.skip_layers) == [4] and self.layer_dim == 256 and self.appearance_dim == 48 and self.rgb_dim == 3 and
+                self.embedding_a is not None and self.affine is None and self.mfma_tile in (0, 16))
+
     def fused_train_supported(self) -> bool:
         """True if the fused training kernels (activation tape + hand-written backward) cover this architecture."""
         if getattr(self, '_fused_train_ok', None) is None:

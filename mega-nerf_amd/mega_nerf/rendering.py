@@ -130,9 +130,78 @@ def _composite(z, raw, n, S, part: _Part, last_delta, zmax_src, flip, depth_real
     return out
 
 
+class _EvalReq:
+    """One MLP pass of a branch, as yielded by :func:`_get_results_gen`: the driver answers with raw [n, S, 4]."""
+
+    def __init__(self, nerf, typ, hparams, xyz, part, S, noise):
+        self.nerf, self.typ, self.hparams, self.xyz, self.part, self.S, self.noise = nerf, typ, hparams, xyz, part, S, noise
+
+
+def _serve(reqs) -> list:
+    """Run the MLP passes the branches are waiting for.  Two default-architecture NeRFs (the foreground and the background
+    model of a render) go out as ONE launch (mnr_mlp_forward_multi): the compacted background rows alone fill half the
+    chip at best, side by side with the foreground's they only lengthen its tail.  Everything else: one launch each."""
+    from mega_nerf.models.nerf import NeRF
+    if len(reqs) > 1 and all(isinstance(q.nerf, NeRF) and q.nerf.is_default_arch() for q in reqs):
+        segs = (N.MlpLaunch * len(reqs))()
+        outs, keep = [], []
+        for sg, q in zip(segs, reqs):
+            n = q.xyz.shape[0]
+            out = _f(n, q.S, 4, device=q.xyz.device)
+            io = q.nerf.mlp_io(q.xyz, q.xyz.shape[-1], q.part.dirs, q.part.dirs.stride(0), q.part.idx, 1, q.S, n * q.S,
+                               out.view(-1, 4), q.noise, q.part.n_units, q.S)
+            desc, packed = q.nerf.packed()
+            keep.append((io, desc, packed))
+            sg.packed_dev, sg.desc, sg.io = packed.data_ptr(), C.pointer(desc), C.pointer(io)
+            outs.append(out)
+
+        def launch():
+            N.check(N.lib().mnr_mlp_forward_multi(segs, len(reqs), N.stream_ptr()))
+        if KERNEL_EVENTS is None:
+            launch()
+        else:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            launch()
+            b.record()
+            KERNEL_EVENTS.append(('fwd_%s' % reqs[0].typ, a, b))
+        return outs
+    return [_model_eval(q.nerf, q.typ, q.hparams, q.xyz, q.part, q.S, q.noise) for q in reqs]
+
+
+def _run_branches(gens) -> list:
+    """Advance the branch generators in lockstep, serving their MLP passes together; returns their result dicts."""
+    results = [None] * len(gens)
+    pending = {}
+    for i, g in enumerate(gens):
+        try:
+            pending[i] = next(g)
+        except StopIteration as e:
+            results[i] = e.value
+    while pending:
+        order = sorted(pending)
+        outs = _serve([pending[i] for i in order])
+        nxt = {}
+        for i, out in zip(order, outs):
+            try:
+                nxt[i] = gens[i].send(out)
+            except StopIteration as e:
+                results[i] = e.value
+        pending = nxt
+    return results
+
+
 def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bool, get_depth_variance: bool,
                  get_bg_lambda: bool, flip: bool, rnd: dict, tag: str) -> Dict[str, torch.Tensor]:
-    """rendering.py:176-248 for one branch.  ``part`` carries z_coarse [n,Sc], xyz_coarse, depth_real, last_delta."""
+    """rendering.py:176-248 for one branch on its own (every MLP pass is its own launch)."""
+    return _run_branches([_get_results_gen(nerf, hparams, part, get_depth, get_depth_variance, get_bg_lambda, flip, rnd, tag)])[0]
+
+
+def _get_results_gen(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bool, get_depth_variance: bool,
+                     get_bg_lambda: bool, flip: bool, rnd: dict, tag: str):
+    """rendering.py:176-248 for one branch as a generator: it yields an :class:`_EvalReq` wherever the reference calls the
+    model and is resumed with the raw output, so that a driver can serve the passes of several branches with one launch.
+    ``part`` carries z_coarse [n,Sc], xyz_coarse, depth_real, last_delta.  Returns (StopIteration.value) the result dict."""
     lib = N.lib()
     dev = part.z.device
     n, Sc = part.z.shape
@@ -148,9 +217,7 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     noise_c = rnd.get(tag + '_noise_coarse') if nerf.training else None
     if nerf.training and noise_c is None:
         noise_c = torch.rand(n * Sc, device=dev)
-    if getattr(part, 'before_coarse', None) is not None:
-        part.before_coarse()
-    raw_c = _model_eval(nerf, 'coarse', hparams, xyz_c, part, Sc, noise_c)
+    raw_c = yield _EvalReq(nerf, 'coarse', hparams, xyz_c, part, Sc, noise_c)
     want = set()
     if Nf > 0:
         want.add('weights')
@@ -210,9 +277,7 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     noise_f = rnd.get(tag + '_noise_fine') if nerf.training else None
     if nerf.training and noise_f is None:
         noise_f = torch.rand(n * nf, device=dev)
-    if getattr(part, 'before_fine', None) is not None:
-        part.before_fine()
-    raw_f = _model_eval(nerf, 'fine', hparams, xyz_f, part, nf, noise_f)
+    raw_f = yield _EvalReq(nerf, 'fine', hparams, xyz_f, part, nf, noise_f)
     if cascade:
         z_m, raw_m, dr_m, Sm = z_f, raw_f, depth_real_f, nf
     else:
@@ -242,22 +307,7 @@ def _get_results(nerf: nn.Module, hparams: Namespace, part: _Part, get_depth: bo
     return results
 
 
-OVERLAP_BG = True          # run the background branch on a side stream (see render_rays_async)
-_side_streams: Dict[str, "torch.cuda.Stream"] = {}
-
-
-def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
-    s = _side_streams.get(str(dev))
-    if s is None:
-        # high priority: the few background workgroups are dispatched ahead of the queued foreground ones, so the
-        # branch finishes inside the foreground coarse pass instead of trailing into the fine pass
-        s = torch.cuda.Stream(device=dev, priority=-1)
-        _side_streams[str(dev)] = s
-    return s
-
-
-def _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd, dev,
-                     before_coarse=None) -> _Part:
+def _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd, dev) -> _Part:
     """Coarse background samples (rendering.py:47-56) for the compacted background rays, on the current stream."""
     lib = N.lib()
     Sb = hparams.coarse_samples // 2
@@ -287,15 +337,7 @@ def _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg,
         return p, d
 
     return _Part(z=bg_z, xyz=bg_pts, depth_real=bg_dr, last_delta=None, n_units=n_bg, dirs=rays_bg[:, 3:6], idx=idx_bg,
-                 points=bg_points, rays=rays_bg, tag='bg', before_coarse=before_coarse)
-
-
-def _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, get_depth,
-                get_depth_variance, rnd, dev, before_coarse=None):
-    """Background branch of render_rays (rendering.py:47-75) on the current stream."""
-    bg_part = _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd,
-                               dev, before_coarse)
-    return _get_results(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg')
+                 points=bg_points, rays=rays_bg, tag='bg')
 
 
 def _empty_results(hparams: Namespace, has_bg: bool, get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool,
@@ -349,10 +391,10 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     if n_rays == 0:
         return _empty_results(hparams, bg_nerf is not None, get_depth, get_depth_variance, get_bg_fg_rgb, dev), None, None
 
-    n_bg = err = bg_slot = bg_join = bg_prologue_done = None
+    n_bg = err = bg_slot = None
     far = None
     last_delta = None
-    bg_results = None
+    gens = []
     if bg_nerf is not None:
         c, r = _host_vec(sphere_center), _host_vec(sphere_radius)
         far, last_delta = _f(n_rays, device=dev), _f(n_rays, device=dev)
@@ -363,19 +405,10 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
         N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
                                   last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
                                   err.data_ptr(), N.stream_ptr()))
-        if n_rays > 0:
-            # The background branch is independent of the foreground until the blend: run it on a side
-            # stream so that its small launches (~13 % of the rays) fill the tail of the foreground waves.
-            main = torch.cuda.current_stream()
-            side = _side_stream(dev) if OVERLAP_BG else main
-            if side is not main:
-                side.wait_stream(main)
-            bg_prologue_done = torch.cuda.Event() if side is not main else None
-            with torch.cuda.stream(side):
-                bg_results = _background(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb,
-                                         c, r, get_depth, get_depth_variance, rnd, dev,
-                                         bg_prologue_done.record if bg_prologue_done is not None else None)
-            bg_join = (side, main) if side is not main else None
+        # The background branch (rendering.py:47-75) is independent of the foreground until the blend.  Both advance pass
+        # by pass on the same stream and every MLP pass is ONE launch over the rows of both (see _serve).
+        bg_part = _background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb, c, r, rnd, dev)
+        gens.append(_get_results_gen(bg_nerf, hparams, bg_part, get_depth, get_depth_variance, False, True, rnd, 'bg'))
 
     # ---- foreground (rendering.py:81-100) ----
     t_c = linspace01(Nc, dev)
@@ -394,22 +427,15 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
         N.check(lib.mnr_fg_points(rays.data_ptr(), n_rays, zf.shape[1], zf.data_ptr(), p.data_ptr(), N.stream_ptr()))
         return p, None
 
-    # Join the background stream before the foreground *fine* pass: the background branch then overlaps the
-    # foreground coarse pass + sampling only, and the dominant launch (fg fine) runs on an otherwise idle GPU.
-    join = (lambda: torch.cuda.current_stream().wait_stream(bg_join[0])) if bg_join is not None else None
-    # ... and hold the foreground coarse launch until the background's tiny prologue kernels have run, so that
-    # they are not stuck behind a GPU full of long-running foreground workgroups.
-    hold = (lambda: torch.cuda.current_stream().wait_event(bg_prologue_done)) if bg_join is not None else None
     fg_part = _Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=dirs,
-                    idx=image_indices, points=fg_points, rays=rays, tag='fg', before_fine=join, before_coarse=hold)
-    results = _get_results(nerf, hparams, fg_part, get_depth, get_depth_variance, bg_nerf is not None, False, rnd, 'fg')
+                    idx=image_indices, points=fg_points, rays=rays, tag='fg')
+    gens.insert(0, _get_results_gen(nerf, hparams, fg_part, get_depth, get_depth_variance, bg_nerf is not None, False, rnd, 'fg'))
+    done = _run_branches(gens)
+    results = done[0]
+    bg_results = done[1] if bg_nerf is not None else None
 
     # ---- fg/bg blend (rendering.py:102-139) ----
     if bg_nerf is not None and n_rays > 0:
-        if bg_join is not None:
-            main.wait_stream(side)
-            for v in bg_results.values():
-                v.record_stream(main)                    # allocated on the side stream, consumed on main
         types = ['fine' if Nf > 0 else 'coarse']
         if hparams.use_cascade and Nf > 0:
             types.append('coarse')

@@ -52,34 +52,69 @@ class _Branch:
     pass
 
 
-def _branch_forward(model, hparams: Namespace, part, flip: bool, get_bg_lambda: bool, rnd: dict, tag: str) -> _Branch:
-    """Training-mode _get_results (rendering.py:176-248, non-cascade, Nf > 0) writing the activation tape."""
+def _multi_ok(*models) -> bool:
+    """True if every model is one of the two default architectures the multi-segment launches cover."""
+    import os
+    if os.environ.get('MNR_NO_MULTI'):
+        return False
+    return all(m is None or getattr(m, 'is_default_arch', lambda: False)() for m in models)
+
+
+def _launch_forward(branches, which: str) -> None:
+    """One training-mode MLP pass (``which`` = 'c' coarse / 'f' fine) of every branch: one launch for all of them when the
+    architectures allow it (the compacted background rows ride along with the foreground's), else one launch each."""
     lib = N.lib()
+    if len(branches) > 1 and _multi_ok(*[b.model for b in branches]):
+        segs = (N.MlpLaunch * len(branches))()
+        keep = []
+        for sg, b in zip(segs, branches):
+            io, row0 = (b.io_c, 0) if which == 'c' else (b.io_f, b.rows_c)
+            desc, packed = b.model.packed()
+            keep.append((desc, packed, io))
+            sg.packed_dev, sg.desc, sg.io = packed.data_ptr(), C.pointer(desc), C.pointer(io)
+            sg.tape_dev, sg.tape_rows, sg.tape_row0 = b.tape.data_ptr(), b.cap, row0
+        _timed('fwd_' + which, lambda: N.check(lib.mnr_mlp_forward_multi(segs, len(branches), N.stream_ptr())))
+        return
+    for b in branches:
+        io, row0 = (b.io_c, 0) if which == 'c' else (b.io_f, b.rows_c)
+        _timed('%s_%s' % (b.part.tag, 'coarse' if which == 'c' else 'fine'), lambda: b.model.evaluate_train(io, b.tape, b.cap, row0))
+
+
+def _branch_begin(model, hparams: Namespace, part, flip: bool, rnd: dict, tag: str) -> _Branch:
+    """Training-mode _get_results (rendering.py:176-248, non-cascade, Nf > 0), stage 1: buffers + the coarse MLP launch
+    description (``b.io_c``).  The activation tape holds the coarse rows, then the fine rows."""
     b = _Branch()
     dev = part.z.device
     n, Sc = part.z.shape
     nf = hparams.fine_samples // 2 if flip else hparams.fine_samples
-    b.n, b.Sc, b.Sf, b.flip, b.part, b.model = n, Sc, nf, flip, part, model
-    nunits = part.n_units.data_ptr() if part.n_units is not None else None
-    rows_c, rows_f = n * Sc, n * nf
-    b.cap = rows_c + rows_f
+    b.n, b.Sc, b.Sf, b.flip, b.part, b.model, b.tag = n, Sc, nf, flip, part, model, tag
+    b.rows_c, b.rows_f = n * Sc, n * nf
+    b.cap = b.rows_c + b.rows_f
     b.tape = _f(b.cap * model.tape_floats_per_row(), device=dev)
     b.raw_all = _f(b.cap, 4, device=dev)                       # coarse rows, then fine rows
-
     xyz_c, z_c = part.xyz, part.z
     if flip:                                                   # rendering.py:271-273
         xyz_c, z_c = xyz_c.flip(1).contiguous(), z_c.flip(1).contiguous()
-    b.z_c = z_c
+    b.z_c, b.xyz_c = z_c, xyz_c
     noise_c = rnd.get(tag + '_noise_coarse') if model.training else None
     if model.training and noise_c is None:
-        noise_c = torch.rand(rows_c, device=dev)
-    dirs, dstride = part.dirs, part.dirs.stride(0)
-    io = model.mlp_io(xyz_c, xyz_c.shape[-1], dirs, dstride, part.idx, 1, Sc, rows_c, b.raw_all[:rows_c], noise_c,
-                      part.n_units, Sc)
-    model.evaluate_train(io, b.tape, b.cap, 0)
-    raw_c = b.raw_all[:rows_c].view(n, Sc, 4)
-    comp = R._composite(z_c, raw_c, n, Sc, part, part.last_delta, part.z, flip, part.depth_real, {'weights'}, dev)
+        noise_c = torch.rand(b.rows_c, device=dev)
+    b.noise_c = noise_c
+    b.io_c = model.mlp_io(xyz_c, xyz_c.shape[-1], part.dirs, part.dirs.stride(0), part.idx, 1, Sc, b.rows_c, b.raw_all[:b.rows_c],
+                          noise_c, part.n_units, Sc)
+    return b
 
+
+def _branch_mid(b: _Branch, hparams: Namespace, rnd: dict) -> None:
+    """Stage 2 (after the coarse MLP pass): importance sampling from the coarse weights, fine points, fine launch
+    description (``b.io_f``)."""
+    lib = N.lib()
+    part, model, tag = b.part, b.model, b.tag
+    dev = part.z.device
+    n, Sc, nf = b.n, b.Sc, b.Sf
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    raw_c = b.raw_all[:b.rows_c].view(n, Sc, 4)
+    comp = R._composite(b.z_c, raw_c, n, Sc, part, part.last_delta, part.z, b.flip, part.depth_real, {'weights'}, dev)
     det = (hparams.perturb if model.training else 0) == 0
     if det:
         u = R.linspace01(nf, dev)
@@ -91,38 +126,46 @@ def _branch_forward(model, hparams: Namespace, part, flip: bool, get_bg_lambda: 
     N.check(lib.mnr_sample_fine(part.z.data_ptr(), comp['weights'].data_ptr(), n, nunits, Sc, nf, int(det), u.data_ptr(),
                                 z_f.data_ptr(), None, N.stream_ptr()))
     b.z_f = z_f
-    xyz_f, dr_f = part.points(z_f)
+    b.xyz_f, b.dr_f = part.points(z_f)
     noise_f = rnd.get(tag + '_noise_fine') if model.training else None
     if model.training and noise_f is None:
-        noise_f = torch.rand(rows_f, device=dev)
-    io = model.mlp_io(xyz_f, xyz_f.shape[-1], dirs, dstride, part.idx, 1, nf, rows_f, b.raw_all[rows_c:], noise_f,
-                      part.n_units, nf)
-    _timed(tag + '_fine', lambda: model.evaluate_train(io, b.tape, b.cap, rows_c))
-    raw_f = b.raw_all[rows_c:].view(n, nf, 4)
+        noise_f = torch.rand(b.rows_f, device=dev)
+    b.noise_f = noise_f
+    b.io_f = model.mlp_io(b.xyz_f, b.xyz_f.shape[-1], part.dirs, part.dirs.stride(0), part.idx, 1, nf, b.rows_f,
+                          b.raw_all[b.rows_c:], noise_f, part.n_units, nf)
 
+
+def _branch_end(b: _Branch, get_bg_lambda: bool) -> None:
+    """Stage 3 (after the fine MLP pass): coarse/fine merge + compositing of the merged samples -> ``b.out``."""
+    lib = N.lib()
+    part = b.part
+    dev = part.z.device
+    n, Sc, nf = b.n, b.Sc, b.Sf
+    nunits = part.n_units.data_ptr() if part.n_units is not None else None
+    raw_c, raw_f = b.raw_all[:b.rows_c].view(n, Sc, 4), b.raw_all[b.rows_c:].view(n, nf, 4)
     Sm = nf + Sc
     b.Sm = Sm
     b.z_m, b.raw_m = _f(n, Sm, device=dev), _f(n, Sm, 4, device=dev)
-    dr_m = _f(n, Sm, device=dev) if dr_f is not None else None
+    dr_m = _f(n, Sm, device=dev) if b.dr_f is not None else None
     b.order = torch.empty(n, Sm, device=dev, dtype=torch.int32)
-    N.check(lib.mnr_merge_sorted(z_f.data_ptr(), raw_f.data_ptr(), N.ptr(dr_f), nf, z_c.data_ptr(), raw_c.data_ptr(),
-                                 N.ptr(part.depth_real), Sc, n, nunits, int(flip), b.z_m.data_ptr(), b.raw_m.data_ptr(),
+    N.check(lib.mnr_merge_sorted(b.z_f.data_ptr(), raw_f.data_ptr(), N.ptr(b.dr_f), nf, b.z_c.data_ptr(), raw_c.data_ptr(),
+                                 N.ptr(part.depth_real), Sc, n, nunits, int(b.flip), b.z_m.data_ptr(), b.raw_m.data_ptr(),
                                  N.ptr(dr_m), b.order.data_ptr(), N.stream_ptr()))
     want = {'rgb', 'depth', 'depth_var'}
     if get_bg_lambda:
         want.add('bg_lambda')
-    b.out = R._composite(b.z_m, b.raw_m, n, Sm, part, part.last_delta, z_f, flip, dr_m, want, dev)
-    return b
+    b.out = R._composite(b.z_m, b.raw_m, n, Sm, part, part.last_delta, b.z_f, b.flip, dr_m, want, dev)
 
 
-def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.Tensor], grads: Dict[str, torch.Tensor]):
-    """d(rgb of this branch) [n,3] (+ d bg_lambda) -> parameter gradients (accumulated into ``grads``)."""
+def _branch_backward_begin(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.Tensor], grads: Dict[str, torch.Tensor]):
+    """Adjoint of stage 3 (compositing + merge) and the launch descriptions of the branch's two data-gradient segments
+    (coarse rows, fine rows) and of its weight-gradient region."""
     lib = N.lib()
     part, model = b.part, b.model
     dev = b.z_m.device
     n, Sc, Sf, Sm = b.n, b.Sc, b.Sf, b.Sm
     nunits = part.n_units.data_ptr() if part.n_units is not None else None
-    rows_c, rows_f = n * Sc, n * Sf
+    rows_c, rows_f = b.rows_c, b.rows_f
     # compositing backward -> gradient of the merged raw outputs
     d_raw_m = _f(n, Sm, 4, device=dev)
     io = N.CompositeGradIO()
@@ -140,7 +183,6 @@ def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.T
     d_raw_all = _f(b.cap, 4, device=dev)
     N.check(lib.mnr_merge_backward(d_raw_m.data_ptr(), b.order.data_ptr(), Sf, Sc, n, nunits,
                                    d_raw_all[rows_c:].data_ptr(), d_raw_all[:rows_c].data_ptr(), N.stream_ptr()))
-    # MLP backward
     desc, packed = model.packed()
     packed_bwd = model.packed_bwd()
     gtape = _f(b.tape.numel(), device=dev)
@@ -165,18 +207,75 @@ def _branch_backward(b: _Branch, d_rgb: torch.Tensor, d_lambda: Optional[torch.T
         g.grad = gs
         return g
 
-    gc, gf = gio(0, rows_c, Sc), gio(rows_c, rows_f, Sf)
-    N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gc), N.stream_ptr()))
-    _timed(part.tag + '_bwd_fine', lambda: N.check(lib.mnr_mlp_backward_data(
-        packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(gf), N.stream_ptr())))
+    b.g_c, b.g_f = gio(0, rows_c, Sc), gio(rows_c, rows_f, Sf)
+    b.g_all = gio(0, b.cap, Sc) if part.n_units is None else None
+    b.bwd_keep = (desc, packed, packed_bwd, gtape, dheads, d_raw_all, d_raw_m, counter)
+    b.aligned = not (Sc % 32 or Sf % 32)
+    rg = N.WgradRegion()
+    rg.desc = C.pointer(desc)
+    rg.tape, rg.gtape, rg.tape_rows = b.tape.data_ptr(), gtape.data_ptr(), b.cap
     if part.n_units is None:
-        # foreground: coarse + fine rows are one dense region of the tape -> a single weight-gradient launch
-        gall = gio(0, b.cap, Sc)
-        _timed(part.tag + '_wgrad', lambda: N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gall),
-                                                                                 N.stream_ptr())))
+        rg.n_ranges = 1                                  # foreground: coarse + fine rows are one dense region of the tape
+        rg.row0[0], rg.n_rows[0] = 0, b.cap
     else:
-        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gc), N.stream_ptr()))
-        N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(gf), N.stream_ptr()))
+        rg.n_ranges = 2                                  # compacted background: device-side row counts per pass
+        rg.row0[0], rg.n_rows[0], rg.n_units_dev[0], rg.rows_per_unit[0] = 0, rows_c, nunits, Sc
+        rg.row0[1], rg.n_rows[1], rg.n_units_dev[1], rg.rows_per_unit[1] = rows_c, rows_f, nunits, Sf
+    rg.grad = gs
+    b.wgrad_region = rg
+
+
+def _launch_backward(branches, dev: torch.device) -> None:
+    """Data-gradient chains of every (branch, pass) segment in one launch, then the weight gradients of every branch in one
+    launch (+ its reduction); per-segment / per-branch launches where the batched kernels do not apply."""
+    lib = N.lib()
+    if _multi_ok(*[b.model for b in branches]):
+        segs = (N.MlpGradLaunch * (2 * len(branches)))()
+        i = 0
+        for b in branches:
+            desc, packed, packed_bwd = b.bwd_keep[:3]
+            for g in (b.g_c, b.g_f):
+                segs[i].packed_fwd_dev, segs[i].packed_bwd_dev = packed.data_ptr(), packed_bwd.data_ptr()
+                segs[i].desc, segs[i].io = C.pointer(desc), C.pointer(g)
+                i += 1
+        _timed('bwd', lambda: N.check(lib.mnr_mlp_backward_data_multi(segs, i, N.stream_ptr())))
+    else:
+        for b in branches:
+            desc, packed, packed_bwd = b.bwd_keep[:3]
+            for g, t in ((b.g_c, 'coarse'), (b.g_f, 'fine')):
+                _timed('%s_bwd_%s' % (b.part.tag, t), lambda: N.check(lib.mnr_mlp_backward_data(
+                    packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(g), N.stream_ptr())))
+    regions = []
+    for b in branches:
+        if b.aligned:
+            regions.append(b.wgrad_region)
+            continue
+        # sample counts that are not multiples of the 32-row tile: per-branch launches with ragged-tile handling
+        desc = b.bwd_keep[0]
+        for g in ([b.g_all] if b.g_all is not None else [b.g_c, b.g_f]):
+            N.check(lib.mnr_mlp_backward_weights(C.byref(desc), C.byref(g), N.stream_ptr()))
+    _weight_gradients(regions, dev, 'wgrad')
+
+
+_WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def _wgrad_workspace(dev: torch.device) -> torch.Tensor:
+    """Scratch of the batched weight-gradient launch (partial-sum slabs), allocated once per device."""
+    ws = _WGRAD_WS.get(dev)
+    if ws is None:
+        ws = _WGRAD_WS[dev] = torch.empty(N.lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def _weight_gradients(regions, dev: torch.device, tag: str = 'wgrad') -> None:
+    """One launch (+ one reduction launch) for the weight gradients of every region (fg + bg of a training step)."""
+    regions = [r for r in regions if r is not None]
+    if not regions:
+        return
+    arr = (N.WgradRegion * len(regions))(*regions)
+    ws = _wgrad_workspace(dev)
+    _timed(tag, lambda: N.check(N.lib().mnr_mlp_backward_weights_multi(arr, len(regions), ws.data_ptr(), ws.numel(), N.stream_ptr())))
 
 
 def _zero_grads(names, params) -> Dict[str, torch.Tensor]:
@@ -225,15 +324,9 @@ class RenderFunction(torch.autograd.Function):
             N.check(lib.mnr_ray_setup(rays.data_ptr(), n_rays, N.host3(c), N.host3(r), far.data_ptr(),
                                       last_delta.data_ptr(), bg_list.data_ptr(), bg_slot.data_ptr(), n_bg.data_ptr(),
                                       err.data_ptr(), N.stream_ptr()))
-            # background branch on the side stream (independent of the foreground until the blend)
-            main = torch.cuda.current_stream()
-            side = R._side_stream(dev) if R.OVERLAP_BG else main
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb,
-                                             c, r, rnd, dev)
-                bgb = _branch_forward(bg_nerf, hparams, bg_part, True, False, rnd, 'bg')
+            bg_part = R._background_part(bg_nerf, nerf, hparams, rays, image_indices, bg_list, n_bg, n_rays, perturb,
+                                         c, r, rnd, dev)
+            bgb = _branch_begin(bg_nerf, hparams, bg_part, True, rnd, 'bg')
         t_c = R.linspace01(Nc, dev)
         prnd = None
         if perturb > 0:
@@ -251,14 +344,20 @@ class RenderFunction(torch.autograd.Function):
 
         fg_part = R._Part(z=z, xyz=xyz, depth_real=None, last_delta=last_delta, n_units=None, dirs=rays[:, 3:6],
                           idx=image_indices, points=fg_points, rays=rays, tag='fg')
-        fgb = _branch_forward(nerf, hparams, fg_part, False, bg_nerf is not None, rnd, 'fg')
+        fgb = _branch_begin(nerf, hparams, fg_part, False, rnd, 'fg')
+        # both branches advance pass by pass on ONE stream; each MLP pass is one launch over the rows of both
+        # (a side stream for the background made its small launches compete with the foreground's for CUs: round 1)
+        branches = [fgb] + ([bgb] if bgb is not None else [])
+        _launch_forward(branches, 'c')
+        for b in branches:
+            _branch_mid(b, hparams, rnd)
+        _launch_forward(branches, 'f')
+        _branch_end(fgb, bg_nerf is not None)
+        if bgb is not None:
+            _branch_end(bgb, False)
         rgb = fgb.out['rgb']
         ctx.fg_rgb_unblended = None
         if bgb is not None:
-            if side is not main:
-                main.wait_stream(side)
-                for v in bgb.out.values():
-                    v.record_stream(main)
             # blend in place (rendering.py:102-131); depth is not part of the training outputs
             N.check(lib.mnr_bg_blend(rgb.data_ptr(), None, fgb.out['bg_lambda'].data_ptr(), bg_slot.data_ptr(),
                                      bgb.out['rgb'].data_ptr(), None, n_rays, None, None, None, None, N.stream_ptr()))
@@ -288,17 +387,9 @@ class RenderFunction(torch.autograd.Function):
             N.check(lib.mnr_bg_blend_backward(d_rgb.data_ptr(), fgb.out['bg_lambda'].data_ptr(), ctx.bg_slot.data_ptr(),
                                               bgb.out['rgb'].data_ptr(), ctx.n_rays, d_lambda.data_ptr(),
                                               d_bg_rgb.data_ptr(), N.stream_ptr()))
-            main = torch.cuda.current_stream()
-            side = R._side_stream(dev) if R.OVERLAP_BG else main
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _branch_backward(bgb, d_bg_rgb, None, grads_bg)
-            _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
-            if side is not main:
-                main.wait_stream(side)
-        else:
-            _branch_backward(fgb, d_rgb, d_lambda, grads_fg)
+            _branch_backward_begin(bgb, d_bg_rgb, None, grads_bg)
+        _branch_backward_begin(fgb, d_rgb, d_lambda, grads_fg)
+        _launch_backward([fgb] + ([bgb] if bgb is not None else []), dev)
         out = [grads_fg[k] for k in ctx.names_fg] + [grads_bg[k] for k in ctx.names_bg]
         return (None,) * 9 + tuple(out)
 
