@@ -7,12 +7,24 @@ JSON line.
 
 Workload (BASELINE.json configs[1]/[2]): "configs/mega-nerf Rubble"-shaped model -- foreground + background
 NeRF, 8 layers x 256 channels, 12/4 frequency bands, 48-d appearance embedding -- on synthetic
-1024-ray x (64 coarse + 128 fine)-sample batches; one spatial submodule per GPU (weak scaling: every rank
-owns a private submodule and its own ray batch; no collective in the data path, one RCCL all-reduce of the
-packed metric vector after the timed region, replacing the reference's file-based gather runner.py:495-510).
-A "step" is one pass of the hot path over one batch: ``--mode eval`` = render_rays forward with the
-validation flags (runner.py:569-578); ``--mode train`` = render_rays + MSE loss + backward + 2x Adam
-(runner.py:246-277).  Inputs are resident in HBM before the timed region.
+1024-ray x (64 coarse + 128 fine)-sample batches.  A "step" is one pass of the hot path over one batch:
+``--mode train`` = render_rays + MSE loss + backward + 2x Adam (runner.py:246-277); ``--mode eval`` =
+render_rays forward with the validation flags (runner.py:569-578).  Inputs are resident in HBM before the
+timed region.
+
+Sharding: the path partitions by spatial submodule, no collective in the data path; the only RCCL
+traffic is one all-reduce of the packed metric vector after the timed region (replacing the reference's
+file-based gather, runner.py:495-510).
+  * default: one private submodule + ray batch per rank (``"scaling": "weak"``, parscripts/run_8.txt);
+  * ``--submodules S``: a fixed set of S submodules (Rubble: 8) dealt to the ranks round-robin, every rank steps
+    through its cells one after the other (``"scaling": "strong"``; --gpus 1 = one GPU trains all S).
+
+The line also carries: ``roofline`` (dominant kernel: live HIP-event duration of its launches, algorithmic FLOPs,
+MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r02_pmc_summary.json``), ``cpu_baseline`` (the
+torch-CPU restatement of the reference on this box's host cores, bounded sample), the north-star PSNR check
+(``psnr``: a student model trained for a few steps here and by the CPU restatement on identical batches and
+random numbers, both evaluated against a fixed teacher field), and (N = 1) short extra measurements: 65 536-ray
+evaluation batches and the reference-default 256+512 samples per ray (opts.py:32-35,75).
 """
 import argparse
 import json
@@ -26,23 +38,26 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: requ
 import torch          # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
-for p in (ROOT, ROOT / 'mega-nerf_amd', ROOT / 'tests', ROOT / 'tests' / 'golden'):
+for p in (ROOT, ROOT / 'mega-nerf_amd'):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
 FG_FLOP_PER_SAMPLE = 1211392      # 2 x 605 696 MAC
 BG_FLOP_PER_SAMPLE = 1236992
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HEAD_FLOP_PER_SAMPLE = 2 * (256 + 3 * 128)          # sigma / rgb heads: VALU, not part of the MFMA kernels' work
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+PMC_FILE = ROOT / 'profiles' / 'r02_pmc_summary.json'
 
 
 def build_models(hp, dev, seed):
-    import common
+    """(model, cfg, numpy state_dict) for the foreground and the background NeRF with seeded weights."""
+    import synthetic_scene as S
     from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
-    A = common.SCENE['appearance_count']
+    A = S.SCENE['appearance_count']
     out = []
     for xyz_dim, s in ((3, seed), (4, seed + 500)):
-        cfg = common.model_cfg(hp, xyz_dim, 256)
-        w = common.make_weights(cfg, A, s)
+        cfg = S.model_cfg(hp, xyz_dim, 256)
+        w = S.make_weights(cfg, A, s)
         m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim,
                  False, A, 3, xyz_dim, ShiftedSoftplus())
         m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
@@ -50,13 +65,133 @@ def build_models(hp, dev, seed):
     return out
 
 
-def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode):
+def usable_cores(cap: int = 32) -> int:
+    """Host threads for the CPU baseline: the affinity mask and the cgroup CPU quota (a container on a 256-thread host may
+    own far fewer), capped -- beyond a few dozen threads these GEMM sizes only thrash."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, cap))
+
+
+# ---- north-star PSNR check: identical student training here and in the CPU restatement -------------------------------
+
+PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS = 24, 192, 512
+
+
+def psnr_problem(hp, all_rays_np):
+    """Seeded teacher / student weights, training batches with their random numbers, held-out test rays (all numpy)."""
+    import numpy as np
+    import synthetic_scene as S
+    rng = np.random.default_rng(20260925)
+    A = S.SCENE['appearance_count']
+    fcfg, bcfg = S.model_cfg(hp, 3, 256), S.model_cfg(hp, 4, 256)
+    teacher = (S.make_weights(fcfg, A, 777), S.make_weights(bcfg, A, 778))
+    for w in teacher:                  # a random-init colour head renders almost uniform grey: give the teacher field contrast
+        w['rgb.weight'] = (w['rgb.weight'] * np.float32(16)).astype(np.float32)
+    student = (S.make_weights(fcfg, A, 901, sharpen=False), S.make_weights(bcfg, A, 902, sharpen=False))
+    perm = rng.permutation(all_rays_np.shape[0])
+    test = np.ascontiguousarray(all_rays_np[perm[:PSNR_TEST_RAYS]])
+    pool = perm[PSNR_TEST_RAYS:]
+    Nc, Nf = hp.coarse_samples, hp.fine_samples
+    batches = []
+    for s in range(PSNR_STEPS):
+        sel = pool[s * PSNR_BATCH:(s + 1) * PSNR_BATCH]
+        B = PSNR_BATCH
+        rnd = {'fg_perturb': rng.random((B, Nc), dtype=np.float32), 'fg_noise_coarse': rng.random(B * Nc, dtype=np.float32),
+               'fg_u': rng.random((B, Nf), dtype=np.float32), 'fg_noise_fine': rng.random(B * Nf, dtype=np.float32),
+               'bg_perturb': rng.random((B, Nc // 2), dtype=np.float32), 'bg_noise_coarse': rng.random(B * (Nc // 2), dtype=np.float32),
+               'bg_u': rng.random((B, Nf // 2), dtype=np.float32), 'bg_noise_fine': rng.random(B * (Nf // 2), dtype=np.float32)}
+        batches.append((np.ascontiguousarray(all_rays_np[sel]), rnd))
+    return dict(fcfg=fcfg, bcfg=bcfg, teacher=teacher, student=student, test=test, batches=batches,
+                idx_train=np.zeros(PSNR_BATCH, np.float32), idx_test=np.zeros(PSNR_TEST_RAYS, np.float32))
+
+
+def _psnr(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))      # metrics.py:8-10
+
+
+def psnr_gpu(hp, prob, dev):
+    """Teacher targets + student training on the MI355X path; returns (psnr_db, targets_train, target_test) as CPU tensors."""
+    import synthetic_scene as S
+    from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
+    from mega_nerf.rendering import render_rays_async
+    from mega_nerf.training import render_rays_train
+    s = S.SCENE
+    A = s['appearance_count']
+    sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
+
+    def mk(cfg, w):
+        m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim, False, A, 3,
+                 cfg.xyz_dim, ShiftedSoftplus())
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        return m.to(dev)
+
+    tf, tb = mk(prob['fcfg'], prob['teacher'][0]).eval(), mk(prob['bcfg'], prob['teacher'][1]).eval()
+    idx_tr, idx_te = torch.from_numpy(prob['idx_train']).to(dev), torch.from_numpy(prob['idx_test']).to(dev)
+    with torch.no_grad():
+        tgt_train = [render_rays_async(tf, tb, torch.from_numpy(r).to(dev), idx_tr, hp, sc, sr, False, False, False)[0]['rgb_fine']
+                     for r, _ in prob['batches']]
+        tgt_test = render_rays_async(tf, tb, torch.from_numpy(prob['test']).to(dev), idx_te, hp, sc, sr, False, False, False)[0]['rgb_fine']
+    sf, sb = mk(prob['fcfg'], prob['student'][0]).train(), mk(prob['bcfg'], prob['student'][1]).train()
+    opts = [torch.optim.Adam(sf.parameters(), lr=5e-4), torch.optim.Adam(sb.parameters(), lr=5e-4)]
+    for (r, rnd), tgt in zip(prob['batches'], tgt_train):
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        res, _, _ = render_rays_train(sf, sb, torch.from_numpy(r).to(dev), idx_tr, hp, sc, sr, False, True, False,
+                                      {k: torch.from_numpy(v).to(dev) for k, v in rnd.items()})
+        torch.nn.functional.mse_loss(res['rgb_fine'], tgt).backward()
+        for o in opts:
+            o.step()
+    sf.eval(), sb.eval()
+    with torch.no_grad():
+        out = render_rays_async(sf, sb, torch.from_numpy(prob['test']).to(dev), idx_te, hp, sc, sr, False, False, False)[0]['rgb_fine']
+    return _psnr(out, tgt_test), [t.cpu() for t in tgt_train], tgt_test.cpu()
+
+
+def psnr_cpu(hp, prob, tgt_train, tgt_test):
+    """The same student training in the torch-CPU restatement of the reference (oracle/torch_oracle.py)."""
+    import synthetic_scene as S
+    from oracle import torch_oracle as TO
+    s = S.SCENE
+    sc, sr = torch.from_numpy(s['sphere_center']), torch.from_numpy(s['sphere_radius'])
+    sf, sb = TO.make_models(hp, prob['fcfg'], prob['student'][0], prob['bcfg'], prob['student'][1], s['appearance_count'])
+    sf.train(), sb.train()
+    opts = [torch.optim.Adam(sf.parameters(), lr=5e-4), torch.optim.Adam(sb.parameters(), lr=5e-4)]
+    idx_tr, idx_te = torch.from_numpy(prob['idx_train']), torch.from_numpy(prob['idx_test'])
+    for (r, rnd), tgt in zip(prob['batches'], tgt_train):
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        res = TO.render_rays(sf, sb, torch.from_numpy(r), idx_tr, hp, sc, sr, {k: torch.from_numpy(v) for k, v in rnd.items()})
+        torch.nn.functional.mse_loss(res['rgb_fine'], tgt).backward()
+        for o in opts:
+            o.step()
+    sf.eval(), sb.eval()
+    with torch.inference_mode():
+        out = TO.render_rays(sf, sb, torch.from_numpy(prob['test']), idx_te, hp, sc, sr)['rgb_fine']
+    return _psnr(out, tgt_test)
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------------
+
+def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode, psnr_job=None):
     """The reference algorithm restated with the same torch CPU ops (oracle/torch_oracle.py, pinned to the golden
     vectors) timed on this box's host cores on a bounded sample of the same batch: forward render for --mode eval,
-    forward + autograd backward + 2x Adam for --mode train (runner.py:246-277)."""
-    import common
+    forward + autograd backward + 2x Adam for --mode train (runner.py:246-277).  Also runs the CPU half of the PSNR
+    check (``psnr_job``) -- the only other place bench.py touches oracle/."""
+    import synthetic_scene as S
     from oracle import torch_oracle as TO
-    s = common.SCENE
+    s = S.SCENE
     cores = usable_cores()
     torch.set_num_threads(cores)
     fg, bg = TO.make_models(hp, fcfg, fw, bcfg, bw, s['appearance_count'])
@@ -86,29 +221,19 @@ def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode
     probe = min(run(32), run(32))
     n = int(max(32, min(n_sample, (5.0 / max(probe / 32, 1e-9)) // 32 * 32)))
     best = probe if n == 32 else min(run(n) for _ in range(2))
-    return {'value': n / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-            'sample': 'torch-CPU restatement of the reference (%s), first %d rays x (64+128) samples of the same batch, '
-                      '%d threads, best of 2 after a 32-ray warm-up' % ('fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n, cores)}
+    out = {'value': n / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
+           'sample': 'torch-CPU restatement of the reference (%s), first %d rays x (%d+%d) samples of the same batch, '
+                     '%d threads, best of 2 after a 32-ray warm-up' % ('fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags',
+                                                                    n, hp.coarse_samples, hp.fine_samples, cores)}
+    if psnr_job is not None:
+        prob, tgt_train, tgt_test = psnr_job
+        t0 = time.perf_counter()
+        out['psnr_db'] = psnr_cpu(hp, prob, tgt_train, tgt_test)
+        out['psnr_seconds'] = round(time.perf_counter() - t0, 1)
+    return out
 
 
-def usable_cores(cap: int = 32) -> int:
-    """Host threads for the CPU baseline: the affinity mask and the cgroup CPU quota (a container on a 256-thread host may
-    own far fewer), capped -- beyond a few dozen threads these GEMM sizes only thrash."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
-            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return max(1, min(n, cap))
-
+# ---- main ------------------------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
@@ -118,7 +243,11 @@ def main():
     ap.add_argument('--mode', choices=['eval', 'train'], default='train',
                     help='train: fwd+bwd+Adam step (BASELINE metric: train rays/s); eval: render_rays forward only')
     ap.add_argument('--rays', type=int, default=1024, help='rays per batch (BASELINE: 1024)')
+    ap.add_argument('--samples', default='64,128', help='coarse,fine samples per ray (BASELINE: 64,128; reference default 256,512)')
+    ap.add_argument('--submodules', type=int, default=0, metavar='S',
+                    help='strong scaling: a fixed set of S submodules dealt round-robin to the ranks (0 = one private submodule per rank)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the N = 1 side measurements and the PSNR check')
     ap.add_argument('--container', type=int, default=0, metavar='N',
                     help='eval mode only: render through a merged N-cell container (MegaNeRF router, boundary_margin 1.15) '
                          'instead of one submodule -- the "8-submodule Rubble" evaluation shape on ONE GPU')
@@ -138,57 +267,71 @@ def main():
         dist.init_process_group('nccl', device_id=dev)            # RCCL on ROCm, communicator bound to this rank's GPU
     assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
 
-    import common                      # tests/golden/common.py: the seeded scene / weight generator (no oracle code)
+    import synthetic_scene as S                    # seeded scene / weight generator (pure numpy; no oracle code)
     from mega_nerf import ray_utils, rendering
+    from mega_nerf.distributed import assign_submodules
     from mega_nerf.opts import get_opts_base
     from mega_nerf.rendering import render_rays_async
+    from mega_nerf.training import TrainStep
 
-    # opts.py defaults = configs/mega-nerf (8x256, 12/4 frequency bands, 48-d appearance) at the benchmark's 64+128 samples
-    hp_o = hp = get_opts_base().parse_args(['--coarse_samples', '64', '--fine_samples', '128'])
-    s = common.SCENE
-    (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp_o, dev, 1000 * (rank + 1))   # one submodule per rank
+    Nc, Nf = [int(v) for v in args.samples.split(',')]
+    # opts.py defaults = configs/mega-nerf (8x256, 12/4 frequency bands, 48-d appearance) at the benchmark's samples per ray
+    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf)])
+    s = S.SCENE
+    sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
+    d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
+    all_rays = ray_utils.get_rays(d, torch.from_numpy(s['c2w']).to(dev), s['near'], s['far'], s['ray_altitude_range']).view(-1, 8)
+
+    def make_batch(seed, n_rays):
+        """synthetic batch: rays of the 400x400 camera by seeded permutation, ~13 % bg rays"""
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        sel = torch.randperm(all_rays.shape[0], generator=g)[:n_rays].to(dev)
+        return (all_rays[sel].contiguous(), torch.randint(0, s['appearance_count'], (n_rays,), generator=g).float().to(dev),
+                torch.rand(n_rays, 3, generator=g).to(dev))
+
+    # the cells this rank owns: one private submodule (weak) or its share of the fixed set (strong)
+    cells = assign_submodules(args.submodules, world)[rank] if args.submodules else [rank]
+    total_cells = args.submodules if args.submodules else world
+    work = []
+    for c in cells:
+        (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp, dev, 1000 * (c + 1))
+        work.append(dict(fg=fg, bg=bg, batch=make_batch(42 + c, args.rays), fcfg=fcfg, bcfg=bcfg, fw=fw, bw=bw))
     if args.container:
-        assert args.mode == 'eval', '--container is an evaluation shape (routed containers are inference-only)'
+        assert args.mode == 'eval' and not args.submodules, '--container is a single-GPU evaluation shape (routed containers are inference-only)'
         from mega_nerf.models.mega_nerf import MegaNeRF
         n = args.container
         g0 = max(1, int(round(n ** 0.5)) if int(round(n ** 0.5)) ** 2 == n else 2)
         g1 = n // g0
         assert g0 * g1 == n, '--container must factor into a grid'
-        cent = torch.stack([torch.zeros(n), torch.linspace(-.45, .45, g0).repeat_interleave(g1),
-                            torch.linspace(-.45, .45, g1).repeat(g0)], 1)
-        cells = [build_models(hp_o, dev, 1000 * (rank + 1) + 7 * j) for j in range(n)]
-        fg = MegaNeRF([c[0][0] for c in cells], cent, hp.boundary_margin, False, False).to(dev)
-        bg = MegaNeRF([c[1][0] for c in cells], cent, hp.boundary_margin, True, False).to(dev)
+        cent = torch.stack([torch.zeros(n), torch.linspace(-.45, .45, g0).repeat_interleave(g1), torch.linspace(-.45, .45, g1).repeat(g0)], 1)
+        sub = [build_models(hp, dev, 1000 * (rank + 1) + 7 * j) for j in range(n)]
+        work[0]['fg'] = MegaNeRF([c[0][0] for c in sub], cent, hp.boundary_margin, False, False).to(dev)
+        work[0]['bg'] = MegaNeRF([c[1][0] for c in sub], cent, hp.boundary_margin, True, False).to(dev)
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
-        args.no_cpu_baseline = True
-    sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
 
-    # synthetic batch: rays of the 400x400 camera, seeded permutation, ~13 % bg rays
-    d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
-    all_rays = ray_utils.get_rays(d, torch.from_numpy(s['c2w']).to(dev), s['near'], s['far'],
-                                  s['ray_altitude_range']).view(-1, 8)
-    g = torch.Generator(device='cpu').manual_seed(42 + rank)
-    sel = torch.randperm(all_rays.shape[0], generator=g)[:args.rays].to(dev)
-    rays = all_rays[sel].contiguous()
-    idx = torch.randint(0, s['appearance_count'], (args.rays,), generator=g).float().to(dev)
-    target = torch.rand(args.rays, 3, generator=g).to(dev)
+    steppers = []
+    for w in work:
+        if args.mode == 'train':
+            w['fg'].train(), w['bg'].train()
+            ts = TrainStep(w['fg'], w['bg'], hp, sc, sr)
+            steppers.append(lambda ts=ts, b=w['batch']: ts(*b))
+        else:
+            w['fg'].eval(), w['bg'].eval()
 
-    if args.mode == 'train':
-        from mega_nerf.training import TrainStep
-        fg.train(), bg.train()
-        stepper = TrainStep(fg, bg, hp, sc, sr)
-        step = lambda: stepper(rays, idx, target)                       # noqa: E731
-    else:
-        fg.eval(), bg.eval()
+            def ev_step(w=w):
+                with torch.no_grad():
+                    return render_rays_async(w['fg'], w['bg'], w['batch'][0], w['batch'][1], hp, sc, sr, True, False, True)
+            steppers.append(ev_step)
 
-        def step():
-            with torch.no_grad():
-                return render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
+    def step():
+        out = None
+        for f in steppers:
+            out = f()
+        return out
 
     for _ in range(args.warmup):
         step()
-    # kernel-level timing of the dominant launch (fg fine MLP: rays x 128 rows) with HIP events recorded on the
-    # launch stream inside the timed region
+    # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed region
     rendering.KERNEL_EVENTS = ev = []
     torch.cuda.synchronize()
     if dist is not None:
@@ -203,99 +346,134 @@ def main():
     dt = time.perf_counter() - t0
     rendering.KERNEL_EVENTS = None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    n_bg = int(out[1]) if (args.mode == 'eval' and out[1] is not None) else -1
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    n_bg = int(out[1]) if out[1] is not None else -1          # background rays in the (last cell's) batch
 
-    # eval metric all-reduce (packed [sum_psnr, count]) -- the only collective of the path
+    # eval metric all-reduce (packed [sum_psnr, count]) -- the only collective of the path.  The targets of the
+    # throughput batches are random colours, so this number only exercises the reduction; the PSNR that means something is
+    # the student-vs-teacher check below.
     with torch.no_grad():
-        res = render_rays_async(fg.eval(), bg.eval(), rays, idx, hp, sc, sr, True, False, True)[0]
-        mse = torch.mean((res['rgb_fine'] - target) ** 2)
-        packed = torch.stack([-10 * torch.log10(mse), torch.ones((), device=dev)]).double()
+        w = work[0]
+        res = render_rays_async(w['fg'].eval(), w['bg'].eval(), w['batch'][0], w['batch'][1], hp, sc, sr, True, False, True)[0]
+        packed = torch.stack([-10 * torch.log10(torch.mean((res['rgb_fine'] - w['batch'][2]) ** 2)), torch.ones((), device=dev)]).double()
     if dist is not None:
         dist.all_reduce(packed)
-    psnr = float(packed[0] / packed[1])
+    metric_reduce_check = float(packed[0] / packed[1])
 
-    # a second, untimed pass of the other mode so that one line carries both halves of the BASELINE metric
-    other = None
-    if rank == 0 or dist is not None:
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and not args.container and not args.submodules and (Nc, Nf) == (64, 128):
+        w = work[0]
+        fgm, bgm = w['fg'], w['bg']
+
+        def timed(fn, reps, warm=2):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps
+
+        def ev_fn(batch, hpx):
+            def f():
+                with torch.no_grad():
+                    render_rays_async(fgm, bgm, batch[0], batch[1], hpx, sc, sr, True, False, True)
+            return f
+
+        fgm.eval(), bgm.eval()
         if args.mode == 'train':
-            fg.eval(), bg.eval()
-            with torch.no_grad():
-                for _ in range(3):
-                    render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    render_rays_async(fg, bg, rays, idx, hp, sc, sr, True, False, True)
-                torch.cuda.synchronize()
-                other = ('eval_rays_per_sec_per_gpu', args.rays * args.steps / (time.perf_counter() - t1))
+            extras['eval_rays_per_sec_per_gpu'] = args.rays / timed(ev_fn(w['batch'], hp), args.steps, 3)
+        big = make_batch(4242, 65536)                                   # image_pixel_batch_size (opts.py:75)
+        extras['eval_rays_per_sec_65536_ray_batches'] = 65536 / timed(ev_fn(big, hp), 3, 1)
+        hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
+        extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
+        fgm.train(), bgm.train()
+        ts_ref = TrainStep(fgm, bgm, hp_ref, sc, sr)
+        extras['train_rays_per_sec_256+512_samples'] = args.rays / timed(lambda: ts_ref(*w['batch']), 5, 4)     # (warm-up: 16 GB of tapes to allocate)
+        del ts_ref
+        # north-star PSNR check, GPU half (the CPU half runs inside cpu_baseline)
+        prob = psnr_problem(hp, all_rays.cpu().numpy())
+        psnr_here, tgt_train, tgt_test = psnr_gpu(hp, prob, dev)
+        extras['_psnr_job'] = (prob, tgt_train, tgt_test)
+        extras['psnr'] = {'student_vs_teacher_db': round(psnr_here, 4),
+                          'protocol': '%d Adam steps of %d rays (training mode: jitter + sigma noise, identical random numbers on both sides), '
+                                      'PSNR of %d held-out rays against a fixed teacher field' % (PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS)}
 
     if rank == 0:
-        total_rays = args.rays * args.steps * world
-        traffic_file = ROOT / 'profiles' / 'hbm_traffic.json'
-        traffic_tab = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
+        total_rays = args.rays * args.steps * total_cells
+        pmc = json.loads(PMC_FILE.read_text()) if PMC_FILE.exists() else {}
+        n_fg_c, n_fg_f = args.rays * Nc, args.rays * Nf
+        n_bg_c, n_bg_f = max(n_bg, 0) * (Nc // 2), max(n_bg, 0) * (Nf // 2)
 
-        def roofline(tag, kernel, flops, key):
-            """tag: one launch tag, or a tuple of tags = every launch of one kernel symbol in a step (then ``flops`` is the
-            mean per launch), so that avg_launch_ms is the same population as the kernel's row in a rocprofv3 trace."""
-            tags = tag if isinstance(tag, tuple) else (tag,)
+        def roofline(tags, kernel, flops, pmc_key):
+            """tags: the event tags of every launch of one kernel symbol in a step (``flops`` = mean per launch), so that
+            avg_launch_ms is the same population as the kernel's row in a rocprofv3 trace."""
             ms = [a.elapsed_time(b) for t, a, b in ev if t in tags]
             if not ms:
                 return None
             avg = sum(ms) / len(ms) * 1e-3
             ach = flops / avg / 1e12
+            p = pmc.get(pmc_key, {})
             return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_tab.get(key), 'kernel': kernel,
-                    'avg_launch_ms': round(avg * 1e3, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': p.get('hbm_bytes_per_launch'),
+                    'mfma_busy': p.get('mfma_busy'), 'kernel': kernel, 'avg_launch_ms': round(avg * 1e3, 4),
+                    'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
-        n_fine, n_all = args.rays * 128, args.rays * 192
-        if args.container:
-            ev = []          # routed launches have data-dependent row counts: no per-kernel roofline for this shape
-        fwd_fine = roofline('fg_fine', 'k_mlp_fwd<fg> (fine pass, %d rows)' % n_fine, n_fine * FG_FLOP_PER_SAMPLE,
-                            'k_mlp_fwd_fg_fine_bytes_per_launch')
-        if args.mode == 'train':
-            # dominant kernel of a training step: the weight-gradient GEMMs of all fg layers in one launch
-            # (algorithmic FLOPs = 2 * rows * sum_l M_l*N_l over the MFMA layers = per-sample forward MACs * 2
-            #  minus the two VALU heads)
-            wgrad_flops = n_all * (FG_FLOP_PER_SAMPLE - 2 * (256 + 3 * 128))
-            roof = roofline('fg_wgrad', 'k_wgrad<true> (fg, %d rows x 13 layer jobs; the only launch of this symbol per step)' % n_all,
-                            wgrad_flops, 'k_wgrad_fg_bytes_per_launch')
-            extra_roof = {'k_mlp_fwd_train_fg_fine': fwd_fine,
-                          'k_mlp_bwd_fg_fine': roofline('fg_bwd_fine', 'k_mlp_bwd<fg> (fine rows)',
-                                                        n_fine * (FG_FLOP_PER_SAMPLE - 2 * 80 * 256 - 2 * (27 * 128)),
-                                                        'k_mlp_bwd_fg_fine_bytes_per_launch')}
-        else:
-            # every launch of the fg forward symbol in a step (coarse 64 + fine 128 samples per ray): the population a
-            # rocprofv3 kernel trace averages over; the fine pass alone is reported beside it
-            n_coarse = args.rays * 64
-            roof = roofline(('fg_coarse', 'fg_fine'), 'k_mlp_fwd<fg, false> (coarse %d + fine %d rows: both launches per step)' % (n_coarse, n_fine),
-                            (n_coarse + n_fine) / 2 * FG_FLOP_PER_SAMPLE, 'k_mlp_fwd_fg_all_bytes_per_launch')
-            extra_roof = {'k_mlp_fwd_fg_fine_only': fwd_fine}
+        mlp = lambda nf_, nb_: nf_ * FG_FLOP_PER_SAMPLE + nb_ * BG_FLOP_PER_SAMPLE                      # noqa: E731
+        mfma_only = lambda nf_, nb_: mlp(nf_, nb_) - (nf_ + nb_) * HEAD_FLOP_PER_SAMPLE                # noqa: E731
+        roof, extra_roof = None, {}
+        if not args.container and (Nc, Nf) == (64, 128):
+            if args.mode == 'train':
+                # The weight-gradient GEMMs of every layer of the fg AND bg model in one launch (algorithmic FLOPs = 2 x rows x
+                # sum_l M_l N_l over the MFMA layers); the dominant kernel round 1 was judged on.
+                roof = roofline(('wgrad',), 'k_wgrad2 (fg %d + bg %d rows, every layer of both models; one launch per step)' % (
+                    n_fg_c + n_fg_f, n_bg_c + n_bg_f), mfma_only(n_fg_c + n_fg_f, n_bg_c + n_bg_f), 'k_wgrad2')
+                bwd_flops = mfma_only(n_fg_c + n_fg_f, n_bg_c + n_bg_f) - (n_fg_c + n_fg_f) * 2 * (75 + 5) * 256 \
+                    - (n_bg_c + n_bg_f) * 2 * (100 + 5) * 256 - (n_fg_c + n_fg_f + n_bg_c + n_bg_f) * 2 * 27 * 128
+                extra_roof = {
+                    'k_mlp_fwd_multi<train> (coarse + fine launch of a step, fg + bg rows)': roofline(
+                        ('fwd_c', 'fwd_f'), 'k_mlp_fwd_multi<fg, bg, true>', mlp(n_fg_c + n_fg_f, n_bg_c + n_bg_f) / 2, 'k_mlp_fwd_multi_train'),
+                    'k_mlp_bwd_multi (all segments of a step)': roofline(('bwd',), 'k_mlp_bwd_multi<fg, bg>', bwd_flops, 'k_mlp_bwd_multi')}
+            else:
+                roof = roofline(('fwd_coarse', 'fwd_fine'), 'k_mlp_fwd_multi<fg, bg, false> (coarse + fine launch of a step, fg + bg rows)',
+                                mlp(n_fg_c + n_fg_f, n_bg_c + n_bg_f) / 2, 'k_mlp_fwd_multi_eval')
+                extra_roof = {'fine launch only': roofline(('fwd_fine',), 'k_mlp_fwd_multi<fg, bg, false>', mlp(n_fg_f, n_bg_f),
+                                                           'k_mlp_fwd_multi_eval_fine')}
         cpu = None
-        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            cpu = cpu_baseline(hp_o, rays.cpu().numpy(), idx.cpu().numpy(), target.cpu().numpy(), fw, bw, fcfg, bcfg,
-                               min(1024, args.rays), args.mode)
+        if not args.no_cpu_baseline and world == 1 and not args.container:          # rank 0 at N = 1 only
+            w = work[0]
+            b = w['batch']
+            cpu = cpu_baseline(hp, b[0].cpu().numpy(), b[1].cpu().numpy(), b[2].cpu().numpy(), w['fw'], w['bw'], w['fcfg'], w['bcfg'],
+                               min(1024, args.rays), args.mode, extras.get('_psnr_job'))
+            if 'psnr' in extras and 'psnr_db' in cpu:
+                extras['psnr']['cpu_restatement_db'] = round(cpu.pop('psnr_db'), 4)
+                extras['psnr']['abs_difference_db'] = round(abs(extras['psnr']['student_vs_teacher_db'] - extras['psnr']['cpu_restatement_db']), 4)
+                extras['psnr']['cpu_seconds'] = cpu.pop('psnr_seconds')
+        extras.pop('_psnr_job', None)
+        if args.container:
+            shard = 'merged %d-cell container (MegaNeRF router, margin 1.15) routed on one GPU' % args.container
+        elif args.submodules:
+            shard = '%d submodules dealt round-robin to %d GPU(s); every GPU steps through its cells' % (args.submodules, world)
+        else:
+            shard = 'one submodule per GPU'
         line = {
             'metric': 'train rays/sec (fwd+bwd+2xAdam step)' if args.mode == 'train' else 'eval rays/sec (render_rays fwd)',
             'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.submodules else 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs/mega-nerf Rubble-shaped fg+bg NeRF (8x256, 12/4 freqs, 48-d appearance), '
-                                   '%d rays x (64+128) samples per step, %s' % (
-                                       args.rays, 'one submodule per GPU' if not args.container else
-                                       'merged %d-cell container (MegaNeRF router, margin 1.15)' % args.container),
-                       'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg,
-                       'parallelism': 'submodule-per-gpu x%d' % world if not args.container else
-                       '%d-cell container routed on one GPU' % args.container},
-            'eval_psnr_vs_random_target_db': round(psnr, 4),
+                                   '%d rays x (%d+%d) samples per submodule step, %s' % (args.rays, Nc, Nf, shard),
+                       'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg, 'submodules': total_cells,
+                       'parallelism': 'submodule-per-gpu x%d' % world if not args.submodules else 'submodules %d over %d gpus' % (args.submodules, world)},
+            'metric_allreduce_check_db': round(metric_reduce_check, 4),
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if extra_roof and any(v is not None for v in extra_roof.values()):
             line['roofline_other_kernels'] = extra_roof
-        if other:
-            line[other[0]] = other[1]
+        line.update(extras)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -85,20 +85,31 @@ def depth2pts_outside(o, d, depth, c, r):
     return torch.cat([pnew, depth.unsqueeze(-1)], -1), depth_real
 
 
-def perturb_z(z, perturb, n):
+def _draw(rnd, key, shape):
+    """torch.rand(shape), or the first rows of the caller-supplied tensor rnd[key] (shared with the product path's
+    ``_randoms`` so that both implementations can be driven with identical random numbers)."""
+    if rnd is not None and key in rnd:
+        n = 1
+        for s_ in shape:
+            n *= s_
+        return rnd[key].reshape(-1)[:n].reshape(shape)
+    return torch.rand(shape)
+
+
+def perturb_z(z, perturb, n, rnd=None, key=None):
     z = z.expand(n, z.shape[-1])
     if perturb > 0:
         mid = 0.5 * (z[:, :-1] + z[:, 1:])
         upper, lower = torch.cat([mid, z[:, -1:]], -1), torch.cat([z[:, :1], mid], -1)
-        z = lower + (upper - lower) * (perturb * torch.rand_like(z))
+        z = lower + (upper - lower) * (perturb * _draw(rnd, key, tuple(z.shape)))
     return z
 
 
-def sample_pdf(bins, weights, n, det):
+def sample_pdf(bins, weights, n, det, rnd=None, key=None):
     w = weights + 1e-8
     cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
     cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
-    u = torch.linspace(0, 1, n).expand(cdf.shape[0], n).contiguous() if det else torch.rand(cdf.shape[0], n)
+    u = torch.linspace(0, 1, n).expand(cdf.shape[0], n).contiguous() if det else _draw(rnd, key, (cdf.shape[0], n)).contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below, above = (inds - 1).clamp_min(0), inds.clamp_max(cdf.shape[1] - 1)
     cb, ca = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
@@ -108,13 +119,15 @@ def sample_pdf(bins, weights, n, det):
     return bb + (u - cb) / denom * (ba - bb)
 
 
-def _eval(model, xyz, dirs, idx, chunk=32768):
+def _eval(model, xyz, dirs, idx, chunk=32768, rnd=None, key=None):
     n, S = xyz.shape[:2]
     x = torch.cat([xyz.reshape(n * S, -1), dirs.repeat(1, S, 1).view(-1, 3), idx.repeat(1, S, 1).view(-1, 1)], 1)
+    noise = _draw(rnd, key, (x.shape[0], 1)) if (model.training and rnd is not None and key in rnd) else None
     outs = []
     for i in range(0, x.shape[0], chunk):
         xc = x[i:i + chunk]
-        outs.append(model(xc, torch.rand(len(xc), 1) if model.training else None))
+        nz = noise[i:i + chunk] if noise is not None else (torch.rand(len(xc), 1) if model.training else None)
+        outs.append(model(xc, nz))
     return torch.cat(outs).view(n, S, 4)
 
 
@@ -133,22 +146,22 @@ def _composite(z, raw, last_delta, flip, depth_src=None):
     return w, rgb, depth, var, lam
 
 
-def _branch(model, hp, o, d, idx, z, xyz, last_delta, flip, depth_real, points_fn):
+def _branch(model, hp, o, d, idx, z, xyz, last_delta, flip, depth_real, points_fn, rnd=None, tag=''):
     perturb = hp.perturb if model.training else 0
     has = last_delta[:, 0] < 1e10
     diff = torch.zeros_like(last_delta)
     if has.any():
         diff[has, 0] = z[has].max(-1)[0]
     xc, zc = (xyz.flip(1), z.flip(1)) if flip else (xyz, z)
-    raw_c = _eval(model, xc, d, idx)
+    raw_c = _eval(model, xc, d, idx, rnd=rnd, key=tag + '_noise_coarse')
     w, *_ = _composite(zc, raw_c, last_delta - diff, flip)
     nf = hp.fine_samples // 2 if flip else hp.fine_samples
-    zf = sample_pdf(0.5 * (z[:, :-1] + z[:, 1:]), w[:, 1:-1].detach(), nf, perturb == 0)
+    zf = sample_pdf(0.5 * (z[:, :-1] + z[:, 1:]), w[:, 1:-1].detach(), nf, perturb == 0, rnd, tag + '_u')
     xf, dr_f = points_fn(zf)
     diff = torch.zeros_like(last_delta)
     if has.any():
         diff[has, 0] = zf[has].max(-1)[0]
-    raw_f = _eval(model, xf, d, idx)
+    raw_f = _eval(model, xf, d, idx, rnd=rnd, key=tag + '_noise_fine')
     zm, order = torch.sort(torch.cat([zf, zc], -1), -1, descending=flip)
     raw_m = torch.gather(torch.cat([raw_f, raw_c], 1), 1, order.unsqueeze(-1).expand(-1, -1, 4))
     dr_m = torch.gather(torch.cat([dr_f, depth_real], 1), 1, order) if depth_real is not None else None
@@ -156,8 +169,10 @@ def _branch(model, hp, o, d, idx, z, xyz, last_delta, flip, depth_real, points_f
     return rgb, depth, var, lam
 
 
-def render_rays(nerf, bg_nerf, rays, image_indices, hp, sphere_center, sphere_radius) -> Dict[str, torch.Tensor]:
-    """fg + bg render (rendering.py:15-139) returning rgb/depth/depth_variance/bg_lambda + fg/bg splits."""
+def render_rays(nerf, bg_nerf, rays, image_indices, hp, sphere_center, sphere_radius, randoms=None) -> Dict[str, torch.Tensor]:
+    """fg + bg render (rendering.py:15-139) returning rgb/depth/depth_variance/bg_lambda + fg/bg splits.
+    ``randoms``: optional dict of pre-drawn uniforms replacing the torch.rand draws of the training mode (keys
+    ``{fg,bg}_{perturb,noise_coarse,u,noise_fine}``: the first rows are used; background rows are the compacted rays)."""
     N = rays.shape[0]
     o, d = rays[:, None, 0:3], rays[:, None, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
@@ -170,15 +185,15 @@ def render_rays(nerf, bg_nerf, rays, image_indices, hp, sphere_center, sphere_ra
     if bgi.numel() > 0:
         last_delta[bgi, 0] = fg_far[bgi]
         far = torch.minimum(far[:, 0], fg_far).unsqueeze(-1)
-        bz = perturb_z(torch.linspace(0, 1, hp.coarse_samples // 2), perturb, bgi.numel())
+        bz = perturb_z(torch.linspace(0, 1, hp.coarse_samples // 2), perturb, bgi.numel(), randoms, 'bg_perturb')
         ob, db = o[bgi], d[bgi]
         pts, dr = depth2pts_outside(ob, db, bz, sphere_center, sphere_radius)
         bg = _branch(bg_nerf, hp, ob, db, idx[bgi], bz, pts, 1e10 * torch.ones(bgi.numel(), 1), True, dr,
-                     lambda zf: depth2pts_outside(ob, db, zf, sphere_center, sphere_radius))
+                     lambda zf: depth2pts_outside(ob, db, zf, sphere_center, sphere_radius), randoms, 'bg')
     t = torch.linspace(0, 1, hp.coarse_samples)
-    z = perturb_z(near * (1 - t) + far * t, perturb, N)
+    z = perturb_z(near * (1 - t) + far * t, perturb, N, randoms, 'fg_perturb')
     rgb, depth, var, lam = _branch(nerf, hp, o, d, idx, z, o + d * z.unsqueeze(-1), last_delta, False, None,
-                                   lambda zf: (o + d * zf.unsqueeze(-1), None))
+                                   lambda zf: (o + d * zf.unsqueeze(-1), None), randoms, 'fg')
     res = {'fg_rgb_fine': rgb, 'fg_depth_fine': depth, 'depth_variance_fine': var, 'bg_lambda_fine': lam}
     bg_rgb, bg_depth = torch.zeros_like(rgb), torch.zeros_like(depth)
     if bg is not None:

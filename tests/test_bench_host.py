@@ -44,6 +44,61 @@ def test_cpu_baseline_is_time_bounded_and_well_formed():
         assert 'rays' in out['sample']
 
 
+def test_submodule_to_rank_mapping_of_the_strong_scaling_mode():
+    """bench.py --submodules S deals cell j to rank j % world (parscripts/run_8.txt: one per GPU at 8 GPUs; Building's 25 cells
+    on 8 GPUs -> 4,3,3,3,3,3,3,3), every cell exactly once, and a cell's seeds (weights 1000 (c+1), batch 42 + c) do not
+    depend on the world size -- so the total work of a step is the same at every N."""
+    from mega_nerf.distributed import assign_submodules
+    for n_cells, world in ((8, 1), (8, 2), (8, 4), (8, 8), (25, 8)):
+        parts = assign_submodules(n_cells, world)
+        assert len(parts) == world and sorted(c for p in parts for c in p) == list(range(n_cells))
+        assert all(c % world == r for r, p in enumerate(parts) for c in p)
+    assert [len(p) for p in assign_submodules(25, 8)] == [4, 3, 3, 3, 3, 3, 3, 3]
+    assert assign_submodules(8, 8) == [[i] for i in range(8)]
+
+
+def test_psnr_protocol_problem_is_seeded_and_disjoint():
+    """The north-star PSNR check (bench.py: psnr_problem / psnr_gpu / psnr_cpu) trains both implementations on the same
+    batches with the same random numbers: the problem must be reproducible and its test rays held out."""
+    b = _bench()
+    from mega_nerf.opts import get_opts_base
+    hp = get_opts_base().parse_args(['--coarse_samples', '64', '--fine_samples', '128'])
+    rays = np.random.default_rng(5).uniform(-1, 1, (20000, 8)).astype(np.float32)
+    p1, p2 = b.psnr_problem(hp, rays), b.psnr_problem(hp, rays)
+    assert len(p1['batches']) == b.PSNR_STEPS and p1['test'].shape == (b.PSNR_TEST_RAYS, 8)
+    for (r1, d1), (r2, d2) in zip(p1['batches'], p2['batches']):
+        assert np.array_equal(r1, r2) and all(np.array_equal(d1[k], d2[k]) for k in d1)
+        assert d1['fg_perturb'].shape == (b.PSNR_BATCH, 64) and d1['bg_u'].shape == (b.PSNR_BATCH, 64) and d1['fg_noise_fine'].shape == (b.PSNR_BATCH * 128,)
+    train_rows = {r.tobytes() for batch, _ in p1['batches'] for r in batch}
+    assert not any(r.tobytes() in train_rows for r in p1['test'])
+    assert not np.array_equal(p1['teacher'][0]['sigma.weight'], p1['student'][0]['sigma.weight'])
+
+
+def test_torch_oracle_accepts_injected_randoms():
+    """oracle/torch_oracle.render_rays with ``randoms`` is deterministic in training mode and differs from another draw."""
+    import torch
+    from oracle import torch_oracle as TO
+    from mega_nerf.opts import get_opts_base
+    hp = get_opts_base().parse_args(['--coarse_samples', '16', '--fine_samples', '16'])
+    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    fg, bg = TO.make_models(hp, fcfg, common.make_weights(fcfg, 100, 1), bcfg, common.make_weights(bcfg, 100, 2), 100)
+    fg.train(), bg.train()
+    g = load('render_fgbg_train')
+    rays, idx = torch.from_numpy(g['rays'][:16]), torch.from_numpy(g['idx'][:16].astype(np.float32))
+    sc, sr = torch.from_numpy(common.SCENE['sphere_center']), torch.from_numpy(common.SCENE['sphere_radius'])
+
+    def rnd(seed):
+        r = np.random.default_rng(seed)
+        return {k: torch.from_numpy(r.random(shape, dtype=np.float32)) for k, shape in
+                (('fg_perturb', (16, 16)), ('fg_noise_coarse', (256,)), ('fg_u', (16, 16)), ('fg_noise_fine', (256,)),
+                 ('bg_perturb', (16, 8)), ('bg_noise_coarse', (128,)), ('bg_u', (16, 8)), ('bg_noise_fine', (128,)))}
+    with torch.no_grad():
+        a = TO.render_rays(fg, bg, rays, idx, hp, sc, sr, rnd(1))['rgb_fine']
+        b = TO.render_rays(fg, bg, rays, idx, hp, sc, sr, rnd(1))['rgb_fine']
+        c = TO.render_rays(fg, bg, rays, idx, hp, sc, sr, rnd(2))['rgb_fine']
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
 def test_reference_config_files_parse():
     """The 1-6 line yaml files under the reference's configs/ (contents restated here) map onto the flag set."""
     import tempfile
