@@ -144,7 +144,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     const long trow = rc + a.tape_row0;          // row in tape space
 
     WStream st;
-    st.g = a.chunks + threadIdx.x;
+    st.g = a.chunks;
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();

@@ -48,15 +48,19 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 struct WStream {
-    const float4 *g;     // this thread's slice of the next chunk to load
+    const float4 *g;     // the next chunk to load (uniform: lives in SGPRs; the lane's 16-byte slot is added as a 32-bit offset)
     float4 *lds;         // base of the 2-chunk LDS ring
     int cur;             // buffer the MFMAs currently read
     __device__ __forceinline__ void issue() {
-        const int wave = threadIdx.x >> 6;
+        // the wave number is forced into an SGPR: the LDS destination (M0) and everything else that is uniform per wave is
+        // then computed on the scalar unit -- VALU instructions inside the MFMA stream cost matrix-pipe issue slots
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;      // wave-uniform base; HW adds lane*16
+        const unsigned lane_off = threadIdx.x * 16u;                // scalar base + 32-bit lane offset: no 64-bit VALU address math
 #pragma unroll
         for (int i = 0; i < CHUNK_F4 / 256; ++i)
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * 256), (lds_void_t *)(dst + i * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(reinterpret_cast<const char *>(g + i * 256) + lane_off),
+                                             (lds_void_t *)(dst + i * 256), 16, 0, 0);
         g += CHUNK_F4;
     }
     // publish the chunk in flight (hipcc drains vmcnt before the barrier), make it current, start the next one
@@ -126,13 +130,17 @@ __device__ __forceinline__ void init_acc(AccT (&acc)[NOB], const float *bias_par
     }
 }
 
+// max(x, 0) as one v_max_i32 on the bit pattern (negative floats are negative integers; -0 -> +0).  fmaxf costs two VALU
+// instructions per element here (IEEE mode first canonicalises its operand), and VALU work inside the MFMA stream is not free.
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 template <int NOB, int RPB, bool RELU, class AccT, int NH>
 __device__ __forceinline__ void acc_to_regs(float (&h)[NH], const AccT (&acc)[NOB]) {
     static_assert(NH >= NOB * RPB, "register array too small");
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-        for (int r = 0; r < RPB; ++r) h[ob * RPB + r] = RELU ? fmaxf(acc[ob][r], 0.f) : acc[ob][r];
+        for (int r = 0; r < RPB; ++r) h[ob * RPB + r] = RELU ? relu_bits(acc[ob][r]) : acc[ob][r];
 }
 
 // Positional encoding of D coordinates into this lane's registers (layout: mlp_layout.h emb_src).

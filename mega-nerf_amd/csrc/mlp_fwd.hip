@@ -120,7 +120,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     const long ray = src / io.rows_per_ray;
 
     WStream st;
-    st.g = chunks + threadIdx.x;
+    st.g = chunks;
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();                                   // chunk 0 in flight while we encode

@@ -53,6 +53,8 @@ def psnr(rgbs: torch.Tensor, target_rgbs: torch.Tensor) -> float:
     """-10 log10(mean squared error) over all elements (metrics.py:8-10); any [..., 3] shape."""
     import math
     flat_p, flat_t = rgbs.reshape(1, -1, 3), target_rgbs.reshape(1, -1, 3)
+    if flat_p.shape[1] == 0:
+        return math.nan                                  # mean over nothing (torch.mean of an empty tensor is nan, too)
     se, _, n = _accumulate(flat_p, flat_t, 1.0, 1, 1.0, 0.01, 0.03)
     mse = se / n
     return -10 * math.log10(mse) if mse > 0 else math.inf

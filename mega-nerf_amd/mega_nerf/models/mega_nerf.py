@@ -57,10 +57,14 @@ class MegaNeRF(nn.Module):
         return self.sub_modules[0].embedding_a
 
     def _centroids_host(self):
-        if self._cent_host is None:
-            c = self.centroids.detach().float().cpu().contiguous().view(-1).tolist()
-            self._cent_host = (C.c_float * len(c))(*c)
-        return self._cent_host
+        """Host copy of the centroid buffer for mnr_route, re-read whenever the buffer was replaced or written
+        (``load_state_dict`` copies in place: version bump; ``.to()`` swaps the storage: pointer change)."""
+        cen = self.centroids
+        key = (cen.data_ptr(), -1 if cen.is_inference() else cen._version)
+        if self._cent_host is None or self._cent_host[0] != key:
+            c = cen.detach().float().cpu().contiguous().view(-1).tolist()
+            self._cent_host = (key, (C.c_float * len(c))(*c))
+        return self._cent_host[1]
 
     def _routed(self, pos: torch.Tensor, pos_stride: int, xyz: torch.Tensor, xyz_stride: int,
                 dirs: Optional[torch.Tensor], dir_stride: int, idx: Optional[torch.Tensor], idx_stride: int,

@@ -43,6 +43,12 @@ class NullTape:
         return None
 
 
+def _version_of(t: torch.Tensor) -> int:
+    """Version counter of a tensor for cache keys; tensors created under ``torch.inference_mode()`` do not track one
+    (reading it raises) and cannot be updated in place either, so a constant is exact for them."""
+    return -1 if t.is_inference() else t._version
+
+
 class FusedTape:
     """One fused training-mode MLP launch (activation tape in HBM) and its hand-written adjoint
     (csrc/mlp_fwd.hip TRAIN variants, csrc/mlp_bwd.hip).  Spherical-harmonics models (rgb_dim > 3, ``sh_deg`` >= 0): the
@@ -203,7 +209,7 @@ class NeRF(nn.Module):
             cache = self._param_cache = (params, ptrs, self.model_desc(), self.mfma_tile)
             self._packed_key = self._packed_bwd_key = None
         desc = cache[2]
-        key = tuple([p._version for p in params])
+        key = tuple([_version_of(p) for p in params])
         if self._packed is None or key != self._packed_key:
             nbytes = N.lib().mnr_packed_model_bytes(C.byref(desc))
             if nbytes == 0:

@@ -52,13 +52,14 @@ def _host_vec(v) -> Optional[list]:
     if not isinstance(v, torch.Tensor):
         return [float(x) for x in v]
     hit = _host_cache.get(id(v))
-    if hit is not None and hit[0]() is v and hit[1] == v._version:
+    ver = -1 if v.is_inference() else v._version          # inference tensors track no version (and cannot change in place)
+    if hit is not None and hit[0]() is v and hit[1] == ver:
         return hit[2]
     if len(_host_cache) > 64:
         for k in [k for k, e in _host_cache.items() if e[0]() is None]:
             del _host_cache[k]
     h = v.detach().float().cpu().tolist()
-    _host_cache[id(v)] = (weakref.ref(v), v._version, h)
+    _host_cache[id(v)] = (weakref.ref(v), ver, h)
     return h
 
 

@@ -119,18 +119,26 @@ class Runner:
 
     # ------------------------------------------------------------------------------------------------
     def train(self):
-        if self.distributed:
-            raise NotImplementedError('one submodule per GPU: launch one single-rank train.py per submodule '
-                                      '(parscripts/run_8.txt); DDP inside a submodule is not provided')
+        # Several ranks on ONE submodule (the reference's DDP + DistributedSampler mode, runner.py:120-129,228-238): every rank
+        # walks the same shuffled epoch and trains on the batches  index % world == rank; gradients are averaged with one
+        # all_reduce per parameter before the optimiser steps, so all ranks hold identical weights.  (The Mega-NeRF layout
+        # proper -- one submodule per GPU, parscripts/run_8.txt -- is N independent single-rank runs and needs none of this.)
+        world = dist.get_world_size() if self.distributed else 1
+        rank = dist.get_rank() if self.distributed else 0
         hp = self.hparams
         self._setup_experiment_dir()
         optimizers = {'nerf': Adam(self.nerf.parameters(), lr=hp.lr)}
         if self.bg_nerf is not None:
             optimizers['bg_nerf'] = Adam(self.bg_nerf.parameters(), lr=hp.lr)
         train_iterations = 0
+        epoch, discard = 0, 0
         if hp.ckpt_path is not None:
             ckpt = torch.load(hp.ckpt_path, map_location='cpu', weights_only=False)
             train_iterations = ckpt['iteration']
+            if hp.resume_ckpt_state:
+                # resume inside the epoch the checkpoint was taken in: same permutation (seeded by the epoch number), the
+                # batches already consumed are skipped (the reference's discard_index, runner.py:213-226)
+                epoch, discard = int(ckpt.get('epoch', 0)), int(ckpt.get('dataset_index', -1)) + 1
             for key, opt in optimizers.items():
                 sd = opt.state_dict()
                 sd.update(ckpt['optimizers'][key])
@@ -161,7 +169,10 @@ class Runner:
             if filesystem and not chunk_ready:
                 dataset.load_chunk()                      # next chunk (prefetched on its own stream by a worker thread)
             chunk_ready = False
-            for dataset_index, item in enumerate(dataset.batches(hp.batch_size)):
+            gen = torch.Generator().manual_seed(int(hp.random_seed) + 1000003 * epoch)     # same shuffle on every rank / after a resume
+            for dataset_index, item in enumerate(dataset.batches(hp.batch_size, gen)):
+                if dataset_index < discard or dataset_index % world != rank:
+                    continue
                 image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)
                 for key, val in metrics.items():
@@ -173,6 +184,17 @@ class Runner:
                 for opt in optimizers.values():
                     opt.zero_grad(set_to_none=True)
                 metrics['loss'].backward()
+                if world > 1:
+                    flag = torch.tensor([1.0 if bg_present else 0.0], device=self.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    bg_present = bool(flag.item() > 0)
+                    for opt in optimizers.values():
+                        for group in opt.param_groups:
+                            for p in group['params']:
+                                if p.grad is None:
+                                    p.grad = torch.zeros_like(p)
+                                dist.all_reduce(p.grad)
+                                p.grad.div_(world)
                 for key, opt in optimizers.items():
                     if key == 'bg_nerf' and not bg_present:
                         continue
@@ -185,13 +207,17 @@ class Runner:
                                                                         float(metrics['loss'].detach())))
                 if self.is_master and train_iterations % hp.ckpt_interval == 0:
                     self._save_checkpoint(optimizers, None, train_iterations, dataset_index,
-                                          dataset.get_state() if filesystem else None)
+                                          dataset.get_state() if filesystem else None, epoch)
                 if train_iterations % hp.val_interval == 0:
                     self._run_validation(train_iterations)
                 if train_iterations >= hp.train_iterations:
                     break
+            else:
+                epoch, discard = epoch + 1, 0           # the epoch ran to its end
+                continue
+            break
         if self.is_master:
-            self._save_checkpoint(optimizers, None, train_iterations, dataset_index, dataset.get_state() if filesystem else None)
+            self._save_checkpoint(optimizers, None, train_iterations, dataset_index, dataset.get_state() if filesystem else None, epoch)
         if hp.cluster_mask_path is None:
             self._write_final_metrics(self._run_validation(train_iterations))
 
@@ -275,7 +301,7 @@ class Runner:
         return total
 
     def _save_checkpoint(self, optimizers: Dict[str, any], scaler, train_index: int, dataset_index: int,
-                         dataset_state: Optional[str]) -> None:
+                         dataset_state: Optional[str], epoch: int = 0) -> None:
         ckpt = {
             'model_state_dict': self.nerf.state_dict(),
             'scaler': {},                                       # fp32 compute: no GradScaler state
@@ -285,6 +311,7 @@ class Runner:
             'np_random_state': np.random.get_state(),
             'random_state': random.getstate(),
             'dataset_index': dataset_index,
+            'epoch': epoch,                                      # (extra key) which shuffle `dataset_index` counts in
         }
         if dataset_state is not None:
             ckpt['dataset_state'] = dataset_state

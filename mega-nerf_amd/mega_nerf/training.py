@@ -670,6 +670,15 @@ def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
                                   'model_utils.py:22-29 loads them as frozen TorchScript)')
     if get_depth or get_bg_fg_rgb:
         raise NotImplementedError('training render returns rgb / depth_variance / bg_lambda only')
+    if rays.shape[0] == 0:
+        # an empty batch renders to empty results (the inference path does the same); the rgb tensor hangs off the
+        # parameters so that loss.backward() still works and leaves zero gradients
+        res = R._empty_results(hparams, bg_nerf is not None, False, get_depth_variance, False, rays.device)
+        anchor = sum(p.sum() for p in list(nerf.parameters())[:1]) * 0
+        for k in list(res):
+            if k.startswith('rgb_'):
+                res[k] = res[k] + anchor
+        return res, None, None
     rnd = _randoms if _randoms is not None else {}
     params = [p for _, p in _param_list(nerf)] + [p for _, p in _param_list(bg_nerf)]
     aux: Dict[str, torch.Tensor] = {}

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box from the repo root):
+#   kernel trace + stats of the default training bench and of the eval bench, then separate --pmc passes
+#   (HBM counters in their own passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).
+# Output: $OUT (default gpurun_out/r02_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r02
+set -u
+OUT=${1:-$PWD/gpurun_out/r02_prof}
+B=$PWD/bench.py
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+for mode in train eval; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$mode" -o t --output-format csv -- \
+      python "$B" --mode $mode --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_${mode}_under_rocprof.json" 2> "$OUT/trace_$mode.err"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_fetch_$mode" -o p --output-format csv -- \
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_fetch_$mode.err"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_write_$mode" -o p --output-format csv -- \
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_write_$mode.err"
+  timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+      --kernel-trace -d "$OUT/pmc_sq_$mode" -o p --output-format csv -- \
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_sq_$mode.err"
+done
+ls "$OUT"

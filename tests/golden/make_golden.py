@@ -251,7 +251,9 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
     if container is not None:
         n_sub = container
         g = int(np.sqrt(n_sub))
-        ys, zs = np.meshgrid(np.linspace(-.5, .5, g), np.linspace(-.5, .5, g), indexing='ij')
+        g2 = n_sub // g                                   # 4 -> 2 x 2, 8 -> 2 x 4 (Rubble's 8-cell grid)
+        assert g * g2 == n_sub
+        ys, zs = np.meshgrid(np.linspace(-.5, .5, g), np.linspace(-.5, .5, g2), indexing='ij')
         cent = np.stack([np.zeros(n_sub), ys.ravel(), zs.ravel()], -1).astype(f32)
         extra['centroids'] = cent
         subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
@@ -353,6 +355,10 @@ def main(only=None):
     case('render_noapp256_train', dict(base, appearance_dim=0), 32, 16, TR, fg_train=True, bg_train=True, with_grad=True)
     case('render_joint_train', dict(base, train_mega_nerf='dummy'), 32, 17, TR, container=4, joint=True, fg_train=True, bg_train=True,
          with_grad=True, layer_dim=64, bg_layer_dim=64)
+    # round 2: the BASELINE "SH-degree-3" wording (rgb_dim 48), an 8-cell container (Rubble) and 512-channel cells (Building)
+    case('render_sh3_eval', dict(base, sh_deg=3, pos_dir_dim=0), 32, 21, E)
+    case('render_container8_eval', dict(base, container_path='dummy'), 48, 22, E, container=8)
+    case('render_container_w512_eval', dict(base, container_path='dummy'), 24, 23, E, container=4, layer_dim=512, bg_layer_dim=512)
     case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
          bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
 
