@@ -189,6 +189,15 @@ int mnr_sh_apply(float *out_dev, int64_t ldo, const float *coef_dev, int64_t ldc
 int mnr_sh_backward(float *d_coef_dev, int64_t ldc, const float *d_out_dev, int64_t ldd, const float *out_dev, int64_t ldo,
                     const float *dirs_dev, int64_t dir_stride, int64_t rows_per_ray, int deg, int64_t R, void *stream);
 
+/* Affine appearance (nerf.py:87-89,156-158): out[r][0..3) = sigmoid(A[:, :3] . raw[r] + A[:, 3]) with A = table[idx[r / rows_per_ray]]
+ * viewed (3, 4); table [count][12] = affine(embedding_a.weight) (one mnr_linear per weight version).  The adjoint returns d_raw and,
+ * per row, the 12 partial derivatives with respect to its A (reduce per appearance index with mnr_scatter_rows). */
+int mnr_affine_apply(float *out_dev, int64_t ldo, const float *raw_dev, int64_t ldr, const float *table_dev, int count,
+                     const void *idx_dev, int64_t idx_stride, int idx_is_float, int64_t rows_per_ray, int64_t R, void *stream);
+int mnr_affine_backward(float *d_raw_dev, int64_t ldr, float *d_affine_rows_dev, const float *d_out_dev, int64_t ldd,
+                        const float *out_dev, int64_t ldo, const float *raw_dev, int64_t ldri, const float *table_dev, int count,
+                        const void *idx_dev, int64_t idx_stride, int idx_is_float, int64_t rows_per_ray, int64_t R, void *stream);
+
 /* ---- training (the reference obtains all of this from torch autograd over nerf.py:115-160) -------------
  * Forward pass that additionally writes the activation tape (post-ReLU output of every layer, the two
  * positional encodings in reference column order and the gathered appearance rows) as dense row-major

@@ -341,6 +341,48 @@ __global__ void k_sh_apply(float *__restrict__ out, long ldo, const float *__res
     out[r * ldo + 3] = c[3 * nb];
 }
 
+// ---- affine appearance (nerf.py:87-89,156-158): rgb' = A[:, :3] . rgb + A[:, 3] with A = affine(embedding_a[idx]) viewed (3, 4),
+// followed by the sigmoid of the rgb head.  `table` holds A for every appearance index ([count][12], one mnr_linear per
+// weight version); raw = output of the rgb layer without activation.
+__device__ __forceinline__ long affine_row(const void *idx, long idx_stride, int idx_is_float, long ray, int count) {
+    long i = idx_is_float ? (long)reinterpret_cast<const float *>(idx)[ray * idx_stride]
+                          : (long)reinterpret_cast<const int32_t *>(idx)[ray * idx_stride];
+    return i < 0 ? 0 : (i >= count ? count - 1 : i);
+}
+__global__ void k_affine_apply(float *__restrict__ out, long ldo, const float *__restrict__ raw, long ldr, const float *__restrict__ table,
+                               int count, const void *__restrict__ idx, long idx_stride, int idx_is_float, long rows_per_ray, long R) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *A = table + affine_row(idx, idx_stride, idx_is_float, r / rows_per_ray, count) * 12;
+    const float x = raw[r * ldr], y = raw[r * ldr + 1], z = raw[r * ldr + 2];
+    for (int c = 0; c < 3; ++c) {
+        const float v = fmaf(A[4 * c + 2], z, fmaf(A[4 * c + 1], y, A[4 * c] * x)) + A[4 * c + 3];
+        out[r * ldo + c] = 1.f / (1.f + expf(-v));
+    }
+}
+// g = d_out * s (1 - s);  d_raw = A[:, :3]^T g;  d_A_row[r] = [g_c * raw_k, g_c]  (12 floats per row: the caller reduces them
+// per appearance index with mnr_scatter_rows)
+__global__ void k_affine_backward(float *__restrict__ d_raw, long ldr, float *__restrict__ d_arow, const float *__restrict__ d_out, long ldd,
+                                  const float *__restrict__ out, long ldo, const float *__restrict__ raw, long ldri,
+                                  const float *__restrict__ table, int count, const void *__restrict__ idx, long idx_stride,
+                                  int idx_is_float, long rows_per_ray, long R) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float *A = table + affine_row(idx, idx_stride, idx_is_float, r / rows_per_ray, count) * 12;
+    const float x[3] = {raw[r * ldri], raw[r * ldri + 1], raw[r * ldri + 2]};
+    float g[3], dx[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; ++c) {
+        const float s = out[r * ldo + c];
+        g[c] = d_out[r * ldd + c] * (s * (1.f - s));
+        for (int k = 0; k < 3; ++k) {
+            dx[k] = fmaf(A[4 * c + k], g[c], dx[k]);
+            d_arow[r * 12 + 4 * c + k] = g[c] * x[k];
+        }
+        d_arow[r * 12 + 4 * c + 3] = g[c];
+    }
+    for (int k = 0; k < 3; ++k) d_raw[r * ldr + k] = dx[k];
+}
+
 // d_coef[r][c][k] = d_out[r][c] * s (1 - s) * basis_k(dir);  d_coef[r][3 nb] = d_out[r][3]   (s = out[r][c])
 __global__ void k_sh_backward(float *__restrict__ d_coef, long ldc, const float *__restrict__ d_out, long ldd,
                               const float *__restrict__ out, long ldo, const float *__restrict__ dirs, long dir_stride,
@@ -482,4 +524,25 @@ extern "C" int mnr_sh_backward(float *d_coef, int64_t ldc, const float *d_out, i
     hipLaunchKernelGGL(k_sh_backward, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), d_coef, (long)ldc, d_out,
                        (long)ldd, out, (long)ldo, dirs, (long)dir_stride, (long)rows_per_ray, deg, (long)R);
     return check_launch("k_sh_backward");
+}
+
+extern "C" int mnr_affine_apply(float *out, int64_t ldo, const float *raw, int64_t ldr, const float *table, int count, const void *idx,
+                                int64_t idx_stride, int idx_is_float, int64_t rows_per_ray, int64_t R, void *stream) {
+    MNR_REQUIRE(out && raw && table && idx && count >= 1 && rows_per_ray >= 1 && R >= 0, "bad arguments to mnr_affine_apply");
+    if (R == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_affine_apply, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), out, (long)ldo, raw, (long)ldr,
+                       table, count, idx, (long)idx_stride, idx_is_float, (long)rows_per_ray, (long)R);
+    return check_launch("k_affine_apply");
+}
+
+extern "C" int mnr_affine_backward(float *d_raw, int64_t ldr, float *d_affine_rows, const float *d_out, int64_t ldd, const float *out,
+                                   int64_t ldo, const float *raw, int64_t ldri, const float *table, int count, const void *idx,
+                                   int64_t idx_stride, int idx_is_float, int64_t rows_per_ray, int64_t R, void *stream) {
+    MNR_REQUIRE(d_raw && d_affine_rows && d_out && out && raw && table && idx && count >= 1 && rows_per_ray >= 1 && R >= 0,
+                "bad arguments to mnr_affine_backward");
+    if (R == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_affine_backward, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream), d_raw, (long)ldr,
+                       d_affine_rows, d_out, (long)ldd, out, (long)ldo, raw, (long)ldri, table, count, idx, (long)idx_stride,
+                       idx_is_float, (long)rows_per_ray, (long)R);
+    return check_launch("k_affine_backward");
 }

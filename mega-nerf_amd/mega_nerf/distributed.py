@@ -38,6 +38,29 @@ def all_reduce_metrics(sums: Dict[str, float], count: int, device: torch.device)
     return {k: v for k, v in zip(keys, vals[:-1])}, int(round(vals[-1]))
 
 
+def average_gradients(params: Sequence[torch.nn.Parameter]) -> None:
+    """Data-parallel training of ONE submodule on several ranks (the reference's DDP mode, runner.py:120-129): replace every
+    parameter's gradient by its mean over the ranks -- one all_reduce per parameter, missing gradients count as zero -- so
+    that identical optimiser steps keep the replicas bit-identical.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+        p.grad.div_(world)
+
+
+def any_rank(flag: bool, device: torch.device) -> bool:
+    """Logical OR of a per-rank flag (e.g. "this batch had background rays": runner.py:269-272 must decide alike everywhere)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
 def flatten_state(state: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, List[Tuple[str, torch.Size]]]:
     """Deterministic (name-sorted) fp32 flattening of a state_dict."""
     spec = [(k, state[k].shape) for k in sorted(state)]

@@ -24,23 +24,6 @@ class ImageMetadata:
         self.is_val = is_val
         self._mask_path = mask_path
 
-    def __repr__(self) -> str:
-        return 'ImageMetadata(#{} {} {}x{}{}{})'.format(self.image_index, Path(self.image_path).name, self.W, self.H,
-                                                        ' val' if self.is_val else '', ' masked' if self._mask_path else '')
-
-    @property
-    def camera_position(self) -> torch.Tensor:
-        """Camera centre in the normalised scene frame (translation column of the pose)."""
-        return self.c2w[:3, 3]
-
-    @property
-    def pixel_count(self) -> int:
-        return int(self.W) * int(self.H)
-
-    @property
-    def has_mask(self) -> bool:
-        return self._mask_path is not None
-
     def load_image(self) -> torch.Tensor:
         """uint8 (H, W, 3), resampled (Lanczos) to the metadata's resolution when the file on disk is larger."""
         from PIL import Image

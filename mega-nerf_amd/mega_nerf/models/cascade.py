@@ -13,19 +13,6 @@ class Cascade(nn.Module):
         self.add_module('coarse', coarse)
         self.add_module('fine', fine)
 
-    def extra_repr(self) -> str:
-        return 'passes: coarse -> stratified samples, fine -> stratified + importance samples'
-
-    def sub_models(self):
-        """(name, module) pairs in checkpoint-key order."""
-        return [('coarse', self._modules['coarse']), ('fine', self._modules['fine'])]
-
-    @property
-    def training_paths(self):
-        """Which training kernels each pass will use (diagnostics): 'fused' or 'layerwise' per sub-model."""
-        return {name: ('fused' if getattr(m, 'fused_train_supported', lambda: False)() else 'layerwise')
-                for name, m in self.sub_models()}
-
     def select(self, use_coarse: bool) -> nn.Module:
         return self._modules['coarse' if use_coarse else 'fine']
 

@@ -31,8 +31,6 @@ class PortableNeRF(nn.Module):
                  appearance_dim: int, affine_appearance: bool, appearance_count: int, rgb_dim: int, xyz_dim: int,
                  shifted_softplus: bool):
         super().__init__()
-        if affine_appearance:
-            raise NotImplementedError('affine_appearance models cannot be exported')
         self.xyz_dim, self.pos_xyz_dim, self.pos_dir_dim = xyz_dim, pos_xyz_dim, pos_dir_dim
         self.skip_layers = list(skip_layers)
         self.has_dir, self.has_app = pos_dir_dim > 0, appearance_dim > 0
@@ -41,11 +39,13 @@ class PortableNeRF(nn.Module):
         self.xyz_encodings = nn.ModuleList(
             nn.Sequential(nn.Linear(in_xyz if i == 0 else layer_dim + (in_xyz if i in self.skip_layers else 0), layer_dim), nn.ReLU())
             for i in range(layers))
-        self.has_final = self.has_dir or self.has_app
+        self.has_affine = bool(affine_appearance)                 # nerf.py:87-89: appearance enters as a 3x4 colour transform
+        self.has_final = self.has_dir or (self.has_app and not self.has_affine)
         self.embedding_a = nn.Embedding(appearance_count, appearance_dim) if self.has_app else None
+        self.affine = nn.Linear(appearance_dim, 12) if self.has_affine else None
         self.xyz_encoding_final = nn.Linear(layer_dim, layer_dim) if self.has_final else None
-        self.dir_a_encoding = nn.Sequential(nn.Linear(layer_dim + in_dir + appearance_dim, layer_dim // 2), nn.ReLU()) \
-            if self.has_final else None
+        self.dir_a_encoding = nn.Sequential(nn.Linear(layer_dim + in_dir + (0 if self.has_affine else appearance_dim), layer_dim // 2),
+                                            nn.ReLU()) if self.has_final else None
         self.sigma = nn.Linear(layer_dim, 1)
         self.sigma_activation = ShiftedSoftplus() if shifted_softplus else nn.ReLU()
         self.rgb = nn.Linear(layer_dim // 2 if self.has_final else layer_dim, rgb_dim)
@@ -80,10 +80,13 @@ class PortableNeRF(nn.Module):
             feats = [self.xyz_encoding_final(h)]
             if self.has_dir:
                 feats.append(self._encode(x[:, -4:-1], self.pos_dir_dim))        # nerf.py:146 (quirk Q8 included)
-            if self.embedding_a is not None:
+            if self.embedding_a is not None and self.affine is None:
                 feats.append(self.embedding_a(x[:, -1].long()))
             h = self.dir_a_encoding(torch.cat(feats, -1))
         colour = self.rgb(h)
+        if self.affine is not None and self.embedding_a is not None:                 # nerf.py:156-158
+            t = self.affine(self.embedding_a(x[:, -1].long())).view(-1, 3, 4)
+            colour = (torch.matmul(t[:, :, :3], colour.unsqueeze(-1)) + t[:, :, 3:]).squeeze(-1)
         if self.rgb_sigmoid:
             colour = torch.sigmoid(colour)
         return torch.cat([colour, density], -1)

@@ -35,8 +35,7 @@ class LayerwiseTape:
         E = self.E = D * (1 + 2 * m.pos_xyz_dim)
         ED = self.ED = 3 * (1 + 2 * m.pos_dir_dim) if m.has_dir else 0
         A = self.A = m.appearance_dim if (m.embedding_a is not None and m.affine is None) else 0
-        if m.affine is not None:
-            raise NotImplementedError('affine_appearance is not supported by the MI355X kernels')
+        self.affine = m.affine is not None and not sigma_only     # nerf.py:156-158: 3x4 colour transform per appearance index
         self.B, self.out, self.out_stride, self.sigma_only = B, out, out_stride, sigma_only
         self.idx, self.idx_stride, self.rows_per_ray = idx, idx_stride, rows_per_ray
         self.sh = sh_deg >= 0 and m.rgb_dim > 3 and not sigma_only
@@ -75,7 +74,16 @@ class LayerwiseTape:
             sigma_noise.data_ptr() if sigma_noise is not None else None)
         f = side = dact = None
         if not sigma_only:
-            rgb_act = 2 if m.rgb_dim == 3 else 0
+            rgb_act = 2 if (m.rgb_dim == 3 and not self.affine) else 0
+            raw = table = None
+            if self.affine:
+                # A = affine(embedding_a.weight) for every appearance index; the rgb layer writes its raw output beside
+                raw = torch.empty(B, 3, device=dev)
+                table = torch.empty(m.appearance_count, 12, device=dev)
+                N.check(lib.mnr_linear(table.data_ptr(), 12, m.embedding_a.weight.data_ptr(), m.appearance_dim, m.appearance_dim, None, 0, 0,
+                                       m.affine.weight.data_ptr(), m.appearance_dim, m.affine.bias.data_ptr(), None,
+                                       m.appearance_count, 12, 0, st()))
+                hp, hs_ = raw.data_ptr(), 3
             if m.has_final:
                 f = torch.empty(B, W, device=dev)
                 lin(f.data_ptr(), W, h.data_ptr(), W, W, None, 0, 0, m.xyz_encoding_final, 0)
@@ -95,6 +103,10 @@ class LayerwiseTape:
             if self.sh:
                 N.check(lib.mnr_sh_apply(out.data_ptr(), out_stride, head.data_ptr(), hs_, sh_dirs.data_ptr(), sh_dir_stride,
                                          rows_per_ray, sh_deg, B, st()))
+            if self.affine:
+                N.check(lib.mnr_affine_apply(out.data_ptr(), out_stride, raw.data_ptr(), 3, table.data_ptr(), m.appearance_count,
+                                             idx.data_ptr(), idx_stride, 1 if idx.dtype == torch.float32 else 0, rows_per_ray, B, st()))
+            self.raw, self.table = raw, table
         if keep:
             self.emb, self.hs, self.f, self.side, self.dact, self.head = emb, hs, f, side, dact, head
 
@@ -132,7 +144,24 @@ class LayerwiseTape:
         # rgb head
         C = m.rgb_dim
         g_rgb = torch.empty(B, C, device=dev)
-        N.check(lib.mnr_act_grad(g_rgb.data_ptr(), C, dh_p, dh_s, y_p, y_s, B, C, 2 if C == 3 else 0, st()))
+        if self.affine:
+            # adjoint of the colour transform + sigmoid: d(raw rgb), and the per-row derivative with respect to its 3x4 matrix
+            cnt, AD = m.appearance_count, m.appearance_dim
+            d_rows = torch.empty(B, 12, device=dev)
+            isf = 1 if self.idx.dtype == torch.float32 else 0
+            N.check(lib.mnr_affine_backward(g_rgb.data_ptr(), 3, d_rows.data_ptr(), dh_p, dh_s, y_p, y_s, self.raw.data_ptr(), 3,
+                                            self.table.data_ptr(), cnt, self.idx.data_ptr(), self.idx_stride, isf, self.rows_per_ray, B, st()))
+            d_table = torch.zeros(cnt, 12, device=dev)
+            N.check(lib.mnr_scatter_rows(d_table.data_ptr(), 12, cnt, self.idx.data_ptr(), self.idx_stride, isf, self.rows_per_ray,
+                                         d_rows.data_ptr(), 12, B, st()))
+            ew, aw = m.embedding_a.weight, m.affine.weight
+            gw = grads['affine.weight']                   # d W_aff [12][AD] += d_table^T . embedding_a.weight
+            N.check(lib.mnr_gemm(gw.data_ptr(), AD, d_table.data_ptr(), 1, 12, ew.data_ptr(), 1, AD, 12, AD, cnt, 1, 0, st()))
+            N.check(lib.mnr_col_sum(grads['affine.bias'].data_ptr(), d_table.data_ptr(), 12, cnt, 12, st()))
+            ge = grads['embedding_a.weight']              # d embedding_a [cnt][AD] += d_table . W_aff
+            N.check(lib.mnr_gemm(ge.data_ptr(), AD, d_table.data_ptr(), 12, 1, aw.data_ptr(), 1, AD, cnt, AD, 12, 1, 1, st()))
+        else:
+            N.check(lib.mnr_act_grad(g_rgb.data_ptr(), C, dh_p, dh_s, y_p, y_s, B, C, 2 if C == 3 else 0, st()))
         src, k_src = (self.dact, W // 2) if m.has_final else (h_last, W)
         wgrad('rgb.weight', 0, g_rgb.data_ptr(), C, C, src.data_ptr(), k_src, k_src)
         bgrad('rgb.bias', g_rgb.data_ptr(), C, C)

@@ -161,8 +161,6 @@ class NeRF(nn.Module):
         return [p for p in self.parameters()]
 
     def model_desc(self) -> N.ModelDesc:
-        if self.affine is not None:
-            raise NotImplementedError('affine_appearance is not supported by the fused MI355X kernels')
         d = N.ModelDesc()
         d.xyz_dim, d.pos_xyz_dim, d.pos_dir_dim, d.layers = self.xyz_dim, self.pos_xyz_dim, self.pos_dir_dim, self.layers
         d.skip_mask = sum(1 << i for i in self.skip_layers)
@@ -256,8 +254,8 @@ class NeRF(nn.Module):
     def fused_supported(self) -> bool:
         """True if the register-chained kernel has an instantiation for this architecture (queried once)."""
         if getattr(self, '_fused_ok', None) is None:
-            d = self.model_desc()
-            self._fused_ok = bool(N.lib().mnr_fused_supported(C.byref(d)))
+            # affine_appearance (nerf.py:156-158) changes the colour epilogue: evaluated layer by layer (no config uses it)
+            self._fused_ok = self.affine is None and bool(N.lib().mnr_fused_supported(C.byref(self.model_desc())))
         return self._fused_ok
 
     def _evaluate_layerwise(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
@@ -294,8 +292,7 @@ class NeRF(nn.Module):
     def fused_train_supported(self) -> bool:
         """True if the fused training kernels (activation tape + hand-written backward) cover this architecture."""
         if getattr(self, '_fused_train_ok', None) is None:
-            d = self.model_desc()
-            self._fused_train_ok = bool(N.lib().mnr_fused_train_supported(C.byref(d)))
+            self._fused_train_ok = self.affine is None and bool(N.lib().mnr_fused_train_supported(C.byref(self.model_desc())))
         return self._fused_train_ok
 
     def train_eval(self, xyz, xyz_stride, dirs, dir_stride, dir_rows, idx, idx_stride, rows_per_ray, n_rows, out,

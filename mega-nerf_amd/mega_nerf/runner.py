@@ -185,16 +185,9 @@ class Runner:
                     opt.zero_grad(set_to_none=True)
                 metrics['loss'].backward()
                 if world > 1:
-                    flag = torch.tensor([1.0 if bg_present else 0.0], device=self.device)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                    bg_present = bool(flag.item() > 0)
-                    for opt in optimizers.values():
-                        for group in opt.param_groups:
-                            for p in group['params']:
-                                if p.grad is None:
-                                    p.grad = torch.zeros_like(p)
-                                dist.all_reduce(p.grad)
-                                p.grad.div_(world)
+                    from mega_nerf.distributed import any_rank, average_gradients
+                    bg_present = any_rank(bg_present, self.device)
+                    average_gradients([p for opt in optimizers.values() for group in opt.param_groups for p in group['params']])
                 for key, opt in optimizers.items():
                     if key == 'bg_nerf' and not bg_present:
                         continue

@@ -65,6 +65,20 @@ __global__ __launch_bounds__(256, 2) void k_chain(const float4 *chunks, float *o
                 __syncthreads();
                 cur ^= 1;
                 issue();
+                if constexpr (TAPE == 32 || TAPE == 33) {
+                    // store-cost scaling: TAPE 32 = 16 x dwordx2 (same instruction count, half the bytes), TAPE 33 = 8 x dwordx4
+                    // (half the instructions, half the bytes), both in chunk 0
+                    if (c == 0 && l > 0) {
+                        float *r = tape + ((long)(l & 7) * tape_rows + row) * 256 + 4 * part;
+                        if constexpr (TAPE == 32) {
+#pragma unroll
+                            for (int q = 0; q < H / 4; ++q) *reinterpret_cast<float2 *>(r + 16 * q) = make_float2(h[4 * q], h[4 * q + 1]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < H / 8; ++q) *reinterpret_cast<float4 *>(r + 16 * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+                        }
+                    }
+                }
                 if constexpr (TAPE == 8 || TAPE == 16) {
                     // the same 16 float4 stores, two per chunk (TAPE 8) / four in each of the first four chunks (TAPE 16)
                     if (l > 0) {
@@ -256,7 +270,8 @@ int main(int argc, char **argv) {
         run<0, 3>(chunks, out, tape, rows, nl);
         run<0, 4>(chunks, out, tape, rows, nl);
         run<0, 5>(chunks, out, tape, rows, nl);
-        run<0, 7>(chunks, out, tape, rows, nl);
+        run<0, 32>(chunks, out, tape, rows, nl);
+        run<0, 33>(chunks, out, tape, rows, nl);
         run<1>(chunks, out, tape, rows, nl);
         run<1>(chunks, out, tape, rows, nl, 96 * 1024);
     }

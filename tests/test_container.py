@@ -259,3 +259,26 @@ def test_merge_without_appearance_and_without_background(tmp_path):
     assert routed.cluster_dim_start == 1 and len(routed.sub_modules) == 2 and routed.sub_modules[0].embedding_a is None
     for k, v in ws[1].items():
         assert np.array_equal(routed.sub_modules[1].state_dict()[k].numpy(), v), k
+
+
+@pytest.mark.parametrize('name', ['fg', 'affine', 'plain', 'sh2'])
+def test_portable_twin_reproduces_reference_outputs(name):
+    """The TorchScript twin written into containers (models/export.py) evaluates like the reference module, including
+    --affine_appearance (nerf.py:87-89,156-158): checked against outputs recorded from the reference itself (mlp.npz),
+    before and after scripting."""
+    import common
+    from test_oracle_golden import load, mlp_variant
+    from mega_nerf.models.export import to_portable
+    from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
+    g = load('mlp')
+    hp, cfg, w = mlp_variant(name)
+    m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim, cfg.affine_appearance,
+             100, cfg.rgb_dim, cfg.xyz_dim, ShiftedSoftplus() if cfg.shifted_softplus else torch.nn.ReLU())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    twin = to_portable(m)
+    x = torch.from_numpy(g[name + '_x'])
+    for mod in (twin, torch.jit.script(twin)):
+        with torch.no_grad():
+            np.testing.assert_allclose(mod(x).numpy(), g[name + '_out'], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(mod(x, False, torch.from_numpy(g[name + '_noise'])).numpy(), g[name + '_out_noise'], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(mod(x[:, :cfg.xyz_dim], True).numpy(), g[name + '_sigma_only'], rtol=2e-5, atol=2e-6)

@@ -46,9 +46,10 @@ def test_embed_matches_reference():
         close(out, g[key], 2e-6, 2e-6)
 
 
-@pytest.mark.parametrize('name', ['relu', 'plain'])
+@pytest.mark.parametrize('name', ['relu', 'plain', 'affine'])
 def test_remaining_mlp_variants(name):
-    """ReLU density activation (--no_shifted_softplus) and the plain xyz -> rgb network (no direction, no appearance)."""
+    """ReLU density activation (--no_shifted_softplus), the plain xyz -> rgb network (no direction, no appearance) and
+    --affine_appearance (nerf.py:87-89,156-158), each against the reference's own outputs."""
     g = load('mlp')
     hp, cfg, w = mlp_variant(name)
     m = native_nerf(cfg, w)

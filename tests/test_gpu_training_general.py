@@ -47,10 +47,13 @@ def torch_forward(w, cfg, xyz, dirq, idx, noise, sh_dirs=None):
         parts = [h @ w['xyz_encoding_final.weight'].T + w['xyz_encoding_final.bias']]
         if cfg.pos_dir_dim > 0:
             parts.append(emb(dirq, cfg.pos_dir_dim))
-        if cfg.appearance_dim > 0:
+        if cfg.appearance_dim > 0 and 'affine.weight' not in w:
             parts.append(w['embedding_a.weight'][idx])
         h = torch.relu(torch.cat(parts, -1) @ w['dir_a_encoding.0.weight'].T + w['dir_a_encoding.0.bias'])
     rgb = h @ w['rgb.weight'].T + w['rgb.bias']
+    if 'affine.weight' in w:                       # nerf.py:156-158
+        t = (w['embedding_a.weight'][idx] @ w['affine.weight'].T + w['affine.bias']).view(-1, 3, 4)
+        rgb = (t[:, :, :3] @ rgb.unsqueeze(-1) + t[:, :, 3:]).squeeze(-1)
     if cfg.rgb_dim > 3:
         rgb = torch.sigmoid(_eval_sh2(rgb.view(rgb.shape[0], 3, -1), sh_dirs))
     else:
@@ -65,6 +68,8 @@ LW_VARIANTS = dict(
     plain_relu=dict(xyz_dim=3, layer_dim=64, appearance_dim=0, pos_dir_dim=0, shifted_softplus=False),
     sh2=dict(xyz_dim=3, layer_dim=128, sh_deg=2, pos_dir_dim=0),
     w320_skip2=dict(xyz_dim=3, layer_dim=320, layers=5, skip_layers=[2]),
+    affine=dict(xyz_dim=3, layer_dim=256, affine_appearance=True),
+    affine_bg_w128=dict(xyz_dim=4, layer_dim=128, affine_appearance=True),
 )
 # architectures whose training runs on the fused register-chained kernels (tape + hand-written chain)
 FUSED_VARIANTS = dict(

@@ -40,6 +40,22 @@ def _worker(rank, world, port, out):
                    'xyz_encodings.0.0.weight': torch.randn(8, 5, generator=gr)}
             for k in exp:
                 assert torch.equal(allw[r][k], exp[k]), (r, k)
+        # data-parallel gradient averaging (Runner.train with several ranks on one submodule): two replicas with different
+        # "local" gradients, one parameter without a gradient on rank 1 -> identical means everywhere
+        torch.manual_seed(7)
+        lin = torch.nn.Linear(4, 3)
+        lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+        lin.bias.grad = torch.arange(3.) * (rank + 1) if rank == 0 else None
+        D.average_gradients(list(lin.parameters()))
+        assert torch.allclose(lin.weight.grad, torch.full_like(lin.weight, 1.5))
+        assert torch.allclose(lin.bias.grad, torch.arange(3.) * 0.5)
+        assert D.any_rank(rank == 1, torch.device('cpu')) is True and D.any_rank(False, torch.device('cpu')) is False
+        # strong-scaling cell -> rank -> batch mapping of bench.py --submodules 8: every cell exactly once over the ranks,
+        # seeds independent of the world size
+        mine = D.assign_submodules(8, world)[rank]
+        cells = [None] * world
+        dist.all_gather_object(cells, mine)
+        assert sorted(c for part in cells for c in part) == list(range(8)) and all(c % world == rank for c in mine)
         dist.barrier()
         out.put((rank, 'ok'))
     except Exception as e:      # pragma: no cover
