@@ -122,6 +122,7 @@ struct WArgs {
     int32_t *ep_job;                // [W2_MAX_EPISODES]
     float *slab;                    // [W2_MAX_EPISODES][W2_EP_FLOATS]
     long long *prof;                // optional [grid][8] cycle accumulators (MNR_WGRAD_PROF diagnostics), else NULL
+    int32_t max_episodes;           // slab slots in use (<= W2_MAX_EPISODES; tests lower it to exercise the atomic fallback)
 };
 
 // ---- small asm helpers: LDS accesses the compiler must not see (it would drain the LDS-DMA queue before each of them) ---
@@ -340,7 +341,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
     if (threadIdx.x == 0) lds_st_i(ctl + 4 * (WCtl::MAILBOX + 2), ep);
     __builtin_amdgcn_s_barrier();
     ep = lds_ld_u(ctl + 4 * (WCtl::MAILBOX + 2));
-    if (ep < W2_MAX_EPISODES) {
+    if (ep < a.max_episodes) {
         float *base = a.slab + (long)ep * W2_EP_FLOATS;
 #pragma unroll
         for (int m = 0; m < MBW; ++m) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(WArgs a) {
         if ((int)blockIdx.x >= a.job[i].red_block0) j = i;
     const WJob &J = a.job[j];
     const int b = blockIdx.x - J.red_block0;
-    const int n_ep = min(a.counters[W2_MAX_JOBS], W2_MAX_EPISODES);
+    const int n_ep = min(a.counters[W2_MAX_JOBS], a.max_episodes);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int cnt = 0;
     for (int e0 = 0; e0 < n_ep; e0 += 256) {          // ordered compaction (slot order) by wave-level prefix sums
@@ -649,6 +650,10 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
         MNR_REQUIRE(!err, "weight-gradient job table: unsupported layer shape or too many jobs (region %d)", ri);
     }
     wa.njobs = nj;
+    {
+        const int cap = (int)env_d("MNR_WGRAD_MAX_EPISODES", (double)W2_MAX_EPISODES);
+        wa.max_episodes = cap < 0 ? 0 : (cap > W2_MAX_EPISODES ? W2_MAX_EPISODES : cap);
+    }
     int red_blocks = 0;
     for (int i = 0; i < nj; ++i) {
         const WShapeInfo si = wshape_info(wa.job[i].shape);
