@@ -182,6 +182,43 @@ int mnr_col_sum(float *out_dev, const float *G_dev, int64_t ldg, int64_t R, int 
 /* table_grad[idx[r / rows_per_ray]][0..width) += src[r][0..width)  (gradient of mnr_gather_rows) */
 int mnr_scatter_rows(float *table_grad_dev, int width, int count, const void *idx_dev, int64_t idx_stride, int idx_is_float,
                      int64_t rows_per_ray, const float *src_dev, int64_t ld_src, int64_t R, void *stream);
+/* ---- wide layers of the layer-by-layer path: tiled GEMM with fused epilogues (csrc/tgemm.hip) and batched weight
+ * gradients (csrc/wgrad.hip); what nerf.py:115-160 + autograd get from cuBLAS, for layer widths that are multiples of 256.
+ *   C[m][n] = gate( relu( sum_p sum_k a[p][m][k] B_p(n,k) + bias[n] + r1_row[m] r1_col[n] ) )
+ * b_kslow 0: B_p(n,k) = b[p][n * ldb[p] + k] (nn.Linear weights, forward);  1: b[p][k * ldb[p] + n] (data gradient dZ . W).
+ * gate (optional): C is zeroed where gate[m][n] <= 0 -- the ReLU adjoint through the previous layer's output.
+ * Requirements: n % 256 == 0, k[p] % 32 == 0, all pointers 16-byte aligned and all pitches multiples of 4 floats
+ * (the caller zero-pads odd input widths, e.g. the 63 embedding columns to 64); anything else -> MNR_E_INVALID. */
+typedef struct mnr_tgemm {
+    const float *a[2];  int64_t lda[2];
+    const float *b[2];  int64_t ldb[2];
+    int32_t k[2];
+    int32_t n_phases;            /* 1 or 2 */
+    int32_t b_kslow;
+    int32_t relu;
+    float *c;  int64_t ldc;
+    int64_t m;  int32_t n;
+    const float *bias;           /* [n] or NULL */
+    const float *gate;  int64_t ldgate;
+    const float *r1_row;  int64_t r1_stride;  const float *r1_col;    /* NULL or rank-1 addend */
+} mnr_tgemm;
+int mnr_tgemm_run(const mnr_tgemm *g, void *stream);
+
+/* dw[m * ldw + n] += sum_r dz[r][m] * in[r][n] (m < 256, n < in_cols),  db[m] += sum_r dz[r][m]  for a list of jobs over
+ * the same `rows` rows (rows % 32 == 0), one launch + one reduction launch (the kernel of mnr_mlp_backward_weights_multi).
+ * dz: 256 consecutive columns of a [rows][ldz] gradient.  in_block 256: 256 consecutive columns of a [rows][ldin] matrix;
+ * in_block 32/64/96/128: a dense [rows][in_block] matrix (ldin == in_block, columns >= in_cols ignored).
+ * At most MNR_WGRAD_MAX_JOBS jobs per call. */
+#define MNR_WGRAD_MAX_JOBS 24
+typedef struct mnr_wgrad_job {
+    const float *dz;  int64_t ldz;
+    const float *in;  int64_t ldin;
+    int32_t in_cols, in_block;
+    float *dw;  int64_t ldw;
+    float *db;                   /* NULL: no bias gradient from this job */
+} mnr_wgrad_job;
+int mnr_wgrad_jobs(const mnr_wgrad_job *jobs, int n_jobs, int64_t rows, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Spherical-harmonics colour outside the fused epilogue (rendering.py:300-305, spherical_harmonics.py:55-107):
  * out[r] = [sigmoid(eval_sh(deg, coef[r] viewed (3, (deg+1)^2), dir[r / rows_per_ray])), coef[r][3 (deg+1)^2]] and its adjoint */
 int mnr_sh_apply(float *out_dev, int64_t ldo, const float *coef_dev, int64_t ldc, const float *dirs_dev, int64_t dir_stride,

@@ -1,0 +1,50 @@
+// lds_asm.h -- LDS accesses hipcc must not see.  Behind an LDS-DMA (global_load_lds) into an LDS array the compiler puts
+// `s_waitcnt vmcnt(0)` in front of every ds_read of that array, i.e. it drains the DMA queue before each fragment read and
+// nothing overlaps.  Kernels that stream tiles with LDS-DMA while computing (wgrad.hip, tgemm.hip) therefore read LDS with
+// inline asm and count their own lgkmcnt / vmcnt waits.
+#pragma once
+#include "mlp_device.h"
+
+namespace mnr {
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int OFF>
+__device__ __forceinline__ float lds_ld(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ floatx4 lds_ld4(unsigned addr) {
+    floatx4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ int lds_ld_i(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// ... the same for a workgroup-uniform word: the value moves to an SGPR, so everything derived from it (job table
+// indexing, tile addresses, loop control) stays on the scalar unit instead of VGPRs + vector loads from the kernel arguments
+__device__ __forceinline__ int lds_ld_u(unsigned addr) { return __builtin_amdgcn_readfirstlane(lds_ld_i(addr)); }
+__device__ __forceinline__ void lds_st_i(unsigned addr, int v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// an empty asm that "redefines" a register: MFMAs consuming it cannot be scheduled above the wait that precedes the pin
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(floatx4 &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// fetch-and-increment WITHOUT waiting for the result (hipcc's atomicAdd puts `s_waitcnt vmcnt(0)` right behind the
+// instruction, which also drains the LDS-DMA queue); the value is valid after the caller's next wait_vm0()
+__device__ __forceinline__ int atomic_inc_async(int32_t *p) {
+    int v, one = 1;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v) : "v"(p), "v"(one) : "memory");
+    return v;
+}
+
+}  // namespace mnr

@@ -25,7 +25,7 @@
 
 #include <initializer_list>
 
-#include "mlp_device.h"
+#include "lds_asm.h"
 
 namespace mnr {
 
@@ -49,6 +49,9 @@ template <int M_, int GM_, int GN_, int KS_, int MBW_, int LD0_, int NB0_, int L
 struct WShape {
     static constexpr int M = M_, GM = GM_, GN = GN_, KS = KS_, MBW = MBW_;
     static constexpr int NSEG = LD2_ ? 3 : (LD1_ ? 2 : 1);
+    // the 256 x 256 shape takes its two operands with run-time row pitches (column windows of wider matrices)
+    static constexpr bool ZPITCH = M_ == 256;                               // dz: run-time pitch (WJob::ldz)
+    static constexpr bool PITCHED = M_ == 256 && LD0_ == 256 && LD1_ == 0;   // ... and in[0] too (WJob::ldin0)
     static constexpr int LD[3] = {LD0_, LD1_, LD2_};
     static constexpr int NB[3] = {NB0_, NB1_, NB2_};
     static constexpr int NBT = NB0_ + NB1_ + NB2_;              // N blocks in total
@@ -78,7 +81,13 @@ using WS_SKF = WShape<256, 8, 1, 1, 1, 76, 3, 256, 8>;                // skip la
 using WS_DIR = WShape<128, 4, 1, 2, 1, 256, 8, 28, 1, 48, 2>;         // dir_a [final | direction embedding (27) | appearance (48)]
 using WS_DIR_NOAPP = WShape<128, 4, 1, 2, 1, 256, 8, 28, 1>;          // appearance_dim 0
 using WS_DIR_NODIR = WShape<128, 4, 1, 2, 1, 256, 8, 48, 2>;          // spherical harmonics: no direction input
-enum WShapeId : int32_t { WSI_BIG = 0, WSI_L0F, WSI_L0B, WSI_SKF, WSI_DIR, WSI_DIR_NOAPP, WSI_DIR_NODIR, WSI_COUNT };
+// dense zero-padded inputs of the layer-by-layer path (mnr_wgrad_jobs): embeddings / direction + appearance columns
+using WS_D32 = WShape<256, 8, 1, 1, 1, 32, 1>;
+using WS_D64 = WShape<256, 8, 1, 1, 1, 64, 2>;
+using WS_D96 = WShape<256, 8, 1, 1, 1, 96, 3>;
+using WS_D128 = WShape<256, 8, 1, 1, 1, 128, 4>;
+enum WShapeId : int32_t { WSI_BIG = 0, WSI_L0F, WSI_L0B, WSI_SKF, WSI_DIR, WSI_DIR_NOAPP, WSI_DIR_NODIR, WSI_D32, WSI_D64, WSI_D96,
+                          WSI_D128, WSI_COUNT };
 
 struct WShapeInfo { int M, NP, KS, nseg, ld[3], nb[3], blocks_per_wave, tile_bytes; };
 template <class S>
@@ -94,7 +103,11 @@ __host__ __device__ inline WShapeInfo wshape_info(int id) {
         case WSI_SKF: return wshape_info_of<WS_SKF>();
         case WSI_DIR: return wshape_info_of<WS_DIR>();
         case WSI_DIR_NOAPP: return wshape_info_of<WS_DIR_NOAPP>();
-        default: return wshape_info_of<WS_DIR_NODIR>();
+        case WSI_DIR_NODIR: return wshape_info_of<WS_DIR_NODIR>();
+        case WSI_D32: return wshape_info_of<WS_D32>();
+        case WSI_D64: return wshape_info_of<WS_D64>();
+        case WSI_D96: return wshape_info_of<WS_D96>();
+        default: return wshape_info_of<WS_D128>();
     }
 }
 
@@ -109,6 +122,7 @@ struct WJob {
     const float *dz, *in[3];        // plane bases (tape row 0)
     float *dw, *db;                 // gradient view dw[m * ldw + col0[s] + n] (n < N[s]) per segment, bias gradient or NULL
     int32_t ldw;
+    int32_t ldz, ldin0;             // row pitches of dz (M = 256 shapes) and of in[0] (PITCHED shape); everything else is dense
     int16_t col0[3], N[3];
     int16_t shape, region;
     int32_t tiles_per_item;
@@ -124,39 +138,6 @@ struct WArgs {
     long long *prof;                // optional [grid][8] cycle accumulators (MNR_WGRAD_PROF diagnostics), else NULL
     int32_t max_episodes;           // slab slots in use (<= W2_MAX_EPISODES; tests lower it to exercise the atomic fallback)
 };
-
-// ---- small asm helpers: LDS accesses the compiler must not see (it would drain the LDS-DMA queue before each of them) ---
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
-template <int OFF>
-__device__ __forceinline__ float lds_ld(unsigned addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ int lds_ld_i(unsigned addr) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-// ... the same for a workgroup-uniform word: the value moves to an SGPR, so everything derived from it (job table
-// indexing, tile addresses, loop control) stays on the scalar unit instead of VGPRs + vector loads from the kernel arguments
-__device__ __forceinline__ int lds_ld_u(unsigned addr) { return __builtin_amdgcn_readfirstlane(lds_ld_i(addr)); }
-__device__ __forceinline__ void lds_st_i(unsigned addr, int v) {
-    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// fetch-and-increment WITHOUT waiting for the result (hipcc's atomicAdd puts `s_waitcnt vmcnt(0)` right behind the
-// instruction, which also drains the LDS-DMA queue); the value is valid after the caller's next wait_vm0()
-__device__ __forceinline__ int atomic_inc_async(int32_t *p) {
-    int v, one = 1;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v) : "v"(p), "v"(one) : "memory");
-    return v;
-}
 
 // rows of a range (device-side count when given), padded to whole tiles
 __device__ __forceinline__ int range_tiles(const WRegion &r, int i) {
@@ -183,6 +164,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
     const int ks = wave / (S::GM * S::GN), wq = wave % (S::GM * S::GN);
     const int wr = wq / S::GN, wc = wq % S::GN;
     const int i32 = lane & 31, kk = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned ctl = lds_addr(lds_all);
     float *stage0 = lds_all + W2_CTRL_FLOATS;
     const int n_items = lds_ld_u(ctl + 4 * (WCtl::ITEMS + j));
@@ -210,13 +192,23 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
         b_off[sg] = (unsigned)((S::SEG_OFF[sg] + (2 * ks + kk) * S::LD[sg] + (S::GN > 1 ? wc * NBW * 32 : 0) + i32) * 4);
     const unsigned st_base0 = lds_addr(stage0), st_base1 = lds_addr(stage0 + S::STAGE_FLOATS);
 
+    // pitched 256-wide operands: float offset of this wave's row inside a tile, per piece (uniform, once per episode)
+    unsigned zrow_off[4], irow_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        zrow_off[p] = S::ZPITCH ? (unsigned)((p * 8 + wave_u) * J.ldz) : 0u;
+        irow_off[p] = S::PITCHED ? (unsigned)((p * 8 + wave_u) * J.ldin0) : 0u;
+    }
     // A tile in LDS = [dz rows | segment 0 rows | segment 1 rows | ...], each a contiguous byte range of its plane.
     struct Src { const float *z, *i[3]; };
     auto tile_src = [&](int t, Src &q) {       // tile index in the job's concatenated row space
         const long row = t < tiles0 ? R.row0[0] + (long)t * W2_KT : R.row0[1] + (long)(t - tiles0) * W2_KT;
-        q.z = J.dz + row * M;
+        q.z = J.dz + row * (S::ZPITCH ? (long)J.ldz : (long)M);
+        if constexpr (S::PITCHED) q.i[0] = J.in[0] + row * J.ldin0;
+        else {
 #pragma unroll
-        for (int sg = 0; sg < S::NSEG; ++sg) q.i[sg] = J.in[sg] + row * S::LD[sg];
+            for (int sg = 0; sg < S::NSEG; ++sg) q.i[sg] = J.in[sg] + row * S::LD[sg];
+        }
     };
     auto dma_piece = [&](auto pc, const Src &q, int stage) {
         constexpr int p = decltype(pc)::value;
@@ -225,7 +217,10 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
         const int t = lo + threadIdx.x;
         if (hi <= S::TILE_F4 || t < S::TILE_F4) {
             const float *src;
-            if constexpr (hi <= F0) src = q.z + t * 4;
+            // 256-wide operands with a run-time pitch: 64 float4 per row, so piece p = rows 8 p .. 8 p + 7 (one per wave)
+            if constexpr (S::ZPITCH && hi <= F0) src = q.z + zrow_off[p] + lane * 4;
+            else if constexpr (S::PITCHED) src = q.i[0] + irow_off[p - F0 / W2_THREADS] + lane * 4;
+            else if constexpr (hi <= F0) src = q.z + t * 4;
             else if constexpr (lo >= F0 && (S::NSEG == 1 || hi <= F1)) src = q.i[0] + (t - F0) * 4;
             else if constexpr (S::NSEG >= 2 && lo >= F1 && (S::NSEG == 2 || hi <= F2)) src = q.i[1] + (t - F1) * 4;
             else if constexpr (S::NSEG == 3 && lo >= F2) src = q.i[2] + (t - F2) * 4;
@@ -395,6 +390,10 @@ __device__ __forceinline__ int wg_broadcast(unsigned word_addr, int v) {
     return lds_ld_u(word_addr);
 }
 
+// FAMILY 0: the shapes of the fused models' tapes (mnr_mlp_backward_weights_multi); FAMILY 1: the job form of the layer-by-layer
+// path (mnr_wgrad_jobs).  Two kernels rather than one: with all eleven episode instantiations in one kernel the 256 x 256
+// shape ran 4 % slower (2.02 vs 1.94 ms on the benchmark step, same instruction mix -- code placement).
+template <int FAMILY>
 __global__ __launch_bounds__(W2_THREADS, 2) void k_wgrad2(WArgs a) {
     extern __shared__ float lds_all[];
     const unsigned ctl = lds_addr(lds_all);
@@ -426,17 +425,28 @@ __global__ __launch_bounds__(W2_THREADS, 2) void k_wgrad2(WArgs a) {
         if (threadIdx.x == 0) item = atomicAdd(a.counters + cur, 1);
         item = wg_broadcast(ctl + 4 * WCtl::PICK, item);
         if (item < lds_ld_u(ctl + 4 * (WCtl::ITEMS + cur))) {
-            switch (a.job[cur].shape) {
-                case WSI_BIG: wgrad_episode<WS_BIG>(a, cur, item, lds_all); break;
-                case WSI_L0F: wgrad_episode<WS_L0F>(a, cur, item, lds_all); break;
-                case WSI_L0B: wgrad_episode<WS_L0B>(a, cur, item, lds_all); break;
-                case WSI_SKF: wgrad_episode<WS_SKF>(a, cur, item, lds_all); break;
-                case WSI_DIR: wgrad_episode<WS_DIR>(a, cur, item, lds_all); break;
+            if constexpr (FAMILY == 0) {
+                switch (a.job[cur].shape) {
+                    case WSI_BIG: wgrad_episode<WS_BIG>(a, cur, item, lds_all); break;
+                    case WSI_L0F: wgrad_episode<WS_L0F>(a, cur, item, lds_all); break;
+                    case WSI_L0B: wgrad_episode<WS_L0B>(a, cur, item, lds_all); break;
+                    case WSI_SKF: wgrad_episode<WS_SKF>(a, cur, item, lds_all); break;
+                    case WSI_DIR: wgrad_episode<WS_DIR>(a, cur, item, lds_all); break;
 #ifdef MNR_ALL_VARIANTS
-                case WSI_DIR_NOAPP: wgrad_episode<WS_DIR_NOAPP>(a, cur, item, lds_all); break;
-                case WSI_DIR_NODIR: wgrad_episode<WS_DIR_NODIR>(a, cur, item, lds_all); break;
+                    case WSI_DIR_NOAPP: wgrad_episode<WS_DIR_NOAPP>(a, cur, item, lds_all); break;
+                    case WSI_DIR_NODIR: wgrad_episode<WS_DIR_NODIR>(a, cur, item, lds_all); break;
 #endif
-                default: break;
+                    default: break;
+                }
+            } else {
+                switch (a.job[cur].shape) {
+                    case WSI_BIG: wgrad_episode<WS_BIG>(a, cur, item, lds_all); break;
+                    case WSI_D32: wgrad_episode<WS_D32>(a, cur, item, lds_all); break;
+                    case WSI_D64: wgrad_episode<WS_D64>(a, cur, item, lds_all); break;
+                    case WSI_D96: wgrad_episode<WS_D96>(a, cur, item, lds_all); break;
+                    case WSI_D128: wgrad_episode<WS_D128>(a, cur, item, lds_all); break;
+                    default: break;
+                }
             }
         }
         // this job is exhausted (for us): steal from the job with the most items left
@@ -556,6 +566,59 @@ static int shape_for(int M, const int *ld, int nseg) {
     return -1;
 }
 
+static double env_d(const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; }
+
+// per-tile cost model (cycles per SIMD): MFMA time of the two co-resident waves vs LDS-DMA fill time, + a fixed
+// boundary term -> tiles per item so that items of all jobs cost about the same (~4 tiles of the 256 x 256 shape)
+static double wgrad_tile_cost(int shape) {
+    const double dma_bpc = env_d("MNR_WGRAD_DMA_BPC", 10.0), fixed = env_d("MNR_WGRAD_FIXED", 600.0);
+    const WShapeInfo si = wshape_info(shape);
+    const double mfma = (double)si.blocks_per_wave * (W2_KT / 2 / si.KS) * 64.0 * 2.0;     // two co-resident waves per SIMD
+    const double dma = si.tile_bytes / dma_bpc;
+    return (mfma > dma ? mfma : dma) + fixed;
+}
+
+// shared tail of the two entry points: reduce-block table, workspace carving, the two launches
+static int launch_wgrad2(WArgs &wa, int nj, void *workspace_dev, hipStream_t s, int family) {
+    wa.njobs = nj;
+    {
+        const int cap = (int)env_d("MNR_WGRAD_MAX_EPISODES", (double)W2_MAX_EPISODES);
+        wa.max_episodes = cap < 0 ? 0 : (cap > W2_MAX_EPISODES ? W2_MAX_EPISODES : cap);
+    }
+    int red_blocks = 0;
+    for (int i = 0; i < nj; ++i) {
+        const WShapeInfo si = wshape_info(wa.job[i].shape);
+        wa.job[i].red_block0 = red_blocks;
+        red_blocks += si.M * si.NP / 4 / 256 + (wa.job[i].db ? 1 : 0);
+    }
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    wa.counters = reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS);
+    wa.ep_job = reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB);
+    wa.slab = reinterpret_cast<float *>(ws + W2Workspace::SLAB);
+    wa.prof = getenv("MNR_WGRAD_PROF") ? reinterpret_cast<long long *>(wa.slab + (size_t)(W2_MAX_EPISODES - 1) * W2_EP_FLOATS) : nullptr;   // diagnostics: borrows the last slab slot
+    size_t lds = 0;
+    for (int i = 0; i < nj; ++i) {
+        const size_t need = (W2_CTRL_FLOATS + 2 * ((size_t)wshape_info(wa.job[i].shape).tile_bytes / 4 + 255) / 256 * 256 * 1 + 2 * 256) * sizeof(float);
+        lds = need > lds ? need : lds;
+    }
+    static bool lds_enabled = false;       // raise the dynamic-LDS cap once (benign if raced)
+    if (!lds_enabled) {
+        for (const void *f : {reinterpret_cast<const void *>(k_wgrad2<0>), reinterpret_cast<const void *>(k_wgrad2<1>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad2): %s", hipGetErrorString(e));
+        }
+        lds_enabled = true;
+    }
+    if (hipMemsetAsync(wa.counters, 0, 256, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(wgrad counters)");
+    const int grid = (int)env_d("MNR_WGRAD_WGS", 256.0);
+    if (family == 0) hipLaunchKernelGGL(k_wgrad2<0>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
+    else hipLaunchKernelGGL(k_wgrad2<1>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
+    int rc = check_launch("k_wgrad2");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wgrad2_reduce, dim3(red_blocks), dim3(256), 0, s, wa);
+    return check_launch("k_wgrad2_reduce");
+}
+
 }  // namespace mnr
 
 using namespace mnr;
@@ -572,15 +635,8 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
     long rows_bound = 0;
     // per-tile cost model (cycles per SIMD): MFMA time of the two co-resident waves vs LDS-DMA fill time, + a fixed
     // boundary term -> tiles per item so that items of all jobs cost about the same (~4 tiles of the 256 x 256 shape)
-    auto env_d = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };
-    const double item_tiles = env_d("MNR_WGRAD_ITEM_TILES", 4.0), dma_bpc = env_d("MNR_WGRAD_DMA_BPC", 10.0),
-                 fixed = env_d("MNR_WGRAD_FIXED", 600.0);
-    auto cost_of = [&](int shape) {
-        const WShapeInfo si = wshape_info(shape);
-        const double mfma = (double)si.blocks_per_wave * (W2_KT / 2 / si.KS) * 64.0 * 2.0;     // two co-resident waves per SIMD
-        const double dma = si.tile_bytes / dma_bpc;
-        return (mfma > dma ? mfma : dma) + fixed;
-    };
+    const double item_tiles = env_d("MNR_WGRAD_ITEM_TILES", 4.0);
+    auto cost_of = [&](int shape) { return wgrad_tile_cost(shape); };
     const double cost_big = cost_of(WSI_BIG);
     const int only_shape = (int)env_d("MNR_WGRAD_ONLY_SHAPE", -1.0);
     for (int ri = 0; ri < n_regions; ++ri) {
@@ -616,6 +672,7 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
             if (only_shape >= 0 && shape != only_shape) return;
             WJob &J = wa.job[nj++];
             J.dz = dz; J.dw = dw; J.db = db; J.ldw = ldw;
+            J.ldz = M; J.ldin0 = ld[0];
             n = 0;
             for (const SegIn &sg : segs) { J.in[n] = sg.in; J.col0[n] = (int16_t)sg.col0; J.N[n] = (int16_t)sg.N; ++n; }
             J.shape = (int16_t)shape; J.region = (int16_t)ri;
@@ -649,39 +706,46 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
         }
         MNR_REQUIRE(!err, "weight-gradient job table: unsupported layer shape or too many jobs (region %d)", ri);
     }
-    wa.njobs = nj;
-    {
-        const int cap = (int)env_d("MNR_WGRAD_MAX_EPISODES", (double)W2_MAX_EPISODES);
-        wa.max_episodes = cap < 0 ? 0 : (cap > W2_MAX_EPISODES ? W2_MAX_EPISODES : cap);
-    }
-    int red_blocks = 0;
-    for (int i = 0; i < nj; ++i) {
-        const WShapeInfo si = wshape_info(wa.job[i].shape);
-        wa.job[i].red_block0 = red_blocks;
-        red_blocks += si.M * si.NP / 4 / 256 + (wa.job[i].db ? 1 : 0);
-    }
     if (rows_bound == 0) return MNR_OK;
-    char *ws = reinterpret_cast<char *>(workspace_dev);
-    wa.counters = reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS);
-    wa.ep_job = reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB);
-    wa.slab = reinterpret_cast<float *>(ws + W2Workspace::SLAB);
-    wa.prof = getenv("MNR_WGRAD_PROF") ? reinterpret_cast<long long *>(wa.slab + (size_t)(W2_MAX_EPISODES - 1) * W2_EP_FLOATS) : nullptr;   // diagnostics: borrows the last slab slot
-    size_t lds = 0;
-    for (int i = 0; i < nj; ++i) {
-        const size_t need = (W2_CTRL_FLOATS + 2 * ((size_t)wshape_info(wa.job[i].shape).tile_bytes / 4 + 255) / 256 * 256 * 1 + 2 * 256) * sizeof(float);
-        lds = need > lds ? need : lds;
+    return launch_wgrad2(wa, nj, workspace_dev, s, 0);
+}
+
+extern "C" int mnr_wgrad_jobs(const mnr_wgrad_job *jobs, int n_jobs, int64_t rows, void *workspace_dev, size_t workspace_bytes,
+                              void *stream) {
+    MNR_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= W2_MAX_JOBS, "mnr_wgrad_jobs: 1..%d jobs per call", W2_MAX_JOBS);
+    MNR_REQUIRE(workspace_dev && workspace_bytes >= W2Workspace::BYTES, "workspace missing or smaller than mnr_wgrad_workspace_bytes()");
+    MNR_REQUIRE(rows >= 0 && rows % W2_KT == 0, "mnr_wgrad_jobs: rows must be a multiple of %d", W2_KT);
+    if (rows == 0) return MNR_OK;
+    WArgs wa{};
+    WRegion &R = wa.region[0];
+    R.n_ranges = 1; R.row0[0] = 0; R.n_rows[0] = rows;
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const double item_tiles = env_d("MNR_WGRAD_ITEM_TILES", 4.0);
+    const double cost_big = wgrad_tile_cost(WSI_BIG);
+    for (int i = 0; i < n_jobs; ++i) {
+        const mnr_wgrad_job &q = jobs[i];
+        int shape = -1;
+        switch (q.in_block) {
+            case 256: shape = WSI_BIG; break;
+            case 32: shape = WSI_D32; break;
+            case 64: shape = WSI_D64; break;
+            case 96: shape = WSI_D96; break;
+            case 128: shape = WSI_D128; break;
+            default: break;
+        }
+        MNR_REQUIRE(shape >= 0, "mnr_wgrad_jobs: job %d: in_block must be 32, 64, 96, 128 or 256", i);
+        MNR_REQUIRE(q.dz && q.in && q.dw && al16(q.dz) && al16(q.in) && q.ldz % 4 == 0 && q.ldin % 4 == 0 && q.ldz >= 256,
+                    "mnr_wgrad_jobs: job %d: operands must be 16-byte aligned", i);
+        MNR_REQUIRE(q.in_cols >= 1 && q.in_cols <= q.in_block && (q.in_block == 256 ? q.ldin >= 256 : q.ldin == q.in_block),
+                    "mnr_wgrad_jobs: job %d: bad input columns / pitch", i);
+        MNR_REQUIRE(q.ldz < (1ll << 24) && q.ldin < (1ll << 24) && q.ldw < (1ll << 31), "mnr_wgrad_jobs: job %d: pitch too large", i);
+        WJob &J = wa.job[i];
+        J.dz = q.dz; J.in[0] = q.in; J.dw = q.dw; J.db = q.db;
+        J.ldw = (int32_t)q.ldw; J.ldz = (int32_t)q.ldz; J.ldin0 = (int32_t)q.ldin;
+        J.col0[0] = 0; J.N[0] = (int16_t)q.in_cols;
+        J.shape = (int16_t)shape; J.region = 0;
+        const int tpi = (int)(item_tiles * cost_big / wgrad_tile_cost(shape) + 0.5);
+        J.tiles_per_item = tpi < 1 ? 1 : tpi;
     }
-    static bool lds_enabled = false;       // raise the dynamic-LDS cap once (benign if raced)
-    if (!lds_enabled) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad2): %s", hipGetErrorString(e));
-        lds_enabled = true;
-    }
-    if (hipMemsetAsync(wa.counters, 0, 256, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(wgrad counters)");
-    const int grid = (int)env_d("MNR_WGRAD_WGS", 256.0);
-    hipLaunchKernelGGL(k_wgrad2, dim3(grid), dim3(W2_THREADS), lds, s, wa);
-    int rc = check_launch("k_wgrad2");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_wgrad2_reduce, dim3(red_blocks), dim3(256), 0, s, wa);
-    return check_launch("k_wgrad2_reduce");
+    return launch_wgrad2(wa, n_jobs, workspace_dev, as_stream(stream), 1);
 }

@@ -98,6 +98,24 @@ class WgradRegion(C.Structure):
                 ('n_units_dev', C.c_void_p * 2), ('rows_per_unit', C.c_int32 * 2), ('grad', ModelGrads)]
 
 
+class TGemm(C.Structure):
+    """struct mnr_tgemm"""
+    _fields_ = [('a', C.c_void_p * 2), ('lda', C.c_int64 * 2), ('b', C.c_void_p * 2), ('ldb', C.c_int64 * 2),
+                ('k', C.c_int32 * 2), ('n_phases', C.c_int32), ('b_kslow', C.c_int32), ('relu', C.c_int32),
+                ('c', C.c_void_p), ('ldc', C.c_int64), ('m', C.c_int64), ('n', C.c_int32), ('bias', C.c_void_p),
+                ('gate', C.c_void_p), ('ldgate', C.c_int64), ('r1_row', C.c_void_p), ('r1_stride', C.c_int64),
+                ('r1_col', C.c_void_p)]
+
+
+class WgradJob(C.Structure):
+    """struct mnr_wgrad_job"""
+    _fields_ = [('dz', C.c_void_p), ('ldz', C.c_int64), ('in_', C.c_void_p), ('ldin', C.c_int64), ('in_cols', C.c_int32),
+                ('in_block', C.c_int32), ('dw', C.c_void_p), ('ldw', C.c_int64), ('db', C.c_void_p)]
+
+
+WGRAD_MAX_JOBS = 24          # MNR_WGRAD_MAX_JOBS
+
+
 class CompositeGradIO(C.Structure):
     """struct mnr_composite_grad_io"""
     _fields_ = [('z', C.c_void_p), ('raw', C.c_void_p), ('last_delta', C.c_void_p), ('zmax_src', C.c_void_p),
@@ -116,6 +134,7 @@ EXPORTS = [
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
     'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
+    'mnr_tgemm_run', 'mnr_wgrad_jobs',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -184,6 +203,8 @@ def lib() -> C.CDLL:
         _lib.mnr_wgrad_workspace_bytes.restype = C.c_size_t
         _lib.mnr_wgrad_workspace_bytes.argtypes = []
         _lib.mnr_mlp_backward_weights_multi.argtypes = [C.POINTER(WgradRegion), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.mnr_tgemm_run.argtypes = [C.POINTER(TGemm), C.c_void_p]
+        _lib.mnr_wgrad_jobs.argtypes = [C.POINTER(WgradJob), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.mnr_composite_backward.argtypes = [C.POINTER(CompositeGradIO), C.c_void_p]
         _lib.mnr_merge_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
@@ -248,3 +269,16 @@ def host3(v) -> Optional[C.Array]:
     if isinstance(v, torch.Tensor):
         v = v.detach().cpu().tolist()
     return (C.c_float * 3)(*[float(x) for x in v])
+
+
+_WGRAD_WS: dict = {}
+
+
+def wgrad_workspace(dev):
+    """Scratch of the batched weight-gradient launches (partial-sum slabs, mnr_wgrad_workspace_bytes()), one per device."""
+    import torch
+    dev = torch.device(dev)
+    ws = _WGRAD_WS.get(dev)
+    if ws is None:
+        ws = _WGRAD_WS[dev] = torch.empty(lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return ws

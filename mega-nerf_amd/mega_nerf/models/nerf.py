@@ -8,6 +8,7 @@ Parameter names (``xyz_encodings.{i}.0.*``, ``embedding_a.weight``, ``xyz_encodi
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -268,7 +269,12 @@ class NeRF(nn.Module):
         if n_rows == 0:
             return out
         ostride = out.stride(0) if out.dim() > 1 else 1
-        chunk = max(rows_per_ray, (32768 // rows_per_ray) * rows_per_ray)
+        # rows per pass: the 128 x 128 kernels like chunks whose activations stay in the 256 MB Infinity Cache between layers;
+        # the tiled GEMM (widths that are multiples of 256) wants >= 256 output tiles of 256 rows per launch -- one per CU --
+        # and is not HBM-bound, so it takes up to 1 GB of activations per layer (288 GB of HBM: no reason to go small)
+        tiled = self.layer_dim % 256 == 0 and os.environ.get('MNR_NO_TGEMM') is None
+        target = max(32768, (1 << 28) // self.layer_dim) if tiled else 32768
+        chunk = max(rows_per_ray, (target // rows_per_ray) * rows_per_ray)
         dir_rows = rows_per_ray if dir_rows is None else dir_rows
         sh = apply_sh_deg >= 0 and self.rgb_dim > 3 and not sigma_only
         mlp_dirs = dirs if self.has_dir else None

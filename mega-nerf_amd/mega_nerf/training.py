@@ -257,15 +257,11 @@ def _launch_backward(branches, dev: torch.device) -> None:
     _weight_gradients(regions, dev, 'wgrad')
 
 
-_WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
 
 
 def _wgrad_workspace(dev: torch.device) -> torch.Tensor:
     """Scratch of the batched weight-gradient launch (partial-sum slabs), allocated once per device."""
-    ws = _WGRAD_WS.get(dev)
-    if ws is None:
-        ws = _WGRAD_WS[dev] = torch.empty(N.lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
-    return ws
+    return N.wgrad_workspace(dev)
 
 
 def _weight_gradients(regions, dev: torch.device, tag: str = 'wgrad') -> None:
