@@ -49,14 +49,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PMC_FILE = ROOT / 'profiles' / 'r02_pmc_summary.json'
 
 
-def build_models(hp, dev, seed):
+def build_models(hp, dev, seed, layer_dim=256):
     """(model, cfg, numpy state_dict) for the foreground and the background NeRF with seeded weights."""
     import synthetic_scene as S
     from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
     A = S.SCENE['appearance_count']
     out = []
     for xyz_dim, s in ((3, seed), (4, seed + 500)):
-        cfg = S.model_cfg(hp, xyz_dim, 256)
+        cfg = S.model_cfg(hp, xyz_dim, layer_dim if xyz_dim == 3 else hp.bg_layer_dim)     # opts.py:48-49: --layer_dim is the foreground's
         w = S.make_weights(cfg, A, s)
         m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim,
                  False, A, 3, xyz_dim, ShiftedSoftplus())
@@ -246,6 +246,8 @@ def main():
     ap.add_argument('--samples', default='64,128', help='coarse,fine samples per ray (BASELINE: 64,128; reference default 256,512)')
     ap.add_argument('--submodules', type=int, default=0, metavar='S',
                     help='strong scaling: a fixed set of S submodules dealt round-robin to the ranks (0 = one private submodule per rank)')
+    ap.add_argument('--layer-dim', type=int, default=256,
+                    help='MLP width (256 = the headline Rubble config; 512 = configs/mega-nerf Building: layer-by-layer tiled GEMM path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the N = 1 side measurements and the PSNR check')
     ap.add_argument('--container', type=int, default=0, metavar='N',
@@ -276,7 +278,8 @@ def main():
 
     Nc, Nf = [int(v) for v in args.samples.split(',')]
     # opts.py defaults = configs/mega-nerf (8x256, 12/4 frequency bands, 48-d appearance) at the benchmark's samples per ray
-    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf)])
+    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf), '--layer_dim', str(args.layer_dim)])
+    wide = args.layer_dim != 256                   # side measurement of the wide configs: headline numbers only
     s = S.SCENE
     sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
     d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
@@ -294,7 +297,7 @@ def main():
     total_cells = args.submodules if args.submodules else world
     work = []
     for c in cells:
-        (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp, dev, 1000 * (c + 1))
+        (fg, fcfg, fw), (bg, bcfg, bw) = build_models(hp, dev, 1000 * (c + 1), args.layer_dim)
         work.append(dict(fg=fg, bg=bg, batch=make_batch(42 + c, args.rays), fcfg=fcfg, bcfg=bcfg, fw=fw, bw=bw))
     if args.container:
         assert args.mode == 'eval' and not args.submodules, '--container is a single-GPU evaluation shape (routed containers are inference-only)'
@@ -304,7 +307,7 @@ def main():
         g1 = n // g0
         assert g0 * g1 == n, '--container must factor into a grid'
         cent = torch.stack([torch.zeros(n), torch.linspace(-.45, .45, g0).repeat_interleave(g1), torch.linspace(-.45, .45, g1).repeat(g0)], 1)
-        sub = [build_models(hp, dev, 1000 * (rank + 1) + 7 * j) for j in range(n)]
+        sub = [build_models(hp, dev, 1000 * (rank + 1) + 7 * j, args.layer_dim) for j in range(n)]
         work[0]['fg'] = MegaNeRF([c[0][0] for c in sub], cent, hp.boundary_margin, False, False).to(dev)
         work[0]['bg'] = MegaNeRF([c[1][0] for c in sub], cent, hp.boundary_margin, True, False).to(dev)
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
@@ -363,7 +366,7 @@ def main():
     metric_reduce_check = float(packed[0] / packed[1])
 
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras and not args.container and not args.submodules and (Nc, Nf) == (64, 128):
+    if rank == 0 and world == 1 and not args.no_extras and not args.container and not args.submodules and (Nc, Nf) == (64, 128) and not wide:
         w = work[0]
         fgm, bgm = w['fg'], w['bg']
 
@@ -425,7 +428,17 @@ def main():
         mlp = lambda nf_, nb_: nf_ * FG_FLOP_PER_SAMPLE + nb_ * BG_FLOP_PER_SAMPLE                      # noqa: E731
         mfma_only = lambda nf_, nb_: mlp(nf_, nb_) - (nf_ + nb_) * HEAD_FLOP_PER_SAMPLE                # noqa: E731
         roof, extra_roof = None, {}
-        if not args.container and (Nc, Nf) == (64, 128):
+        if wide:
+            # whole-step figure: GEMM FLOPs of every MLP evaluation (x3 in training: forward, data and weight gradients) over
+            # the step time -- the layer-by-layer path is ~40 launches per step, no single kernel dominates
+            mac = lambda m_: sum(p.numel() for k_, p in m_.named_parameters() if k_.endswith('weight') and not k_.startswith('embedding_a'))   # noqa: E731
+            fl = 2.0 * ((n_fg_c + n_fg_f) * mac(work[0]['fg']) + (n_bg_c + n_bg_f) * mac(work[0]['bg'])) * (3 if args.mode == 'train' else 1)
+            ach = fl * len(work) / (dt / args.steps) / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'kernel': 'whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages',
+                    'algorithmic_gflop_per_step': round(fl * len(work) / 1e9, 1)}
+        elif not args.container and (Nc, Nf) == (64, 128):
             if args.mode == 'train':
                 # The weight-gradient GEMMs of every layer of the fg AND bg model in one launch (algorithmic FLOPs = 2 x rows x
                 # sum_l M_l N_l over the MFMA layers); the dominant kernel round 1 was judged on.
@@ -443,7 +456,7 @@ def main():
                 extra_roof = {'fine launch only': roofline(('fwd_fine',), 'k_mlp_fwd_multi<fg, bg, false>', mlp(n_fg_f, n_bg_f),
                                                            'k_mlp_fwd_multi_eval_fine')}
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and not args.container:          # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and not args.container and not wide:          # rank 0 at N = 1 only
             w = work[0]
             b = w['batch']
             cpu = cpu_baseline(hp, b[0].cpu().numpy(), b[1].cpu().numpy(), b[2].cpu().numpy(), w['fw'], w['bw'], w['fcfg'], w['bcfg'],
@@ -464,7 +477,8 @@ def main():
             'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.submodules else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs/mega-nerf Rubble-shaped fg+bg NeRF (8x256, 12/4 freqs, 48-d appearance), '
+            'config': {'workload': 'configs/mega-nerf %s-shaped fg+bg NeRF (fg 8x%d, bg 8x%d, 12/4 freqs, 48-d appearance), ' % (
+                                       'Building' if wide else 'Rubble', args.layer_dim, hp.bg_layer_dim) +
                                    '%d rays x (%d+%d) samples per submodule step, %s' % (args.rays, Nc, Nf, shard),
                        'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg, 'submodules': total_cells,
                        'parallelism': 'submodule-per-gpu x%d' % world if not args.submodules else 'submodules %d over %d gpus' % (args.submodules, world)},

@@ -122,6 +122,8 @@ class FusedTape:
 
 
 class NeRF(nn.Module):
+    prefer_wide_layerwise = True      # evaluate(): layer_dim >= 512 takes the tiled per-layer GEMMs for large launches (diagnostics flip it)
+
     def __init__(self, pos_xyz_dim: int, pos_dir_dim: int, layers: int, skip_layers: List[int], layer_dim: int,
                  appearance_dim: int, affine_appearance: bool, appearance_count: int, rgb_dim: int, xyz_dim: int,
                  sigma_activation: nn.Module):
@@ -225,7 +227,11 @@ class NeRF(nn.Module):
                  n_units_dev: Optional[torch.Tensor] = None, rows_per_unit: int = 0) -> torch.Tensor:
         """Enqueue one fused MLP launch on the current stream (no host sync).  All tensors are raw device
         buffers; see ``mnr_mlp_io`` in include/mnr_api.h for the row/ray addressing."""
-        if not self.fused_supported():
+        # layer_dim >= 512: once a launch fills the chip the tiled per-layer GEMMs (csrc/tgemm.hip, 118 TFLOP/s at 196 608
+        # rows of the 8 x 512 model) beat the register-chained kernel (100: one wave per SIMD, nothing hides its weight stream)
+        wide = (self.prefer_wide_layerwise and self.layer_dim >= 512 and self.layer_dim % 256 == 0 and n_units_dev is None and
+                n_rows >= 65536 and os.environ.get('MNR_NO_TGEMM') is None)
+        if wide or not self.fused_supported():
             return self._evaluate_layerwise(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
                                             sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit)
         desc, packed = self.packed()

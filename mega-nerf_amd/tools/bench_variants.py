@@ -64,7 +64,9 @@ def main():
                 if force_layerwise:
                     m._evaluate_layerwise(*args, None, 0)
                 else:
+                    m.prefer_wide_layerwise = False          # measure the register-chained kernel itself
                     m.evaluate(*args)
+                    m.prefer_wide_layerwise = True
 
         if m.fused_supported():
             ms = timed(lambda: fwd(False), a.reps)
