@@ -340,14 +340,21 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_enq = time.perf_counter() - t0               # host time to ENQUEUE the timed steps (diagnostic: host-bound when ~ total)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     rendering.KERNEL_EVENTS = None
+    ms1 = torch.cuda.memory_stats(dev)
+    host_diag = {'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
+                 'device_mallocs_in_timed_region': int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
+                 'alloc_retries_in_timed_region': int(ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)),
+                 'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 1e9, 1)}
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -390,7 +397,16 @@ def main():
         if args.mode == 'train':
             extras['eval_rays_per_sec_per_gpu'] = args.rays / timed(ev_fn(w['batch'], hp), args.steps, 3)
         big = make_batch(4242, 65536)                                   # image_pixel_batch_size (opts.py:75)
-        extras['eval_rays_per_sec_65536_ray_batches'] = 65536 / timed(ev_fn(big, hp), 3, 1)
+        t_big = timed(ev_fn(big, hp), 3, 1)
+        extras['eval_rays_per_sec_65536_ray_batches'] = 65536 / t_big
+        with torch.no_grad():
+            nbg_big = int(render_rays_async(fgm, bgm, big[0], big[1], hp, sc, sr, True, False, True)[1])
+        # whole step (every kernel of render_rays, wall clock) against the MFMA peak: at this batch size the launches are
+        # ~40 waves of workgroups, so the partial last wave that costs the 1024-ray launches ~15 % is amortised
+        fl_big = 65536 * (Nc + Nf) * FG_FLOP_PER_SAMPLE + nbg_big * (Nc // 2 + Nf // 2) * BG_FLOP_PER_SAMPLE
+        extras['eval_65536_ray_batches_whole_step'] = {'tflops': round(fl_big / t_big / 1e12, 1),
+                                                       'frac_of_f32_mfma_peak': round(fl_big / t_big / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                                       'bg_rays': nbg_big}
         hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
         extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
         fgm.train(), bgm.train()
@@ -482,7 +498,7 @@ def main():
                                    '%d rays x (%d+%d) samples per submodule step, %s' % (args.rays, Nc, Nf, shard),
                        'mode': args.mode, 'rays_per_batch': args.rays, 'bg_rays_in_batch': n_bg, 'submodules': total_cells,
                        'parallelism': 'submodule-per-gpu x%d' % world if not args.submodules else 'submodules %d over %d gpus' % (args.submodules, world)},
-            'metric_allreduce_check_db': round(metric_reduce_check, 4),
+            'metric_allreduce_check_db': round(metric_reduce_check, 4), 'host': host_diag,
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if extra_roof and any(v is not None for v in extra_roof.values()):

@@ -307,6 +307,10 @@ typedef struct mnr_mlp_grad_launch {
     const mnr_mlp_grad_io *io;
 } mnr_mlp_grad_launch;
 int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream);
+/* ... its two halves, for callers that time or schedule them separately: the chain launch (k_mlp_bwd_multi: fills gtape / dheads,
+ * accumulates the appearance-embedding gradient) and the head gradients (sigma / rgb weights and biases from dheads + tape). */
+int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream);
+int mnr_mlp_head_grads_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream);
 
 /* Backward, step 2: weight + bias gradients of every layer over tape rows [tape_row0, tape_row0 + n_rows) in one
  * launch (so several forward passes that share a tape are reduced together).  d_out/out/idx are not read. */

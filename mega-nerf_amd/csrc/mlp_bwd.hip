@@ -669,7 +669,7 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 
 // Data-gradient chains of several segments (coarse + fine rows of the foreground and background models) in ONE launch,
 // then the head gradients of every segment.  Default 8x256 fg / bg architectures only (MNR_E_UNSUPPORTED otherwise).
-extern "C" int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+extern "C" int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
     using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
     using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
     MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
@@ -700,9 +700,16 @@ extern "C" int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int 
     if (wg == 0) return MNR_OK;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL((k_mlp_bwd_multi<CfgFG, CfgBG>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
-    int rc = check_launch("k_mlp_bwd_multi");
-    // head gradients: segments that continue each other in one tape (coarse + fine rows of the foreground) go out as one launch
+    return check_launch("k_mlp_bwd_multi");
+}
+
+extern "C" int mnr_mlp_head_grads_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
+    hipStream_t s = as_stream(stream);
+    int rc = MNR_OK;
+    // segments that continue each other in one tape (coarse + fine rows of the foreground) go out as one launch
     for (int i = 0; i < n_segs && rc == MNR_OK; ++i) {
+        MNR_REQUIRE(segs[i].desc && segs[i].io, "segment %d: NULL argument", i);
         mnr_mlp_grad_io io = *segs[i].io;
         while (i + 1 < n_segs && !io.n_units_dev && !segs[i + 1].io->n_units_dev && segs[i + 1].io->tape == io.tape &&
                segs[i + 1].io->dheads == io.dheads && segs[i + 1].io->tape_row0 == io.tape_row0 + io.n_rows &&
@@ -713,6 +720,11 @@ extern "C" int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int 
         rc = launch_head_grads(segs[i].desc, &io, s);
     }
     return rc;
+}
+
+extern "C" int mnr_mlp_backward_data_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+    const int rc = mnr_mlp_backward_chain_multi(segs, n_segs, stream);
+    return rc != MNR_OK ? rc : mnr_mlp_head_grads_multi(segs, n_segs, stream);
 }
 
 extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_grad_io *io, void *stream) {

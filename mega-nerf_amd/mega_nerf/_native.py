@@ -134,7 +134,7 @@ EXPORTS = [
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
     'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
-    'mnr_tgemm_run', 'mnr_wgrad_jobs',
+    'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -196,6 +196,8 @@ def lib() -> C.CDLL:
         _lib.mnr_mlp_backward_weights.argtypes = [C.POINTER(ModelDesc), C.POINTER(MlpGradIO), C.c_void_p]
         _lib.mnr_mlp_forward_multi.argtypes = [C.POINTER(MlpLaunch), C.c_int, C.c_void_p]
         _lib.mnr_mlp_backward_data_multi.argtypes = [C.POINTER(MlpGradLaunch), C.c_int, C.c_void_p]
+        _lib.mnr_mlp_backward_chain_multi.argtypes = [C.POINTER(MlpGradLaunch), C.c_int, C.c_void_p]
+        _lib.mnr_mlp_head_grads_multi.argtypes = [C.POINTER(MlpGradLaunch), C.c_int, C.c_void_p]
         _lib.mnr_affine_apply.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                           C.c_int64, C.c_int64, C.c_void_p]
         _lib.mnr_affine_backward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

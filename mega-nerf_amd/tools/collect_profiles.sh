@@ -11,13 +11,24 @@ export TMPDIR=/tmp
 cd /tmp
 for mode in train eval; do
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_$mode" -o t --output-format csv -- \
-      python "$B" --mode $mode --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_${mode}_under_rocprof.json" 2> "$OUT/trace_$mode.err"
+      python "$B" --mode $mode --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_${mode}_under_rocprof.json" 2> "$OUT/trace_$mode.err" < /dev/null
   timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_fetch_$mode" -o p --output-format csv -- \
-      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_fetch_$mode.err"
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_fetch_$mode.err" < /dev/null
   timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_write_$mode" -o p --output-format csv -- \
-      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_write_$mode.err"
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_write_$mode.err" < /dev/null
   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
       --kernel-trace -d "$OUT/pmc_sq_$mode" -o p --output-format csv -- \
-      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_sq_$mode.err"
+      python "$B" --mode $mode --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> "$OUT/pmc_sq_$mode.err" < /dev/null
 done
+# Building-shaped foreground (layer_dim 512): kernel trace + the SQ / HBM passes of the training step
+W5="--layer-dim 512 --no-cpu-baseline --no-extras"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_w512" -o t --output-format csv -- \
+    python "$B" $W5 --steps 10 --warmup 3 > "$OUT/bench_w512_under_rocprof.json" 2> "$OUT/trace_w512.err" < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_fetch_w512" -o p --output-format csv -- \
+    python "$B" $W5 --steps 3 --warmup 2 > /dev/null 2> "$OUT/pmc_fetch_w512.err" < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_write_w512" -o p --output-format csv -- \
+    python "$B" $W5 --steps 3 --warmup 2 > /dev/null 2> "$OUT/pmc_write_w512.err" < /dev/null
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+    --kernel-trace -d "$OUT/pmc_sq_w512" -o p --output-format csv -- \
+    python "$B" $W5 --steps 3 --warmup 2 > /dev/null 2> "$OUT/pmc_sq_w512.err" < /dev/null
 ls "$OUT"

@@ -24,13 +24,17 @@ from collections import defaultdict
 from pathlib import Path
 
 KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid size))
-    'k_wgrad2': ('train', lambda n, g: 'k_wgrad2(' in n),
+    'k_wgrad2': ('train', lambda n, g: 'k_wgrad2<' in n or 'k_wgrad2(' in n),
     'k_wgrad2_reduce': ('train', lambda n, g: 'k_wgrad2_reduce' in n),
     'k_mlp_fwd_multi_train': ('train', lambda n, g: 'k_mlp_fwd_multi' in n and 'true>' in n),
     'k_mlp_bwd_multi': ('train', lambda n, g: 'k_mlp_bwd_multi' in n),
     'k_head_grads': ('train', lambda n, g: 'k_head_grads' in n),
     'k_mlp_fwd_multi_eval': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and 'false>' in n),
     'k_mlp_fwd_multi_eval_fine': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and 'false>' in n and g >= 2048 * 256),
+    # Building-shaped foreground (layer_dim 512): tiled GEMMs + job-form weight gradients of the layer-by-layer path
+    'k_tgemm_forward_w512': ('w512', lambda n, g: 'k_tgemm<false' in n),
+    'k_tgemm_data_gradient_w512': ('w512', lambda n, g: 'k_tgemm<true' in n),
+    'k_wgrad2_jobs_w512': ('w512', lambda n, g: 'k_wgrad2<1>' in n),
 }
 
 
@@ -57,13 +61,13 @@ def med(xs):
 def main():
     src, dst, rnd = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
     dst.mkdir(exist_ok=True)
-    for mode in ('train', 'eval'):
+    for mode in ('train', 'eval', 'w512'):
         for f in glob.glob(str(src / ('trace_' + mode) / '**' / '*kernel_stats.csv'), recursive=True):
             shutil.copy(f, dst / ('%s_%s_kernel_stats.csv' % (rnd, mode)))
         j = src / ('bench_%s_under_rocprof.json' % mode)
         if j.exists() and j.stat().st_size:
             shutil.copy(j, dst / ('%s_bench_%s_under_rocprof.json' % (rnd, mode)))
-    passes = {(kind, mode): load_pass(src / ('pmc_%s_%s' % (kind, mode))) for kind in ('fetch', 'write', 'sq') for mode in ('train', 'eval')}
+    passes = {(kind, mode): load_pass(src / ('pmc_%s_%s' % (kind, mode))) for kind in ('fetch', 'write', 'sq') for mode in ('train', 'eval', 'w512')}
     out = {}
     for key, (mode, pred) in KERNELS.items():
         e = {}
