@@ -488,25 +488,31 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
 }
 
 // sigma / rgb head weight gradients:  d w_sigma[W] = sum_r ds[r] * a_{L-1}[r][:],  d w_rgb[3][W/2] = sum_r dr[r][c] * d[r][:]
-__global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
+// Pure streaming (1.5 KB per row): HBM-bound, so what matters is loads in flight.  A block is 16 waves = 4 groups of 256
+// threads; group g takes the 8-row chunks g, g + 4, g + 8, ... of the block's row range, every load of a chunk issued
+// before its first use.  In a group thread t owns sigma-head feature t (W == 256) and rgb-head feature t & 127 for the
+// rows of parity t >> 7 (W2 == 128); the bias sums ride on values the thread loads anyway (dheads is read by every
+// thread: a broadcast).  Groups are combined in LDS, one set of 644 atomics per block (few, long blocks: round 1
+// launched 1024 small blocks per segment and spent most of its time on those same-address atomics).
+constexpr int HG_GROUPS = 4;
+__global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
                                                     const float *__restrict__ dact, int W2, long row0, long n_rows,
                                                     const int32_t *__restrict__ n_units_dev, int rows_per_unit,
                                                     float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
                                                     float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb) {
+    __shared__ float red[HG_GROUPS][256 + 3 * 128 + 8];
     const long n = n_units_dev ? (long)(*n_units_dev) * rows_per_unit : n_rows;
-    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long per = ((n + gridDim.x - 1) / gridDim.x + 7) / 8 * 8;            // whole 8-row chunks per block
     const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
     if (rb >= re) return;
     const long r0 = row0 + rb, r1 = row0 + re;
-    const int t = threadIdx.x;
-    // One pass over the rows, 8 at a time with every load issued before the first use (the kernel is pure streaming:
-    // 1.5 KB per row, latency-bound unless many loads are in flight).  Thread t owns sigma-head feature t (W == 256 ==
-    // blockDim) and rgb-head feature t & 127 for the rows of parity t >> 7 (W2 == 128).
+    const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
     const int f2 = t & (W2 - 1), par = t >> 7;
     float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float sr[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    long r = r0;
-    for (; r + 7 < r1; r += 8) {
+    float bs = 0.f, br[3] = {0.f, 0.f, 0.f};
+    long r = r0 + 8 * grp;
+    for (; r + 7 < r1; r += 8 * HG_GROUPS) {
         float al[8], hs[8], da[4];
         float4 h4[4];
 #pragma unroll
@@ -520,32 +526,70 @@ __global__ __launch_bounds__(256) void k_head_grads(const float *__restrict__ dh
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss[j] = fmaf(hs[j], al[j], ss[j]);
+        for (int j = 0; j < 8; ++j) { ss[j] = fmaf(hs[j], al[j], ss[j]); bs += hs[j]; }
         if (with_rgb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sr[j][0] = fmaf(h4[j].x, da[j], sr[j][0]); sr[j][1] = fmaf(h4[j].y, da[j], sr[j][1]);
                 sr[j][2] = fmaf(h4[j].z, da[j], sr[j][2]);
+                br[0] += h4[j].x; br[1] += h4[j].y; br[2] += h4[j].z;
             }
         }
     }
-    for (; r < r1; ++r) {                                   // ragged tail of the row range
-        ss[0] = fmaf(dheads[r * 4 + 3], a_last[r * W + t], ss[0]);
-        if (with_rgb && ((r - r0) & 1) == par) {
-            const float d = dact[r * W2 + f2];
-            sr[0][0] = fmaf(dheads[r * 4 + 0], d, sr[0][0]); sr[0][1] = fmaf(dheads[r * 4 + 1], d, sr[0][1]);
-            sr[0][2] = fmaf(dheads[r * 4 + 2], d, sr[0][2]);
+    // ragged tail of the row range (< 8 rows): the group whose turn it would be takes it row by row
+    if (r < r1) {
+        for (; r < r1; ++r) {
+            const float h = dheads[r * 4 + 3];
+            ss[0] = fmaf(h, a_last[r * W + t], ss[0]);
+            bs += h;
+            if (with_rgb && ((r - r0) & 1) == par) {
+                const float d = dact[r * W2 + f2];
+                const float4 h4 = *reinterpret_cast<const float4 *>(dheads + r * 4);
+                sr[0][0] = fmaf(h4.x, d, sr[0][0]); sr[0][1] = fmaf(h4.y, d, sr[0][1]); sr[0][2] = fmaf(h4.z, d, sr[0][2]);
+                br[0] += h4.x; br[1] += h4.y; br[2] += h4.z;
+            }
         }
     }
-    atomicAdd(d_sigma_w + t, ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7])));
+    float *mine = red[grp];
+    mine[t] = ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7]));
+    // rgb partials of the two row parities of feature f2 land in different slots and are added below
     if (with_rgb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(d_rgb_w + c * W2 + f2, (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]));
+        for (int c = 0; c < 3; ++c) {
+            if (par == 0) mine[256 + c * 128 + f2] = (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]);
+        }
     }
-    if (t < 4 && (with_rgb || t == 3)) {                   // biases
-        float s = 0.f;
-        for (long r = r0; r < r1; ++r) s += dheads[r * 4 + t];
-        atomicAdd(t < 3 ? d_rgb_b + t : d_sigma_b, s);
+    __syncthreads();
+    if (with_rgb && par == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[256 + c * 128 + f2] += (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]);
+    }
+    if (t == 0) mine[256 + 384] = bs;                                   // sigma bias: every thread saw every row of its group
+    if (with_rgb && f2 == 0) {                                          // rgb biases: threads 0 and 128 hold the two parities
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[256 + 384 + 1 + 3 * par + c] = br[c];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < HG_GROUPS; ++g) v += red[g][t];
+        atomicAdd(d_sigma_w + t, v);
+        if (with_rgb) {
+            for (int e = t; e < 384; e += 256) {
+                float u = 0.f;
+#pragma unroll
+                for (int g = 0; g < HG_GROUPS; ++g) u += red[g][256 + e];
+                atomicAdd(d_rgb_w + e, u);
+            }
+        }
+        if (t < 4 && (with_rgb || t == 3)) {
+            float u = 0.f;
+#pragma unroll
+            for (int g = 0; g < HG_GROUPS; ++g)
+                u += t == 3 ? red[g][256 + 384] : red[g][256 + 384 + 1 + t] + red[g][256 + 384 + 4 + t];
+            atomicAdd(t < 3 ? d_rgb_b + t : d_sigma_b, u);
+        }
     }
 }
 
@@ -629,7 +673,7 @@ static int launch_head_grads(const mnr_model_desc *d, const mnr_mlp_grad_io *io,
     // every block ends with 644 atomics on the same addresses: few, long blocks (round 1 launched 1024 per segment and spent
     // 60-125 us per launch mostly there)
     const long blocks = io->n_units_dev ? 48 : (io->n_rows + 767) / 768;
-    hipLaunchKernelGGL(k_head_grads, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks))), dim3(256), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
+    hipLaunchKernelGGL(k_head_grads, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks))), dim3(256 * HG_GROUPS), 0, s, io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, W,
                        io->tape + (long)tl.dact_off * cap, W / 2, (long)io->tape_row0, (long)io->n_rows, io->n_units_dev,
                        io->rows_per_unit, G.sigma_w, G.sigma_b, G.rgb_w, G.rgb_b, d->rgb_dim == 3 ? 1 : 0);
     return check_launch("k_head_grads");
