@@ -104,7 +104,12 @@ __device__ __forceinline__ MaskBits<NH> mask_load(const float *plane, long row, 
 template <int NH>
 __device__ __forceinline__ void mask_apply(float (&g)[NH], const MaskBits<NH> &m) {
 #pragma unroll
-    for (int i = 0; i < NH; ++i) g[i] = (m.w[i / 32] >> (i % 32)) & 1u ? g[i] : 0.f;
+    // bit -> 0 / ~0 by a sign-extending 1-bit field extract, then AND: 2 VALU instructions per value (select form: 3)
+    // (inline asm: LLVM canonicalises `x & sext(bit)` back into compare + select)
+    for (int i = 0; i < NH; ++i) {
+        int t;
+        asm("v_bfe_i32 %1, %2, %3, 1\n\tv_and_b32 %0, %0, %1" : "+v"(g[i]), "=&v"(t) : "v"(m.w[i / 32]), "n"(i % 32));
+    }
 }
 // write dZ to the gradient tape (flat register i <-> feature 4P*(i/4) + 4*part + i%4).  Callers issue this right
 // AFTER a chunk barrier of the next layer: a barrier drains vmcnt, so a store issued just before one would stall the
@@ -144,7 +149,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     const long trow = rc + a.tape_row0;          // row in tape space
 
     WStream st;
-    st.g = a.chunks;
+    st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(a.chunks)));      // into SGPRs once: the stream pointer arithmetic stays scalar
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();

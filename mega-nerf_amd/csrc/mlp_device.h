@@ -47,6 +47,14 @@ struct MlpCfg {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
+// marks a pointer as wave-uniform (it is: derived from kernel arguments and block / tile indices) so that pointer + 32-bit
+// lane offset selects the SGPR-base addressing form
+__device__ __forceinline__ const char *uniform_ptr(const char *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
 struct WStream {
     const float4 *g;     // the next chunk to load (uniform: lives in SGPRs; the lane's 16-byte slot is added as a 32-bit offset)
     float4 *lds;         // base of the 2-chunk LDS ring
@@ -56,11 +64,17 @@ struct WStream {
         // then computed on the scalar unit -- VALU instructions inside the MFMA stream cost matrix-pipe issue slots
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;      // wave-uniform base; HW adds lane*16
-        const unsigned lane_off = threadIdx.x * 16u;                // scalar base + 32-bit lane offset: no 64-bit VALU address math
+        // scalar base + 32-bit lane offset: the SGPR-base form of the load.  Every piece gets its own scalar base
+        // (s_add_u32 / s_addc_u32): left to itself hipcc forms ONE per-lane 64-bit address and adds the piece offsets with a
+        // v_lshl_add_u64 each (they exceed the 12-bit immediate) -- 8 VALU instructions per chunk inside the MFMA stream
+        const unsigned lane_off = threadIdx.x * 16u;
 #pragma unroll
-        for (int i = 0; i < CHUNK_F4 / 256; ++i)
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(reinterpret_cast<const char *>(g + i * 256) + lane_off),
+        for (int i = 0; i < CHUNK_F4 / 256; ++i) {
+            unsigned lo = lane_off;
+            asm("" : "+v"(lo));          // a fresh 32-bit value per piece: otherwise its zero-extension is hoisted and the add goes 64-bit VALU again
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + i * 256)) + lo),
                                              (lds_void_t *)(dst + i * 256), 16, 0, 0);
+        }
         g += CHUNK_F4;
     }
     // publish the chunk in flight (hipcc drains vmcnt before the barrier), make it current, start the next one

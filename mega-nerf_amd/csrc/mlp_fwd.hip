@@ -52,7 +52,13 @@ __device__ __forceinline__ void tape_store_mask(float *plane, long row, int widt
 #pragma unroll
     for (int i = 0; i < NW; ++i) w[i] = 0u;
 #pragma unroll
-    for (int i = 0; i < NH; ++i) w[i / 32] |= h[i] > 0.f ? (1u << (i % 32)) : 0u;
+    // h is a ReLU output (>= +0, never -0: relu_bits), so h > 0 <=> its bit pattern is non-zero: min(bits, 1) << i, OR-ed in with
+    // one v_lshl_or_b32 -- 2 VALU instructions per value (compare + select + or: 3)
+    // (inline asm: LLVM turns the min back into compare + select)
+    for (int i = 0; i < NH; ++i) {
+        unsigned t;
+        asm("v_min_u32 %1, 1, %2\n\tv_lshl_or_b32 %0, %1, %3, %0" : "+v"(w[i / 32]), "=&v"(t) : "v"(h[i]), "n"(i % 32));
+    }
     if constexpr (NW == 2) *reinterpret_cast<uint2 *>(r) = make_uint2(w[0], w[1]);
     else {
 #pragma unroll
@@ -120,7 +126,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     const long ray = src / io.rows_per_ray;
 
     WStream st;
-    st.g = chunks;
+    st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));      // into SGPRs once: the stream pointer arithmetic stays scalar
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();                                   // chunk 0 in flight while we encode

@@ -48,14 +48,6 @@ struct TgArgs {
 
 // BKS: k-slow weights;  BIAS / GATE / R1: which epilogue terms exist (compile-time, so the epilogue is branch-free and its
 // loads are issued together)
-// marks a pointer as wave-uniform (it is: derived from kernel arguments and the tile index) so that pointer + 32-bit lane
-// offset selects the SGPR-base addressing form
-__device__ __forceinline__ const char *uniform_ptr(const char *p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
-}
-
 template <bool BKS, bool BIAS, bool GATE, bool R1>
 __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
     extern __shared__ float tg_lds[];
