@@ -35,6 +35,17 @@ struct MlpFwdArgs {
     TapeLayout tl;
 };
 
+// The tape row of a lane, re-derived at every store site from an SGPR (first tape row of the wave) and a freshly read lane
+// id (v_mbcnt: needs no input register): nothing row-related stays live in VGPRs across the layers.  Kept as a value computed
+// once, the row offset was spilled (the kernel sits at its 256-register budget), and every layer's reload (`scratch_load` +
+// vmcnt(0)) drained the weight chunk that had just been requested.
+template <int TILE>
+__device__ __forceinline__ long tape_row(unsigned wave_row0) {
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return (long)(wave_row0 + (l & (TILE - 1)));
+}
+
 // tape stores (training): flat register i of a C-layout array <-> feature 4P*(i/4) + 4*part + i%4
 template <int P, int NH>
 __device__ __forceinline__ void tape_store_regs(float *plane, long row, int width, const float (&h)[NH], int part) {
@@ -117,10 +128,18 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
         if (blk * C::ROWS_PER_WG >= n_rows) return;             // uniform per workgroup
     }
 
+    // the per-cell pointers come out of a device table (vector loads), so the merged values would live in VGPR pairs for the
+    // whole kernel -- and get spilled: every layer then reloaded `aux` from scratch and waited vmcnt(0) for it, draining the
+    // weight prefetch in the middle of the layer.  They are uniform: move them to SGPRs.
+    aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(aux)));
+    emb_a = reinterpret_cast<decltype(emb_a)>(uniform_ptr(reinterpret_cast<const char *>(emb_a)));
+    outp = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(outp))));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
     const long row = (blk * 4 + wave) * TILE + (lane % TILE);
     const bool valid = row < n_rows;
+    // first tape row of this wave (training; uniform -> SGPR; tapes hold < 2^32 rows)
+    const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * 4 + wave) * TILE + a.tape_row0));
     const long rc = valid ? row : n_rows - 1;
     const long src = row_index ? (long)row_index[rc] : rc;           // gathered evaluation (MegaNeRF router)
     const long ray = src / io.rows_per_ray;
@@ -137,7 +156,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     float ex[C::EX];
     embed<C::XYZ, C::LX, P>(ex, x, part);
     if constexpr (TRAIN) {
-        if (valid) tape_store_emb<C::XYZ, C::LX, P>(a.tape + a.tl.embx_off * a.tape_rows, row + a.tape_row0, a.tl.embx_w, ex, part);
+        if (valid) tape_store_emb<C::XYZ, C::LX, P>(a.tape + a.tl.embx_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.embx_w, ex, part);
     }
 
     float h[H];
@@ -153,8 +172,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
             // Tape stores of the previous layer's output are issued right AFTER the chunk barrier: a barrier drains
             // vmcnt, so stores issued just before one would stall the wave for a full HBM write round trip.
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, row + a.tape_row0, C::W, h, part);
-                tape_store_mask<P>(a.tape + a.tl.mask_off[l - 1] * a.tape_rows, row + a.tape_row0, a.tl.mask_w, h, part);
+                tape_store_regs<P>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
+                tape_store_mask<P>(a.tape + a.tl.mask_off[l - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
         if constexpr (l == 0) {
@@ -197,8 +216,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
         st.next_chunk();
         if constexpr (TRAIN) {                                   // deferred store of the last trunk layer (see above)
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, row + a.tape_row0, C::W, h, part);
-                tape_store_mask<P>(a.tape + a.tl.mask_off[C::NL - 1] * a.tape_rows, row + a.tape_row0, a.tl.mask_w, h, part);
+                tape_store_regs<P>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
+                tape_store_mask<P>(a.tape + a.tl.mask_off[C::NL - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
@@ -210,7 +229,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
         init_acc<NOB2, RPB>(acc2, aux + a.bias_off[li] + part * H2);
         st.next_chunk();
         if constexpr (TRAIN) {
-            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, row + a.tape_row0, C::W, h, part);
+            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
         }
         run_segment<TILE, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane);
         if constexpr (C::ED > 0) {
@@ -220,7 +239,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
             float ed[C::ED];
             embed<3, C::LD, P>(ed, dv, part);
             if constexpr (TRAIN) {
-                if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, row + a.tape_row0, a.tl.embd_w, ed, part);
+                if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.embd_w, ed, part);
             }
             run_segment<TILE, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane);
         }
@@ -234,7 +253,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
             for (int i = 0; i < C::AP; ++i) ap[i] = (i < C::APP / P) ? ea[i] : 0.f;
             if constexpr (TRAIN) {
                 if (valid) {
-                    float *r = a.tape + a.tl.app_off * a.tape_rows + (row + a.tape_row0) * a.tl.app_w + part * (C::APP / P);
+                    float *r = a.tape + a.tl.app_off * a.tape_rows + tape_row<TILE>(trow0) * a.tl.app_w + part * (C::APP / P);
 #pragma unroll
                     for (int i = 0; i < C::APP / P; ++i) r[i] = ap[i];
                 }
@@ -245,8 +264,8 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
         acc_to_regs<NOB2, RPB, true>(dreg, acc2);
         if constexpr (TRAIN) {
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, row + a.tape_row0, C::W / 2, dreg, part);
-                tape_store_mask<P>(a.tape + a.tl.dmask_off * a.tape_rows, row + a.tape_row0, a.tl.dmask_w, dreg, part);
+                tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, tape_row<TILE>(trow0), C::W / 2, dreg, part);
+                tape_store_mask<P>(a.tape + a.tl.dmask_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.dmask_w, dreg, part);
             }
         }
 #pragma unroll
