@@ -131,9 +131,11 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     // the per-cell pointers come out of a device table (vector loads), so the merged values would live in VGPR pairs for the
     // whole kernel -- and get spilled: every layer then reloaded `aux` from scratch and waited vmcnt(0) for it, draining the
     // weight prefetch in the middle of the layer.  They are uniform: move them to SGPRs.
-    aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(aux)));
-    emb_a = reinterpret_cast<decltype(emb_a)>(uniform_ptr(reinterpret_cast<const char *>(emb_a)));
-    outp = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(outp))));
+    if constexpr (TRAIN) {          // (the eval instantiation fits its 252 registers without this and spills 26 with it)
+        aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(aux)));
+        emb_a = reinterpret_cast<decltype(emb_a)>(uniform_ptr(reinterpret_cast<const char *>(emb_a)));
+        outp = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(outp))));
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
     const long row = (blk * 4 + wave) * TILE + (lane % TILE);
@@ -382,8 +384,15 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
 
 }  // namespace mnr
 
-#ifdef MNR_PROBE_TRAIN      // codegen probe (not part of the library): only the foreground training kernel
+#ifdef MNR_PROBE_TRAIN      // codegen probes (not part of the library): -DMNR_PROBE_TRAIN=1 the foreground training kernel,
+                            // =2 / =3 the two-model launch in its eval / training instantiation (seconds instead of minutes)
+#if MNR_PROBE_TRAIN == 2
+template __global__ void mnr::k_mlp_fwd_multi<mnr::MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, mnr::MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>, false>(mnr::MlpFwdMulti);
+#elif MNR_PROBE_TRAIN == 3
+template __global__ void mnr::k_mlp_fwd_multi<mnr::MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, mnr::MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>, true>(mnr::MlpFwdMulti);
+#else
 template __global__ void mnr::k_mlp_fwd<mnr::MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, true>(mnr::MlpFwdArgs);
+#endif
 #else
 using namespace mnr;
 
