@@ -84,7 +84,8 @@ class MegaNeRF(nn.Module):
         out.zero_()
         blend = self.boundary_margin > 1
         kids = list(self.sub_modules)
-        same_arch = all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) for c in kids)
+        # (mnr_mlp_forward_cells takes at most 64 cells per launch: larger grids go cell by cell below)
+        same_arch = n_sub <= 64 and all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) for c in kids)
         if same_arch:
             # one launch for all cells: each cell alone (~1/n of the rows) cannot fill 256 CUs
             sub_out = torch.empty(n_sub, B, ncol, device=dev, dtype=torch.float32)

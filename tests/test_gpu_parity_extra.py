@@ -239,3 +239,22 @@ def test_batched_weight_gradients(mode, monkeypatch):
             if not (e < 5e-6 and loose < 0.2 and np.abs(r).max() > 0):
                 bad[name + '.' + k] = (e, loose)
     assert not bad, bad
+
+
+def test_default_width_model_built_under_inference_mode():
+    """Reference-style callers (render_images.py, create_octree.py, the merge / convert scripts) build or load the model inside
+    ``torch.inference_mode()``: its parameters then carry no version counter.  The 256-wide model goes through the packed-weight
+    cache of the fused kernel (the 32-wide merge-script golden does not), which must neither raise nor go stale."""
+    from test_gpu_parity import mlp_variant
+    hp, cfg, w = mlp_variant('fg')
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-1, 1, (300, 3)), rng.standard_normal((300, 3)), rng.integers(0, 100, (300, 1))], 1).astype(f32)
+    with torch.inference_mode():
+        m = native_nerf(cfg, w)
+        assert all(p.is_inference() for p in m.parameters())
+        a = m(T(x)).cpu().numpy()
+        b = m(T(x)).cpu().numpy()                   # second call: cache hit
+    with torch.no_grad():
+        c = native_nerf(cfg, w)(T(x)).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
