@@ -233,6 +233,34 @@ def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode
     return out
 
 
+def cpu_baseline_container(hp, rays_np, idx_np, cells):
+    """Routed evaluation through a merged container on the host: the numpy restatement of the reference (oracle/nerf_oracle.py,
+    pinned to the container goldens; the torch restatement has no MegaNeRF router).  BLAS threads as numpy finds them; a
+    bounded sample of the same batch."""
+    import numpy as np
+    import synthetic_scene as S
+    from oracle import nerf_oracle as O
+    s = S.SCENE
+    cores = usable_cores()
+    fg = O.Model(cells['fcfg'], subs=cells['fg'], centroids=cells['cent'], boundary_margin=float(hp.boundary_margin), xyz_real=False, cluster_2d=False)
+    bg = O.Model(cells['bcfg'], subs=cells['bg'], centroids=cells['cent'], boundary_margin=float(hp.boundary_margin), xyz_real=True, cluster_2d=False)
+    ohp = O.make_hparams(**{k: getattr(hp, k) for k in vars(O.make_hparams()) if hasattr(hp, k)})
+    ohp.perturb, ohp.container_path = 0.0, 'bench'
+
+    def run(n):
+        t = time.perf_counter()
+        O.render_rays(fg, bg, rays_np[:n], idx_np[:n], ohp, s['sphere_center'], s['sphere_radius'], get_depth=True,
+                      get_depth_variance=False, get_bg_fg_rgb=True)
+        return time.perf_counter() - t
+    run(8)                                   # warm-up (first-call overheads of numpy / BLAS)
+    t_probe = run(16)
+    n = int(max(16, min(rays_np.shape[0], 16 * 10.0 / max(t_probe, 1e-3))))          # ~10 s of host work
+    dt = run(n)
+    return {'value': n / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': 'numpy restatement of the reference (render_rays through the routed %d-cell container, eval flags), first %d rays '
+                      'x (%d+%d) samples of the same batch, one run after a 16-ray probe' % (len(cells['fg']), n, hp.coarse_samples, hp.fine_samples)}
+
+
 # ---- main ------------------------------------------------------------------------------------------------------------
 
 def main():
@@ -310,6 +338,9 @@ def main():
         sub = [build_models(hp, dev, 1000 * (rank + 1) + 7 * j, args.layer_dim) for j in range(n)]
         work[0]['fg'] = MegaNeRF([c[0][0] for c in sub], cent, hp.boundary_margin, False, False).to(dev)
         work[0]['bg'] = MegaNeRF([c[1][0] for c in sub], cent, hp.boundary_margin, True, False).to(dev)
+        for k in ('fg', 'bg'):               # device-side tally of the rows the router hands to cells (a row near a boundary goes to two)
+            work[0][k].routed_rows = torch.zeros((), device=dev, dtype=torch.int64)
+        work[0]['cells_np'] = dict(cent=cent.numpy(), fg=[c[0][2] for c in sub], bg=[c[1][2] for c in sub], fcfg=sub[0][0][1], bcfg=sub[0][1][1])
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
 
     steppers = []
@@ -340,6 +371,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.container:
+        work[0]['fg'].routed_rows.zero_(), work[0]['bg'].routed_rows.zero_()
     ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -444,7 +477,18 @@ def main():
         mlp = lambda nf_, nb_: nf_ * FG_FLOP_PER_SAMPLE + nb_ * BG_FLOP_PER_SAMPLE                      # noqa: E731
         mfma_only = lambda nf_, nb_: mlp(nf_, nb_) - (nf_ + nb_) * HEAD_FLOP_PER_SAMPLE                # noqa: E731
         roof, extra_roof = None, {}
-        if wide:
+        if args.container:
+            # whole-step figure from the device-side routed row counts (a row inside the boundary margin is evaluated by two cells)
+            r_fg, r_bg = int(work[0]['fg'].routed_rows), int(work[0]['bg'].routed_rows)
+            fl = (r_fg * FG_FLOP_PER_SAMPLE + r_bg * BG_FLOP_PER_SAMPLE) / args.steps
+            ach = fl / (dt / args.steps) / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'kernel': 'whole step (k_mlp_fwd gather mode: all cells of a pass in one launch; k_route, k_route_combine, render stages), wall clock',
+                    'routed_rows_per_step': {'fg': r_fg // args.steps, 'bg': r_bg // args.steps,
+                                             'unrouted': {'fg': args.rays * (Nc + Nf), 'bg': max(n_bg, 0) * (Nc // 2 + Nf // 2)}},
+                    'algorithmic_gflop_per_step': round(fl / 1e9, 1)}
+        elif wide:
             # whole-step figure: GEMM FLOPs of every MLP evaluation (x3 in training: forward, data and weight gradients) over
             # the step time -- the layer-by-layer path is ~40 launches per step, no single kernel dominates
             mac = lambda m_: sum(p.numel() for k_, p in m_.named_parameters() if k_.endswith('weight') and not k_.startswith('embedding_a'))   # noqa: E731
@@ -472,6 +516,8 @@ def main():
                 extra_roof = {'fine launch only': roofline(('fwd_fine',), 'k_mlp_fwd_multi<fg, bg, false>', mlp(n_fg_f, n_bg_f),
                                                            'k_mlp_fwd_multi_eval_fine')}
         cpu = None
+        if not args.no_cpu_baseline and world == 1 and args.container and not wide:
+            cpu = cpu_baseline_container(hp, work[0]['batch'][0].cpu().numpy(), work[0]['batch'][1].cpu().numpy(), work[0]['cells_np'])
         if not args.no_cpu_baseline and world == 1 and not args.container and not wide:          # rank 0 at N = 1 only
             w = work[0]
             b = w['batch']

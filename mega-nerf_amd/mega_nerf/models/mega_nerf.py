@@ -81,6 +81,9 @@ class MegaNeRF(nn.Module):
         N.check(lib.mnr_route(pos.data_ptr(), pos_stride, B, N.ptr(n_units), rows_per_unit, self._centroids_host(), n_sub,
                               self.cluster_dim_start, float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(),
                               counts.data_ptr(), N.stream_ptr()))
+        rr = getattr(self, 'routed_rows', None)        # optional device-side tally of routed rows (bench.py: FLOPs of a routed step)
+        if rr is not None:
+            rr.add_(counts.sum())
         out.zero_()
         blend = self.boundary_margin > 1
         kids = list(self.sub_modules)
