@@ -29,8 +29,8 @@
 namespace mnr {
 
 constexpr int TG_THREADS = 512;
-constexpr int TG_BM = 256, TG_BN = 256, TG_KT = 32;
-constexpr int TG_FBW = 2, TG_RBW = 4;               // 32 x 32 blocks per wave: features x rows
+constexpr int TG_BM = 256, TG_BN = 256, TG_KT = 32;   // (TG_BM: the taller of the two tile heights; sizes the LDS stage)
+constexpr int TG_FBW = 2;                           // 32-feature blocks per wave (x RBW 32-row blocks: kernel template parameter)
 constexpr int TG_OPER_BYTES = TG_BM * TG_KT * 4;    // one operand tile = 32 KB
 constexpr int TG_STAGE_BYTES = 2 * TG_OPER_BYTES;
 
@@ -48,8 +48,11 @@ struct TgArgs {
 
 // BKS: k-slow weights;  BIAS / GATE / R1: which epilogue terms exist (compile-time, so the epilogue is branch-free and its
 // loads are issued together)
-template <bool BKS, bool BIAS, bool GATE, bool R1>
+// RBW: 32-row blocks per wave = 4 (256-row tiles) or 2 (128-row tiles: twice the tiles, for row counts whose 256-row tiling
+// leaves a poorly filled last round of workgroups)
+template <bool BKS, bool BIAS, bool GATE, bool R1, int RBW>
 __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
+    constexpr int BM = 64 * RBW;
     extern __shared__ float tg_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const unsigned po = (unsigned)(((2 * g + kk) ^ (i32 & 7)) * 16);
-        xa[g] = lds0 + (unsigned)((wr * TG_RBW * 32 + i32) * 128) + po;
+        xa[g] = lds0 + (unsigned)((wr * RBW * 32 + i32) * 128) + po;
         wa[g] = lds0 + TG_OPER_BYTES + (unsigned)((wf * TG_FBW * 32 + i32) * 128) + po;
     }
     const unsigned wb = lds0 + TG_OPER_BYTES + (unsigned)(((4 * kk) * TG_BN + wf * TG_FBW * 32 + i32) * 4);
@@ -91,14 +94,14 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
         const long lda = p ? a.lda[1] : a.lda[0], ldb = p ? a.ldb[1] : a.ldb[0];
         const unsigned xv = p ? xvo[1] : xvo[0], wv = p ? wvo[1] : wvo[0];
         float *dst = tg_lds + stage * (TG_STAGE_BYTES / 4) + wave * 256;        // wave-uniform; HW adds lane * 16 bytes
-        if (m0 + TG_BM <= a.M) {
+        if (m0 + BM <= a.M) {
             const char *ub = reinterpret_cast<const char *>(A + m0 * lda + k0);
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi)
+            for (int pi = 0; pi < RBW; ++pi)
                 __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(ub + (long)pi * 64 * lda * 4) + xv), (lds_void_t *)(dst + pi * 2048), 16, 0, 0);
         } else {
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
+            for (int pi = 0; pi < RBW; ++pi) {
                 const long row = min(m0 + pi * 64 + prow, a.M - 1);              // rows past M re-read the last row (never stored)
                 const float *src = A + row * lda + k0 + ppiece;
                 __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)(dst + pi * 2048), 16, 0, 0);
@@ -114,18 +117,18 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
         }
     };
 
-    floatx16 acc[TG_FBW][TG_RBW];
+    floatx16 acc[TG_FBW][RBW];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int f = 0; f < TG_FBW; ++f)
 #pragma unroll
-            for (int r = 0; r < TG_RBW; ++r) acc[f][r] = floatx16(0.f);
+            for (int r = 0; r < RBW; ++r) acc[f][r] = floatx16(0.f);
     };
     zero_acc();
 
     int t = vid;
     int kti = 0, s = 0;
-    long m0 = (long)(t / a.n_tiles) * TG_BM;
+    long m0 = (long)(t / a.n_tiles) * BM;
     int n0 = (t % a.n_tiles) * TG_BN;
     issue(0, m0, n0, 0);
     for (;;) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
         const bool last_k = ktn == nkt;
         if (last_k) { tn = t + (int)gridDim.x; ktn = 0; }
         const bool have = tn < a.total_tiles;
-        const long m0n = have ? (long)(tn / a.n_tiles) * TG_BM : m0;
+        const long m0n = have ? (long)(tn / a.n_tiles) * BM : m0;
         const int n0n = have ? (tn % a.n_tiles) * TG_BN : n0;
         if (have) issue(s ^ 1, m0n, n0n, ktn);
 
@@ -144,11 +147,11 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) { xs[g] = xa[g] + so; ws[g] = wa[g] + so; }
         const unsigned wbs = wb + so;
-        floatx4 xf[2][TG_RBW], wf4[2][TG_FBW];
+        floatx4 xf[2][RBW], wf4[2][TG_FBW];
         float wf1[2][4][TG_FBW];
         auto frag_read = [&](auto gc, auto bufc) {
             constexpr int g = decltype(gc)::value, buf = decltype(bufc)::value;
-            static_for<0, TG_RBW>([&](auto rc) {
+            static_for<0, RBW>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 xf[buf][r] = lds_ld4<r * 4096>(xs[g]);
             });
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
                 });
             }
         };
-        constexpr int NREADS = TG_RBW + (BKS ? 4 * TG_FBW : TG_FBW);
+        constexpr int NREADS = RBW + (BKS ? 4 * TG_FBW : TG_FBW);
         frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 4>([&](auto gc) {
             constexpr int g = decltype(gc)::value, cur = g & 1;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
                 wait_lgkm<0>();
             }
 #pragma unroll
-            for (int r = 0; r < TG_RBW; ++r) pin(xf[cur][r]);
+            for (int r = 0; r < RBW; ++r) pin(xf[cur][r]);
             if constexpr (BKS) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
 #pragma unroll
                 for (int f = 0; f < TG_FBW; ++f)
 #pragma unroll
-                    for (int r = 0; r < TG_RBW; ++r)
+                    for (int r = 0; r < RBW; ++r)
                         acc[f][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(BKS ? wf1[cur][q][f] : wf4[cur][f][q], xf[cur][r][q],
                                                                          acc[f][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);       // keep the software pipeline as written (reads one group ahead)
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
                     for (int g = 0; g < 4; ++g)
                         colv[f][g] = *reinterpret_cast<const float4 *>(cp + n0 + (wf * TG_FBW + f) * 32 + 8 * g + 4 * ke);
             }
-            float r1[TG_RBW];
-            unsigned gm[TG_RBW];
+            float r1[RBW];
+            unsigned gm[RBW];
 #pragma unroll
-            for (int r = 0; r < TG_RBW; ++r) {
-                const long rowc = min(m0 + (wr * TG_RBW + r) * 32 + ie, a.M - 1);
+            for (int r = 0; r < RBW; ++r) {
+                const long rowc = min(m0 + (wr * RBW + r) * 32 + ie, a.M - 1);
                 r1[r] = 0.f;
                 gm[r] = 0u;
                 if constexpr (R1) r1[r] = a.r1_row[rowc * a.r1_stride];
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
             }
             // Pass 2: arithmetic + 16-byte stores
 #pragma unroll
-            for (int r = 0; r < TG_RBW; ++r) {
-                const long row = m0 + (wr * TG_RBW + r) * 32 + ie;
+            for (int r = 0; r < RBW; ++r) {
+                const long row = m0 + (wr * RBW + r) * 32 + ie;
                 if (row < a.M) {
 #pragma unroll
                     for (int f = 0; f < TG_FBW; ++f) {
@@ -276,13 +279,17 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
     }
 }
 
-constexpr int TG_VARIANTS = 4;
+constexpr int TG_VARIANTS = 8;                       // epilogue form (4) x tile height (2)
 static const void *tgemm_variant(int v) {
     switch (v) {
-        case 0: return reinterpret_cast<const void *>(k_tgemm<false, true, false, false>);
-        case 1: return reinterpret_cast<const void *>(k_tgemm<true, false, false, false>);
-        case 2: return reinterpret_cast<const void *>(k_tgemm<true, false, true, false>);
-        default: return reinterpret_cast<const void *>(k_tgemm<true, false, true, true>);
+        case 0: return reinterpret_cast<const void *>(k_tgemm<false, true, false, false, 4>);
+        case 1: return reinterpret_cast<const void *>(k_tgemm<true, false, false, false, 4>);
+        case 2: return reinterpret_cast<const void *>(k_tgemm<true, false, true, false, 4>);
+        case 3: return reinterpret_cast<const void *>(k_tgemm<true, false, true, true, 4>);
+        case 4: return reinterpret_cast<const void *>(k_tgemm<false, true, false, false, 2>);
+        case 5: return reinterpret_cast<const void *>(k_tgemm<true, false, false, false, 2>);
+        case 6: return reinterpret_cast<const void *>(k_tgemm<true, false, true, false, 2>);
+        default: return reinterpret_cast<const void *>(k_tgemm<true, false, true, true, 2>);
     }
 }
 
@@ -309,9 +316,6 @@ extern "C" int mnr_tgemm_run(const mnr_tgemm *g, void *stream) {
     if (g->m <= 0) return MNR_OK;
     a.c = g->c; a.ldc = g->ldc; a.M = g->m;
     a.n_tiles = g->n / TG_BN;
-    const long total = (g->m + TG_BM - 1) / TG_BM * (long)a.n_tiles;
-    MNR_REQUIRE(total < (1l << 30), "mnr_tgemm_run: too many output tiles");
-    a.total_tiles = (int)total;
     a.bias = g->bias; a.relu = g->relu; a.gate = g->gate; a.ldgate = g->ldgate;
     a.r1_row = g->r1_row; a.r1_stride = g->r1_stride; a.r1_col = g->r1_col;
     static int n_cu = 0;
@@ -328,7 +332,17 @@ extern "C" int mnr_tgemm_run(const mnr_tgemm *g, void *stream) {
         lds_enabled = true;
     }
     const char *ev = getenv("MNR_TGEMM_WGS");
-    long grid = ev ? atol(ev) : n_cu;
+    const long wgs = ev ? atol(ev) : n_cu;
+    // Tile height: 256 rows unless that tiling leaves the last round of workgroups poorly filled and 128-row tiles (same
+    // kernel, half the accumulators, ~10 % less efficient per tile: twice the weight-tile traffic per FLOP) fill it better.
+    auto fill = [&](long tiles) { const double r = (double)tiles / (double)wgs; return r / (double)((tiles + wgs - 1) / wgs); };
+    const long tiles256 = (g->m + 255) / 256 * (long)a.n_tiles, tiles128 = (g->m + 127) / 128 * (long)a.n_tiles;
+    const char *eh = getenv("MNR_TGEMM_TILE_ROWS");
+    const bool half = eh ? atoi(eh) == 128 : 0.9 * fill(tiles128) > fill(tiles256);
+    const long total = half ? tiles128 : tiles256;
+    MNR_REQUIRE(total < (1l << 30), "mnr_tgemm_run: too many output tiles");
+    a.total_tiles = (int)total;
+    long grid = wgs;
     if (grid > a.total_tiles) grid = a.total_tiles;
     if (grid < 1) grid = 1;
     hipStream_t s = as_stream(stream);
@@ -341,6 +355,7 @@ extern "C" int mnr_tgemm_run(const mnr_tgemm *g, void *stream) {
         MNR_REQUIRE(!g->bias && !g->relu && (g->gate || !g->r1_row), "mnr_tgemm_run: the k-slow form takes no bias / ReLU; a rank-1 addend needs a gate");
         variant = g->gate ? (g->r1_row ? 3 : 2) : 1;
     }
+    if (half) variant += 4;
     void *params[] = {&a};
     if (hipLaunchKernel(tgemm_variant(variant), dim3((unsigned)grid), dim3(TG_THREADS), params, 2 * TG_STAGE_BYTES, s) != hipSuccess)
         return set_err(MNR_E_LAUNCH, "hipLaunchKernel(k_tgemm)");

@@ -21,9 +21,11 @@ def close(got, ref, rel):
     assert err <= rel * max(float(np.abs(ref).max()), 1e-20), (err, float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize('tile_rows', ['256', '128'])
 @pytest.mark.parametrize('M', [700, 256, 1])
-def test_forward_two_phases_bias_relu(M):
+def test_forward_two_phases_bias_relu(M, tile_rows, monkeypatch):
     from mega_nerf import _native as N
+    monkeypatch.setenv('MNR_TGEMM_TILE_ROWS', tile_rows)          # both tile heights (the library picks by row count otherwise)
     rng = np.random.default_rng(3)
     K1, K2, Nn = 64, 256, 512
     x1 = rng.standard_normal((M, K1)).astype(np.float32)
@@ -48,9 +50,11 @@ def test_forward_two_phases_bias_relu(M):
         assert float(y[:, Nn:].min()) == 7.0                              # columns past n untouched
 
 
+@pytest.mark.parametrize('tile_rows', ['256', '128'])
 @pytest.mark.parametrize('mode', ['plain', 'gate', 'gate_r1'])
-def test_data_gradient_forms(mode):
+def test_data_gradient_forms(mode, tile_rows, monkeypatch):
     from mega_nerf import _native as N
+    monkeypatch.setenv('MNR_TGEMM_TILE_ROWS', tile_rows)
     rng = np.random.default_rng(4)
     M, n_out, k_in, col0 = 900, 512, 512, 64
     gz = rng.standard_normal((M, n_out)).astype(np.float32)
