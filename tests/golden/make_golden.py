@@ -50,12 +50,20 @@ class Recorder:
     """Records torch.rand / rand_like / searchsorted results in reference call order, tagged by
     which part of render_rays drew them."""
 
-    def __init__(self, Nc):
+    def __init__(self, Nc, replay=None):
         self.Nc = Nc
         self.ctx = ['fg', 'coarse']
         self.rnd = {}
         self.inds = {}
         self._orig = {}
+        # replay: {key: [draws in call order]} from an earlier recording -- the draws are handed back (in the current default
+        # dtype) instead of fresh ones, so a second run of the reference (fp64) sees the same random numbers as the first
+        self.replay = {k: list(v) for k, v in replay.items()} if replay is not None else None
+
+    def _draw(self, key, fresh):
+        if self.replay is None:
+            return fresh
+        return torch.from_numpy(self.replay[key].pop(0)).to(fresh.dtype).reshape(fresh.shape)
 
     def _add(self, key, val):
         self.rnd.setdefault(key, []).append(val.detach().numpy().copy())
@@ -67,13 +75,15 @@ class Recorder:
         rec = self
 
         def rand(*a, **k):
-            v = o['rand'](*a, **k)
-            rec._add('%s_%s' % (rec.ctx[0], rec.ctx[2] if len(rec.ctx) > 2 else 'noise_' + rec.ctx[1]), v)
+            key = '%s_%s' % (rec.ctx[0], rec.ctx[2] if len(rec.ctx) > 2 else 'noise_' + rec.ctx[1])
+            v = rec._draw(key, o['rand'](*a, **k))
+            rec._add(key, v)
             return v
 
         def rand_like(x, **k):
-            v = o['rand_like'](x, **k)
-            rec._add('bg_perturb' if x.shape[1] == rec.Nc // 2 else 'fg_perturb', v)
+            key = 'bg_perturb' if x.shape[1] == rec.Nc // 2 else 'fg_perturb'
+            v = rec._draw(key, o['rand_like'](x, **k))
+            rec._add(key, v)
             return v
 
         def ss(cdf, u, right=False):
@@ -248,30 +258,36 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
     bcfg = common.model_cfg(hp, 4, hp.bg_layer_dim)
     A = s['appearance_count']
     extra = {}
-    if container is not None:
-        n_sub = container
-        g = int(np.sqrt(n_sub))
-        g2 = n_sub // g                                   # 4 -> 2 x 2, 8 -> 2 x 4 (Rubble's 8-cell grid)
-        assert g * g2 == n_sub
-        ys, zs = np.meshgrid(np.linspace(-.5, .5, g), np.linspace(-.5, .5, g2), indexing='ij')
-        cent = np.stack([np.zeros(n_sub), ys.ravel(), zs.ravel()], -1).astype(f32)
-        extra['centroids'] = cent
-        subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
-        bsubs = [ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500 + i), A) for i in range(n_sub)]
-        if joint:        # --train_mega_nerf: model_utils.py:37-42 (hard routing, joint_training flag)
-            nerf = MegaNeRF(subs, T(cent), 1, False, False, True)
-            bg_nerf = MegaNeRF(bsubs, T(cent), 1, True, False, True)
+
+    def make_models():
+        if container is not None:
+            n_sub = container
+            g = int(np.sqrt(n_sub))
+            g2 = n_sub // g                                   # 4 -> 2 x 2, 8 -> 2 x 4 (Rubble's 8-cell grid)
+            assert g * g2 == n_sub
+            ys, zs = np.meshgrid(np.linspace(-.5, .5, g), np.linspace(-.5, .5, g2), indexing='ij')
+            cent = np.stack([np.zeros(n_sub), ys.ravel(), zs.ravel()], -1).astype(f32)
+            extra['centroids'] = cent
+            cent_t = T(cent).to(torch.get_default_dtype())
+            subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
+            bsubs = [ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500 + i), A) for i in range(n_sub)]
+            if joint:        # --train_mega_nerf: model_utils.py:37-42 (hard routing, joint_training flag)
+                nerf = MegaNeRF(subs, cent_t, 1, False, False, True)
+                bg_nerf = MegaNeRF(bsubs, cent_t, 1, True, False, True)
+            else:
+                nerf = MegaNeRF(subs, cent_t, hp.boundary_margin, False, False)
+                bg_nerf = MegaNeRF(bsubs, cent_t, hp.boundary_margin, True, False)
+        elif cascade:
+            nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
+                           ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
+            bg_nerf = Cascade(ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A),
+                              ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 501), A)) if bg else None
         else:
-            nerf = MegaNeRF(subs, T(cent), hp.boundary_margin, False, False)
-            bg_nerf = MegaNeRF(bsubs, T(cent), hp.boundary_margin, True, False)
-    elif cascade:
-        nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
-                       ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
-        bg_nerf = Cascade(ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A),
-                          ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 501), A)) if bg else None
-    else:
-        nerf = ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A)
-        bg_nerf = ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A) if bg else None
+            nerf = ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A)
+            bg_nerf = ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500), A) if bg else None
+        return nerf, bg_nerf
+
+    nerf, bg_nerf = make_models()
     nerf.train(fg_train)
     if bg_nerf is not None:
         bg_nerf.train(bg_train)
@@ -313,6 +329,34 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
                     out['grad_%s_%s' % (tag, pn)] = g.numpy()
                 else:   # big matrices: keep a strided sample (every 37th element of the flat grad)
                     out['gsub_%s_%s' % (tag, pn)] = g.reshape(-1)[::37].numpy().copy()
+        # The same render + loss + backward by the reference in DOUBLE precision on the replayed random numbers: the
+        # reference's fp32 gradients carry their own rounding noise (ReLU units whose pre-activation sits within an ulp of 0
+        # switch side between implementations; trunk gradients of a sharpened field are sums of a few dominant rows), so
+        # tests measure both the fp32 reference and the implementation under test against this.
+        torch.set_default_dtype(torch.float64)
+        try:
+            n64, b64 = make_models()
+            n64.train(fg_train)
+            if b64 is not None:
+                b64.train(bg_train)
+            with Recorder(hp.coarse_samples, replay=rec.rnd):
+                res64, _ = R.render_rays(n64, b64, T(rays).double(), idx_t, hp, sc.double() if sc is not None else None,
+                                         sr.double() if sr is not None else None, *flags)
+            t64 = T(target).double()
+            loss64 = torch.nn.functional.mse_loss(res64['rgb_' + typ], t64)
+            if cascade and typ == 'fine':
+                loss64 = (loss64 + torch.nn.functional.mse_loss(res64['rgb_coarse'], t64)) / 2
+            loss64.backward()
+            out['loss64'] = loss64.detach().numpy()
+            for tag, m in (('fg', n64), ('bg', b64)):
+                if m is None:
+                    continue
+                for pn, p in m.named_parameters():
+                    g = p.grad if p.grad is not None else torch.zeros_like(p)
+                    full = g.numel() <= 2048 or pn.startswith('sigma') or pn.startswith('rgb')
+                    out['g64_%s_%s' % (tag, pn)] = (g if full else g.reshape(-1)[::37]).numpy().copy()
+        finally:
+            torch.set_default_dtype(torch.float32)
     save(name, **out)
 
 
@@ -359,6 +403,10 @@ def main(only=None):
     case('render_sh3_eval', dict(base, sh_deg=3, pos_dir_dim=0), 32, 21, E)
     case('render_container8_eval', dict(base, container_path='dummy'), 48, 22, E, container=8)
     case('render_container_w512_eval', dict(base, container_path='dummy'), 24, 23, E, container=4, layer_dim=512, bg_layer_dim=512)
+    # round 3: the Building-shaped configuration (README "Larger models": 25 submodules with 512 channels each) -- training
+    # gradients at layer_dim 512 and a 5 x 5 container routed with the evaluation margin 1.15
+    case('render_w512_train', base, 32, 24, TR, fg_train=True, bg_train=True, with_grad=True, layer_dim=512, bg_layer_dim=256)
+    case('render_container25_eval', dict(base, container_path='dummy'), 24, 25, E, container=25, layer_dim=512, bg_layer_dim=512)
     case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
          bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
 

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import common
+import fp64_ref
 from oracle import nerf_oracle as O
 from test_oracle_golden import build_case, load, mlp_variant
 from test_gpu_parity import DEV, T, close, native_models, native_nerf
@@ -60,7 +61,7 @@ def test_remaining_mlp_variants(name):
         close(m(x[:, :cfg.xyz_dim].contiguous(), sigma_only=True), g[name + '_sigma_only'], 1e-4, 2e-6)
 
 
-@pytest.mark.parametrize('name', ['render_sh3_eval', 'render_container8_eval', 'render_container_w512_eval'])
+@pytest.mark.parametrize('name', ['render_sh3_eval', 'render_container8_eval', 'render_container_w512_eval', 'render_container25_eval'])
 def test_new_render_goldens(name):
     from mega_nerf.rendering import render_rays
     g = load(name)
@@ -78,11 +79,37 @@ def test_new_render_goldens(name):
         np.testing.assert_allclose(a, b, err_msg=k, **tol)
 
 
+def all_ray_violations(res, ores, rnd, dbg, keys, rtol=1e-4, atol=2e-5):
+    """Rays of a render that miss ``|a - b| <= atol + rtol |b|`` (the north-star 1e-4 relative bound) in any of ``keys``, with
+    what is needed to explain them: the largest relative move of one of the ray's fine samples against the oracle's."""
+    n = next(iter(ores.values())).shape[0]
+    bad = np.zeros(n, bool)
+    worst = {}
+    for k in keys:
+        a, b = res[k].cpu().numpy().astype(np.float64), ores[k].astype(np.float64)
+        excess = (np.abs(a - b) - (atol + rtol * np.abs(b))).reshape(n, -1).max(1)
+        bad |= excess > 0
+        worst[k] = float((np.abs(a - b) / (atol / rtol + np.abs(b))).max())      # in units of rtol-relative error
+    zmove = np.zeros(n)
+    zg, zo = rnd['_fine_z_fg'].cpu().numpy(), dbg['fg']['fine_z']
+    zmove = (np.abs(zg - zo) / np.maximum(np.abs(zo), 1e-9)).max(1)
+    if 'bg' in dbg and 'fine_z' in dbg['bg']:
+        ids = np.asarray(dbg['rays_with_bg'])
+        zb, zbo = rnd['_fine_z_bg'].cpu().numpy()[:len(ids)], dbg['bg']['fine_z']
+        zmove[ids] = np.maximum(zmove[ids], (np.abs(zb - zbo) / np.maximum(np.abs(zbo), 1e-9)).max(1))
+    return np.flatnonzero(bad), worst, zmove
+
+
 def test_benchmark_shape_render_against_oracle():
     """The bench.py shape -- 1024 rays x (64 + 128) samples, fg + bg, eval flags -- against the numpy oracle on the same
     rays / weights: every workgroup, compaction and tile boundary of the stage kernels at the size that is benchmarked.
-    Rays whose fine-sample indices all agree with the oracle must meet the north-star tolerance (1e-4 relative on rgb / depth);
-    the few rays where a u value straddles a cdf entry (GEMM rounding ~1e-6) may differ more, and must be few."""
+    ALL 1024 rays must meet the north-star tolerance (1e-4 relative on rgb / depth) in every output.  A fine-sample index
+    may differ from the oracle's where a u value sits within GEMM rounding (~1e-6) of a cdf entry -- the last u = 1.0 against
+    cdf[-1] = 1 -+ ulp does so on ~20 % of the rays -- but _sample_cdf is continuous across an entry (rendering.py:524-535:
+    t -> 1 in bin k meets t -> 0 in bin k + 1), so a moved index does not move the sample.  The one genuine discontinuity is
+    a run of cdf entries that are EQUAL in fp32 (zero-probability bins: searchsorted(right=True) jumps across the whole run):
+    a ray may miss the bound only if one of its fine samples really sits elsewhere (relative z move > 1e-5), and there may be
+    at most 9 such rays."""
     from mega_nerf import ray_utils
     from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
     from mega_nerf.rendering import render_rays
@@ -108,23 +135,18 @@ def test_benchmark_shape_render_against_oracle():
     dbg = {}
     ores, opresent = O.render_rays(O.Model(fcfg, fw), O.Model(bcfg, bw), rays, idx.astype(f32), hp, s['sphere_center'],
                                    s['sphere_radius'], True, False, True, debug=dbg)
-    assert present == opresent
-    same = (rnd['_inds_fg'].cpu().numpy() == dbg['fg']['inds']).all(axis=1)                 # rays with identical fg sample indices
-    n_bg = dbg['bg']['inds'].shape[0]
-    bg_same = (rnd['_inds_bg'].cpu().numpy()[:n_bg] == dbg['bg']['inds']).all(axis=1)
-    bg_rays = np.flatnonzero(np.asarray(dbg.get('bg_ray_ids', np.zeros(0, np.int64)))) if 'bg_ray_ids' in dbg else None
-    if bg_rays is not None and len(dbg['bg_ray_ids']) == n_bg:
-        same[np.asarray(dbg['bg_ray_ids'])[~bg_same]] = False
-    # ~0.2 % of the 131 072 fine indices move (GEMM rounding ~1e-6 across a cdf entry); a ray counts as "same" only if all 128 agree
-    assert (rnd['_inds_fg'].cpu().numpy() != dbg['fg']['inds']).mean() < 5e-3
-    assert same.mean() > 0.6, same.mean()
-    for k in ('rgb_fine', 'fg_rgb_fine', 'depth_fine', 'bg_lambda_fine', 'fg_depth_fine'):
-        a, b = res[k].cpu().numpy(), ores[k]
-        if bg_rays is None and k in ('rgb_fine', 'depth_fine'):
-            continue                                        # blended outputs also depend on the bg indices: covered via bg_same below
-        np.testing.assert_allclose(a[same], b[same], rtol=1e-4, atol=2e-5, err_msg=k)
-        np.testing.assert_allclose(a, b, rtol=5e-2, atol=5e-3, err_msg=k + ' (all rays)')
+    assert present == opresent and sorted(res.keys()) == sorted(ores.keys())
     assert np.isfinite(res['rgb_fine'].cpu().numpy()).all()
+    moved = rnd['_inds_fg'].cpu().numpy() != dbg['fg']['inds']
+    keys = ('rgb_fine', 'fg_rgb_fine', 'bg_rgb_fine', 'depth_fine', 'fg_depth_fine', 'bg_depth_fine', 'bg_lambda_fine')
+    offenders, worst, zmove = all_ray_violations(res, ores, rnd, dbg, keys)
+    print('moved fine indices: %d of %d (%d at the last u), rays with a moved index: %d; worst error per output in units of the '
+          'bound: %s; rays missing the bound: %s' % (moved.sum(), moved.size, moved[:, -1].sum(), moved.any(1).sum(),
+                                                     {k: '%.3f' % v for k, v in worst.items()}, offenders.tolist()))
+    assert moved.mean() < 5e-3
+    unexplained = [int(r) for r in offenders if not zmove[r] > 1e-5]
+    assert not unexplained, ('rays miss 1e-4 without a moved sample', unexplained, worst)
+    assert len(offenders) <= 9, (offenders.tolist(), zmove[offenders].tolist())
 
 
 def test_training_render_deviates_only_where_sample_indices_moved():
@@ -205,39 +227,94 @@ def test_batched_weight_gradients(mode, monkeypatch):
             rg.n_ranges, rg.row0[0], rg.n_rows[0] = 1, 0, cap
         regions.append(rg)
         keep.append((m, desc, packed, pb, tape, gtape, dheads, out, xyz_t, dirs_t, idx_t, dout_t, nun, counter, gios, grads))
-        # reference gradients (fp64 autograd over the rows that count)
+        # reference gradients: fp64 autograd over the rows that count, with the ReLU masks the kernels actually used (read back
+        # from the tape: tests/fp64_ref.py explains why)
+        torch.cuda.synchronize()
         rows = np.concatenate([np.arange(p * B, p * B + n_used * S) for p in range(2)])
-        wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+        mk = fp64_ref.tape_masks(lib, m, desc, tape, cap, 0, cap)
+        mk = dict(act=[a[rows] for a in mk['act']], dact=mk['dact'][rows])
         ray = (rows % B) // S
         x_full = np.concatenate([xyz[rows], dirs[ray], idx[ray][:, None]], 1)
-        ref = _torch_nerf_forward(wt, cfg, torch.tensor(x_full, dtype=torch.float64), torch.zeros(len(rows), dtype=torch.float64))
-        (ref * torch.tensor(d_out[rows], dtype=torch.float64)).sum().backward()
-        refs.append(wt)
+        refs.append(fp64_ref.autograd_grads64(w, cfg, x_full, None, d_out[rows], mk))
     ws = torch.empty(lib.mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
     arr = (N.WgradRegion * 2)(*regions)
     N.check(lib.mnr_mlp_backward_weights_multi(arr, 2, ws.data_ptr(), ws.numel(), None))
     torch.cuda.synchronize()
-    # the checker is the round-1 weight-gradient kernel (pinned against fp64 autograd by
-    # test_gpu_parity.py::test_mlp_backward_against_fp64_autograd) run over the SAME tapes: a comparison with autograd at
-    # this row count would mostly measure ReLU-mask flips of pre-activations within 1e-7 of zero, not the kernel under test
     bad = {}
-    for name, k_, wt in zip(('fg', 'bg'), keep, refs):
-        m, gios = k_[0], k_[-2]
-        g2 = {k: torch.zeros_like(p) for k, p in m.named_parameters()}
-        gs2 = m.grad_struct(g2)
-        for g in gios:
-            g.grad = gs2
-            N.check(lib.mnr_mlp_backward_weights(C.byref(k_[1]), C.byref(g), None))
-        torch.cuda.synchronize()
-        for k, old in g2.items():
+    for name, k_, ref in zip(('fg', 'bg'), keep, refs):
+        for k, got in k_[-1].items():
             if k.split('.')[0] in ('embedding_a', 'sigma', 'rgb'):
                 continue                                              # head / embedding gradients come from backward_data
-            r, got, f = old.cpu().numpy(), k_[-1][k].cpu().numpy(), wt[k].grad.numpy()
-            sc = max(float(np.abs(r).max()), 1e-20)
-            e = float(np.abs(got - r).max()) / sc
-            loose = float(np.abs(got - f).max()) / max(float(np.abs(f).max()), 1e-20)
-            if not (e < 5e-6 and loose < 0.2 and np.abs(r).max() > 0):
-                bad[name + '.' + k] = (e, loose)
+            e = fp64_ref.rel_to_scale(got.cpu().numpy(), ref[k])
+            if not (e < 2e-4 and np.abs(ref[k]).max() > 0):
+                bad[name + '.' + k] = e
+    assert not bad, bad
+
+
+def _flat_backward(name, S, n_ray, row0, pad, seed):
+    """One training-mode launch of model ``name`` over n_ray x S rows written at tape row ``row0`` + its data-gradient chain /
+    head gradients; returns everything the weight-gradient launch and the fp64 checker need."""
+    from mega_nerf import _native as N
+    lib = N.lib()
+    hp, cfg, w = mlp_variant(name)
+    m = native_nerf(cfg, w)
+    rng = np.random.default_rng(seed)
+    B = S * n_ray
+    xyz = rng.uniform(-1, 1, (B, cfg.xyz_dim)).astype(f32)
+    dirs = rng.standard_normal((n_ray, 3)).astype(f32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    idx = rng.integers(0, 100, n_ray).astype(f32)
+    noise = rng.uniform(0, 1, B).astype(f32)
+    d_out = rng.standard_normal((B, 4)).astype(f32)
+    cap = row0 + B + pad
+    fpr = m.tape_floats_per_row()
+    tape, gtape = torch.zeros(cap * fpr, device=DEV), torch.zeros(cap * fpr, device=DEV)
+    dheads, out = torch.zeros(cap, 4, device=DEV), torch.empty(B, 4, device=DEV)
+    t = [T(a) for a in (xyz, dirs, idx, noise, d_out)]
+    io = m.mlp_io(t[0], cfg.xyz_dim, t[1], 3, t[2], 1, S, B, out, t[3])
+    m.evaluate_train(io, tape, cap, row0)
+    grads = {k: torch.zeros_like(p) for k, p in m.named_parameters()}
+    desc, packed = m.packed()
+    pb = m.packed_bwd()
+    counter = torch.zeros(1, device=DEV, dtype=torch.int32)
+    g = N.MlpGradIO()
+    g.tape, g.gtape, g.tape_rows, g.tape_row0 = tape.data_ptr(), gtape.data_ptr(), cap, row0
+    g.d_out, g.d_out_stride, g.out, g.out_stride = t[4].data_ptr(), 4, out.data_ptr(), 4
+    g.dheads, g.idx, g.idx_stride, g.idx_is_float, g.rows_per_ray = dheads.data_ptr(), t[2].data_ptr(), 1, 1, S
+    g.n_rows, g.work_counter, g.grad = B, counter.data_ptr(), m.grad_struct(grads)
+    N.check(lib.mnr_mlp_backward_data(packed.data_ptr(), pb.data_ptr(), C.byref(desc), C.byref(g), None))
+    rg = N.WgradRegion()
+    rg.desc, rg.tape, rg.gtape, rg.tape_rows, rg.grad = C.pointer(desc), tape.data_ptr(), gtape.data_ptr(), cap, g.grad
+    rg.n_ranges, rg.row0[0], rg.n_rows[0] = 1, row0, B
+    x_full = np.concatenate([xyz, np.repeat(dirs, S, 0), np.repeat(idx, S)[:, None]], 1)
+    return dict(m=m, cfg=cfg, w=w, desc=desc, tape=tape, cap=cap, row0=row0, B=B, region=rg, grads=grads, x=x_full, noise=noise,
+                d_out=d_out, out=out, keep=(packed, pb, gtape, dheads, t, counter, g))
+
+
+@pytest.mark.parametrize('size', ['r592', 'benchmark'])
+def test_wgrad2_against_fp64_autograd(size):
+    """k_wgrad2 (mnr_mlp_backward_weights_multi: the weight-gradient launch of a training step) against torch fp64 autograd of
+    the reference's NeRF.forward (nerf.py:115-160): EVERY parameter gradient within 2e-4 of its tensor's scale -- at the 592
+    ragged rows of test_mlp_backward_against_fp64_autograd and at the benchmark's row counts (fg 1024 x 192 = 196 608 rows, bg
+    138 x 96 = 13 248), fg + bg regions in ONE launch.  The fp64 side uses the ReLU masks found on the kernel's own tape, so
+    the comparison measures the kernels, not which way a pre-activation within an ulp of zero was rounded."""
+    from mega_nerf import _native as N
+    lib = N.lib()
+    shapes = dict(r592=(('fg', 16, 37, 24, 40), ('bg', 16, 37, 24, 40)),
+                  benchmark=(('fg', 192, 1024, 0, 0), ('bg', 96, 138, 0, 0)))[size]
+    runs = [_flat_backward(name, S, n_ray, row0, pad, 40 + i) for i, (name, S, n_ray, row0, pad) in enumerate(shapes)]
+    ws = torch.empty(lib.mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    arr = (N.WgradRegion * len(runs))(*[r['region'] for r in runs])
+    N.check(lib.mnr_mlp_backward_weights_multi(arr, len(runs), ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    worst, flips = {}, {}
+    for (name, *_), r in zip(shapes, runs):
+        mk = fp64_ref.tape_masks(lib, r['m'], r['desc'], r['tape'], r['cap'], r['row0'], r['B'])
+        ref = fp64_ref.autograd_grads64(r['w'], r['cfg'], r['x'], r['noise'], r['d_out'], mk)
+        for k, got in r['grads'].items():
+            worst[name + '.' + k] = fp64_ref.rel_to_scale(got.cpu().numpy(), ref[k])
+    print(size, {k: '%.1e' % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < 2e-4}
     assert not bad, bad
 
 

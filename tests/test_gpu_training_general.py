@@ -8,7 +8,7 @@ import torch
 
 import common
 from oracle import nerf_oracle as O
-from test_gpu_parity import DEV, T, close, native_models, native_nerf
+from test_gpu_parity import DEV, T, check_gradients_against_reference, close, native_models, native_nerf
 from test_oracle_golden import load
 
 pytestmark = pytest.mark.gpu
@@ -149,7 +149,7 @@ def test_nerf_forward_autograd_matches_fp64():
             assert err < 3e-4, (width, k, err)
 
 
-TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_sh2_256_train', 'render_noapp_train',
+TRAIN_CASES = ['render_fgbg_train', 'render_w512_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_sh2_256_train', 'render_noapp_train',
                'render_noapp256_train',
                'render_nerf_cfg_train', 'render_joint_train']
 
@@ -157,8 +157,8 @@ TRAIN_CASES = ['render_fgbg_train', 'render_cascade_bg_train', 'render_sh2_train
 @pytest.mark.parametrize('name', TRAIN_CASES)
 def test_general_training_render_and_gradients_match_reference(name):
     """Training-mode render_rays through GeneralRenderFunction with the reference's captured random draws, loss as in
-    runner.py:370-379, backward.  Outputs to 1e-4; gradients relative to each tensor's scale (tolerance as in
-    test_gpu_parity.test_train_render_and_gradients_match_reference: a few importance samples land in a neighbouring bin)."""
+    runner.py:370-379, backward.  Outputs to 1e-4; gradients against the reference's fp32 and fp64 gradients
+    (test_gpu_parity.check_gradients_against_reference)."""
     import mega_nerf.training as TRN
     from mega_nerf.rendering import render_rays
     g = load(name)
@@ -192,23 +192,7 @@ def test_general_training_render_and_gradients_match_reference(name):
         loss = (loss + torch.nn.functional.mse_loss(res['rgb_coarse'], T(g['target']))) / 2
     np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=1e-4)
     loss.backward()
-    errs = {}
-    for tag, m in (('fg', nerf), ('bg', bg_nerf)):
-        if m is None:
-            continue
-        for pn, p in m.named_parameters():
-            got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), f32)
-            gn = float(g['gnorm_%s_%s' % (tag, pn)])
-            nerr = abs(float(np.linalg.norm(got)) - gn) / max(gn, 1e-20)
-            if 'grad_%s_%s' % (tag, pn) in g:
-                ref = g['grad_%s_%s' % (tag, pn)]
-            else:
-                ref, got = g['gsub_%s_%s' % (tag, pn)], got.reshape(-1)[::37]
-            scale = max(float(np.abs(ref).max()), 1e-20)
-            errs['%s.%s' % (tag, pn)] = (float(np.abs(got - ref).max()) / scale if scale > 1e-20 else float(np.abs(got).max()), nerr if gn > 0 else 0.0)
-    print({k: ('%.1e' % v[0], '%.1e' % v[1]) for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not (v[0] < 3e-2 and v[1] < 2e-2)}
-    assert not bad, bad
+    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)))
 
 
 def test_general_path_agrees_with_tuned_path():

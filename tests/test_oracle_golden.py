@@ -138,6 +138,8 @@ RENDER_CASES = {
     'render_container_w512_eval': dict(hp=dict(container_path='dummy', layer_dim=512, bg_layer_dim=512), seed=23, container=4),
     'render_joint_train': dict(hp=dict(train_mega_nerf='dummy', layer_dim=64, bg_layer_dim=64), seed=17, container=4, joint=True,
                                fg_train=True, bg_train=True),
+    'render_w512_train': dict(hp=dict(layer_dim=512, bg_layer_dim=256), seed=24, fg_train=True, bg_train=True),
+    'render_container25_eval': dict(hp=dict(container_path='dummy', layer_dim=512, bg_layer_dim=512), seed=25, container=25),
     'render_nerf_cfg_train': dict(hp=dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0, layer_dim=160),
                                   seed=15, bg=False, cascade=True, fg_train=True),
 }
