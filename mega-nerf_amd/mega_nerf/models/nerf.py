@@ -189,6 +189,11 @@ class NeRF(nn.Module):
         self._fused_ok = self._fused_train_ok = None
         return super()._apply(fn, *args, **kwargs)
 
+    def weights_changed(self) -> None:
+        """Tell the packed-weight caches that the parameters were updated by something that does not bump their version
+        counters (``torch.optim.Adam(fused=True)`` does not)."""
+        self._packed_key = self._packed_bwd_key = None
+
     def packed(self):
         """(desc, packed device buffer); re-packs when any parameter changed (in-place updates bump ``_version``; storage
         replacement goes through ``_apply`` / ``load_state_dict`` and is caught by the pointer check).  The steady-state

@@ -741,6 +741,13 @@ class TrainStep:
         loss.backward()
         for o in self.opts:          # NB: the reference skips the bg optimiser when no ray had a bg segment
             o.step()                 # (runner.py:269-272); with zero bg rays every bg gradient is exactly 0 here
+        # torch's fused Adam updates the parameters WITHOUT bumping their version counters, which is what NeRF.packed() keys
+        # its packed-weight cache on: without this the next step would run on the previous weights (rounds 1-2 did: the
+        # benchmark's timed region skipped the four re-pack launches, and TrainStep did not learn)
+        for m in (self.nerf, self.bg_nerf):
+            for sub in (m.modules() if m is not None else ()):
+                if hasattr(sub, 'weights_changed'):
+                    sub.weights_changed()
         for s in self.scheds:
             s.step()
         return loss, n_bg, err
