@@ -344,7 +344,22 @@ def main():
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
 
     steppers = []
-    for w in work:
+    fused = None
+    if args.mode == 'train' and not wide:
+        # every cell this rank owns goes through ONE mnr_train_step call per step (csrc/step.hip): 13 launches + a memset for the
+        # whole iteration, the cells' rows side by side in the MLP launches
+        from mega_nerf.training import FusedTrainStep, fused_step_supported
+        for w in work:
+            w['fg'].train(), w['bg'].train()
+        if all(fused_step_supported(w['fg'], w['bg'], hp, args.rays) for w in work):
+            fused = FusedTrainStep([(w['fg'], w['bg']) for w in work], hp, sc, sr, args.rays)
+            batches = [w['batch'] for w in work]
+
+            def fused_step():
+                loss, n_bg, err = fused(batches)
+                return loss[-1], n_bg[-1], err[-1]
+            steppers.append(fused_step)
+    for w in (work if fused is None else []):
         if args.mode == 'train':
             w['fg'].train(), w['bg'].train()
             ts = TrainStep(w['fg'], w['bg'], hp, sc, sr)
@@ -367,6 +382,8 @@ def main():
         step()
     # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed region
     rendering.KERNEL_EVENTS = ev = []
+    if fused is not None:
+        fused.profile(args.steps)                # HIP events on the launch stream around every kernel group of the timed steps
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -383,6 +400,12 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     rendering.KERNEL_EVENTS = None
+    span_ms = {}
+    if fused is not None:
+        for i in range(args.steps):
+            for k, v in fused.kernel_times(i).items():
+                span_ms.setdefault(k, []).append(v)
+        fused.profile(0)
     ms1 = torch.cuda.memory_stats(dev)
     host_diag = {'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
                  'device_mallocs_in_timed_region': int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
@@ -464,8 +487,12 @@ def main():
             """tags: the event tags of every launch of one kernel symbol in a step (``flops`` = mean per launch), so that
             avg_launch_ms is the same population as the kernel's row in a rocprofv3 trace."""
             ms = [a.elapsed_time(b) for t, a, b in ev if t in tags]
+            for t in tags:                         # fused step: spans recorded by mnr_train_step itself (one launch covers all cells;
+                ms += [v / (len(work) if t == 'wgrad' else 1) for v in span_ms.get(t, [])]      # the weight gradients: one per cell)
             if not ms:
                 return None
+            if span_ms and tags[0] != 'wgrad':
+                flops = flops * len(work)
             avg = sum(ms) / len(ms) * 1e-3
             ach = flops / avg / 1e12
             p = pmc.get(pmc_key, {})
@@ -513,8 +540,9 @@ def main():
                                  'k_mlp_bwd_multi'))]
                 cands = [(n_, r_) for n_, r_ in cands if r_ is not None]
                 for n_, r_ in cands:
-                    r_['launches_per_step'] = n_ * len(work)
-                    r_['share_of_step_time'] = round(n_ * len(work) * r_['avg_launch_ms'] / (dt / args.steps * 1e3), 4)
+                    nl_ = n_ * (len(work) if (not span_ms or r_['kernel'].startswith('k_wgrad2')) else 1)
+                    r_['launches_per_step'] = nl_
+                    r_['share_of_step_time'] = round(nl_ * r_['avg_launch_ms'] / (dt / args.steps * 1e3), 4)
                 cands.sort(key=lambda c_: -c_[1]['share_of_step_time'])
                 if cands:
                     roof = cands[0][1]
@@ -562,6 +590,11 @@ def main():
         }
         if extra_roof and any(v is not None for v in extra_roof.values()):
             line['roofline_other_kernels'] = extra_roof
+        if span_ms:
+            line['step_spans_ms'] = {k: round(sum(v) / len(v), 4) for k, v in span_ms.items()}
+            mlp_ms = sum(line['step_spans_ms'][k] for k in ('fwd_c', 'fwd_f', 'bwd', 'wgrad'))
+            line['step_spans_ms']['non_mlp_share_of_step'] = round(1.0 - mlp_ms / (dt / args.steps * 1e3), 4)
+            line['host']['launches_per_step'] = 11 + 2 * len(work)      # memset + 10 kernels + (k_wgrad2 + reduce) per cell
         line.update(extras)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -504,6 +504,93 @@ int mnr_merge_backward(const float *d_merged_dev, const int32_t *order_dev, int 
 int mnr_bg_blend_backward(const float *d_rgb_dev, const float *bg_lambda_dev, const int32_t *bg_slot_dev,
                           const float *bg_rgb_c_dev, int64_t N, float *d_lambda_dev, float *d_bg_rgb_c_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * One whole training step per call -- runner.py:244-277 + rendering.py:15-173
+ *
+ * What the reference's trainer does per iteration (runner.py:347-358 render_rays with the training flags, :370 mse_loss,
+ * :263-277 backward + Adam step on the foreground and the background model), for ONE OR SEVERAL independent submodules
+ * ("cells": parscripts/run_8.txt runs one trainer per cell; a rank that owns several cells steps all of them here), enqueued
+ * on one stream as a fixed sequence of 13 launches + one memset (csrc/step.hip):
+ *     memset (gradients, counters) | k_step_begin (batch copy, _intersect_sphere, background compaction) | k_step_samples
+ *     (coarse samples of both branches, random numbers) | MLP coarse pass, all cells, fg + bg rows | k_step_mid (coarse
+ *     compositing weights -> _sample_pdf -> fine points) | MLP fine pass | k_step_tail (merge, compositing, fg/bg blend, MSE,
+ *     and the adjoints of all of these) | data-gradient chains | head gradients | weight gradients (+ reduction, per cell) |
+ *     Adam | re-pack of every weight image.
+ * Default architectures only (8 x 256 fg / bg models with appearance embedding, no cascade, fine_samples > 0); anything else:
+ * MNR_E_UNSUPPORTED, and the caller sequences the stage entry points above.  All device memory is the caller's: one workspace
+ * (mnr_step_query tells its size and where the gradient area sits inside it), the parameters, Adam moments and packed images.
+ * ---------------------------------------------------------------------------------------------- */
+#define MNR_STEP_MAX_CELLS 16
+
+typedef struct mnr_step_model {
+    mnr_model_desc desc;             /* the nn.Module parameters (updated in place by the optimiser) */
+    mnr_model_grads grad;            /* param.grad: views INTO the workspace's gradient area (zeroed at the start of every step) */
+    mnr_model_grads adam_m, adam_v;  /* torch.optim.Adam's exp_avg / exp_avg_sq, same shapes (caller-owned, zero before step 1) */
+    void *packed_dev;                /* mnr_packed_model_bytes(desc) bytes: re-packed at the end of every step */
+    void *packed_bwd_dev;            /* mnr_packed_bwd_bytes(desc) bytes */
+} mnr_step_model;
+
+typedef struct mnr_step_cfg {
+    int32_t n_cells;                 /* 1 .. MNR_STEP_MAX_CELLS */
+    int32_t n_rays;                  /* rays per cell and step (opts.py:74 batch_size) */
+    int32_t coarse_samples, fine_samples;       /* opts.py:32-35; multiples of 2, (n_rays * samples) % 128 == 0 */
+    float perturb;                   /* opts.py:80: > 0 = stratified jitter + random u (training mode); 0 = deterministic */
+    int32_t sigma_noise;             /* 1: uniform noise on sigma before its activation (rendering.py:294,321, training mode) */
+    float sphere_center[3], sphere_radius[3];   /* runner.py:96-106 */
+    int64_t grad_floats_per_cell;    /* size of one cell's gradient area (fg + bg, the caller's layout), in floats */
+    float adam_beta1, adam_beta2, adam_eps;     /* 0.9, 0.999, 1e-8 = torch defaults (runner.py:169-171) */
+    const float *t_coarse;           /* HOST tables: torch.linspace(0, 1, n) as the CPU kernel computes it (values are data: */
+    const float *t_bg_coarse;        /*   DESIGN.md) for n = coarse_samples, coarse_samples / 2, fine_samples, fine_samples / 2 */
+    const float *t_fine, *t_bg_fine;
+} mnr_step_cfg;
+
+typedef struct mnr_step_layout {
+    size_t workspace_bytes;
+    size_t grad_offset, grad_stride; /* cell c's gradient area: workspace + grad_offset + c * grad_stride */
+    size_t loss_offset;              /* float  [n_cells]          mean squared error of the step */
+    size_t rgb_offset;               /* float  [n_cells][n_rays][3]   rgb_fine */
+    size_t depth_var_offset;         /* float  [n_cells][n_rays]      depth_variance_fine */
+    size_t bg_lambda_offset;         /* float  [n_cells][n_rays]      bg_lambda_fine */
+    size_t n_bg_offset, err_offset;  /* int32  [n_cells]          rays with a background segment / camera-outside-sphere flag */
+} mnr_step_layout;
+int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg_arch, const mnr_model_desc *bg_arch, mnr_step_layout *out);
+
+typedef struct mnr_step_plan mnr_step_plan;
+/* models: [n_cells][2] = fg of cell 0, bg of cell 0, fg of cell 1, ...  Uploads the (step-invariant) device tables into the
+ * workspace and packs every weight image on `stream`.  The plan keeps host copies of everything it was given. */
+int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, const mnr_step_model *models, void *workspace_dev,
+                    size_t workspace_bytes, void *stream);
+void mnr_step_destroy(mnr_step_plan *plan);
+/* re-pack all weight images (after the caller changed parameters behind the plan's back, e.g. loaded a checkpoint) */
+int mnr_step_repack(mnr_step_plan *plan, void *stream);
+
+typedef struct mnr_step_batch {      /* one cell's batch: device pointers, read (copied into the workspace) by the first kernel */
+    const float *rays;               /* [n_rays][8] */
+    const void *idx;                 /* [n_rays] image indices, int32 or float */
+    int32_t idx_is_float;
+    const float *target;             /* [n_rays][3] ground-truth colours */
+} mnr_step_batch;
+typedef struct mnr_step_randoms {    /* optional injected uniforms of one cell (parity tests); NULL members are generated */
+    const float *fg_perturb, *bg_perturb;            /* [n_rays][coarse], [n_bg][coarse / 2] */
+    const float *fg_noise_coarse, *fg_noise_fine;    /* [n_rays * coarse], [n_rays * fine] */
+    const float *bg_noise_coarse, *bg_noise_fine;    /* [n_bg * coarse / 2], [n_bg * fine / 2] (compacted background rays) */
+    const float *fg_u, *bg_u;                        /* [n_rays][fine], [n_bg][fine / 2] */
+} mnr_step_randoms;
+#define MNR_STEP_NO_OPTIMIZER 1      /* flags: stop after the gradients (no Adam, no re-pack) */
+/* batches [n_cells]; randoms NULL or [n_cells]; lr = this step's learning rate (the caller applies ExponentialLR,
+ * runner.py:173-176); adam_step = 1, 2, ... (bias correction); seed + adam_step key the counter-based generator. */
+int mnr_train_step(mnr_step_plan *plan, const mnr_step_batch *batches, const mnr_step_randoms *randoms, float lr, int64_t adam_step,
+                   uint64_t seed, int flags, void *stream);
+
+/* Kernel-level timing without a profiler (bench.py's roofline): after mnr_step_profile(plan, n) every step records HIP events on
+ * its launch stream around its kernels, into slot (step index mod n); mnr_step_kernel_times reads a finished slot (the caller
+ * synchronises first): ms[MNR_STEP_SPANS] = { samples stage (begin + samples), MLP coarse pass, mid stage, MLP fine pass, tail
+ * stage, data-gradient chains, head gradients, weight gradients (all cells, incl. reductions), Adam + re-pack }.  n = 0 stops
+ * recording.  The events are host objects owned by the plan. */
+#define MNR_STEP_SPANS 9
+int mnr_step_profile(mnr_step_plan *plan, int n_slots);
+int mnr_step_kernel_times(mnr_step_plan *plan, int slot, float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 
 #include "mlp_device.h"
+#include "pack_device.h"
+#include "step_internal.h"
 
 namespace mnr {
 
@@ -24,7 +26,7 @@ static ArchDims arch_of(const mnr_model_desc *d) {
                     d->rgb_dim, d->mfma_tile};
 }
 
-static int bwd_layout_from_desc(const mnr_model_desc *d, BwdLayout &b) {
+int bwd_layout_from_desc(const mnr_model_desc *d, BwdLayout &b) {
     ModelLayout m;
     int rc = layout_from_desc(d, m);
     if (rc != MNR_OK) return rc;
@@ -39,30 +41,7 @@ static int bwd_layout_from_desc(const mnr_model_desc *d, BwdLayout &b) {
 }
 
 __global__ void k_pack_bwd(BwdLayout b, float4 *__restrict__ chunks) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)b.total_chunks * CHUNK_F4) return;
-    const int chunk = (int)(tid / CHUNK_F4), within = (int)(tid % CHUNK_F4);
-    const int P = b.parts, tile = b.tile;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int li = -1;
-    for (int i = 0; i < b.n_layers; ++i)
-        if (chunk >= b.layer[i].chunk0 && chunk < b.layer[i].chunk0 + b.layer[i].nchunks) li = i;
-    if (li >= 0) {
-        const BwdLayerLayout &l = b.layer[li];
-        const int lane = within & 63, blk = within >> 6;
-        const int gic = blk / l.nob, ob = blk % l.nob;
-        const int g = (chunk - l.chunk0) * l.gpc + gic;
-        if (gic < l.gpc && g < l.ngroups) {
-            const int row = ob * tile + lane % tile, part = lane / tile;
-            if (row < l.n_rows) {
-                const int in_col = row < l.split ? l.in_off + row : l.in_off2 + (row - l.split);
-                float t[4];
-                for (int c = 0; c < 4; ++c) t[c] = l.w[(long)hid_src(P, 4 * g + c, part) * l.ld + in_col];
-                v = make_float4(t[0], t[1], t[2], t[3]);
-            }
-        }
-    }
-    chunks[tid] = v;
+    pack_bwd_thread(b, chunks, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 struct MlpBwdArgs {
@@ -82,6 +61,9 @@ struct MlpBwdArgs {
     const int32_t *n_units_dev;  int rows_per_unit;
     long tape_row0;                // tape / gradient-tape row of this launch's row 0
     const float *dd_in;            // rgb_dim != 3: dL/d(dir_a output) [n_rows][W/2] supplied by the caller (see mnr_mlp_grad_io)
+    const MlpCellSeg *dcells;      // several cells' rows side by side in one segment (device table; csrc/step.hip), else NULL:
+    long cell_rows;                // cell c owns rows [c * cell_rows, ...) of d_out / out / idx space and tape rows from its tape_row0
+    long aux_byte_off;             // offset of the aux block inside a forward image (dcells)
 };
 
 // ReLU masks: the forward pass left the sign bits of every activation packed per lane (TapeLayout mask planes), so a
@@ -129,7 +111,7 @@ __device__ __forceinline__ void zero_acc(AccT (&acc)[NOB]) {
 }
 
 template <class C>
-__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
+__device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int cidx = 0) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB, H2 = C::H2, W = C::W;
     static_assert(C::HAS_FINAL, "backward kernel covers the dir/appearance architecture");
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
@@ -138,18 +120,35 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     constexpr int GPCD = CHUNK_F4 / (NOBD * 64) < 1 ? 1 : CHUNK_F4 / (NOBD * 64);
     extern __shared__ float4 lds_ring[];
 
-    const long n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
-    if (blk * C::ROWS_PER_WG >= n_rows) return;
+    long n_rows, row_base = 0, tape_row0 = a.tape_row0;
+    const float4 *chunks = a.chunks;
+    const float *aux = a.aux;
+    float *d_emb_a = a.d_emb_a;
+    if (a.dcells) {
+        // training step of several submodules (see mlp_fwd_body): cell = blockIdx.y, `blk` = workgroup index inside the cell
+        const MlpCellSeg cell = a.dcells[cidx];
+        n_rows = cell.n_units ? (long)__builtin_amdgcn_readfirstlane(*cell.n_units) * a.rows_per_unit : a.cell_rows;
+        if (blk * C::ROWS_PER_WG >= n_rows) return;
+        chunks = reinterpret_cast<const float4 *>(cell.packed_bwd);
+        aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(cell.packed) + a.aux_byte_off));
+        d_emb_a = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(cell.d_emb_a))));
+        row_base = (long)cidx * a.cell_rows;
+        tape_row0 = uniform_long(cell.tape_row0);
+    } else {
+        n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
+        if (blk * C::ROWS_PER_WG >= n_rows) return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
-    const long row = (blk * 4 + wave) * TILE + (lane % TILE);
-    const bool valid = row < n_rows;
-    const long rc = valid ? row : n_rows - 1;
+    const long lrow = (blk * 4 + wave) * TILE + (lane % TILE);
+    const bool valid = lrow < n_rows;
+    const long lrc = valid ? lrow : n_rows - 1;
+    const long rc = row_base + lrc;              // row in d_out / out / ray space
     const long cap = a.tape_rows;
-    const long trow = rc + a.tape_row0;          // row in tape space
+    const long trow = lrc + tape_row0;           // row in tape space
 
     WStream st;
-    st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(a.chunks)));      // into SGPRs once: the stream pointer arithmetic stays scalar
+    st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));      // into SGPRs once: the stream pointer arithmetic stays scalar
     st.lds = lds_ring;
     st.cur = 1;
     st.issue();
@@ -170,7 +169,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     float dd[H2];
     {
         if constexpr (C::RGB == 3) {
-            const float *wr = a.aux + a.rgb_off;
+            const float *wr = aux + a.rgb_off;
 #pragma unroll
             for (int q = 0; q < H2 / 4; ++q) {
                 float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -209,7 +208,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
 #pragma unroll
             for (int r = 0; r < RPB; ++r) g[ob * RPB + r] = accd[ob][r];    // dZ of xyz_encoding_final (no activation)
         if constexpr (C::APP > 0) {
-            if (a.d_emb_a) {
+            if (d_emb_a) {
                 constexpr int NAB = cdiv(C::APP, TILE);          // appearance blocks after the W final-feature rows
                 const long ray = rc / a.rows_per_ray;
                 long idx = a.idx_is_float ? (long)reinterpret_cast<const float *>(a.idx)[ray * a.idx_stride]
@@ -226,9 +225,9 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
                         if (uniform) {
 #pragma unroll
                             for (int o = 1; o < TILE; o <<= 1) v += __shfl_xor(v, o);
-                            if ((lane % TILE) == 0 && col < C::APP) atomicAdd(a.d_emb_a + idx * C::APP + col, v);
+                            if ((lane % TILE) == 0 && col < C::APP) atomicAdd(d_emb_a + idx * C::APP + col, v);
                         } else if (valid && col < C::APP) {
-                            atomicAdd(a.d_emb_a + idx * C::APP + col, v);
+                            atomicAdd(d_emb_a + idx * C::APP + col, v);
                         }
                     }
             }
@@ -238,7 +237,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk) {
     // ---- final^T (+ sigma head): dZ of trunk layer L-1 ---------------------------------------------
     AccT acc[NOB];
     {
-        const float *ws = a.aux + a.sigma_off + part * H;
+        const float *ws = aux + a.sigma_off + part * H;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
@@ -286,8 +285,8 @@ template <class CA, class CB>
 __global__ __launch_bounds__(256, 2) void k_mlp_bwd_multi(MlpBwdMulti m) {
     const int blk = blockIdx.x;
     const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
-    if (m.is_b[s]) mlp_bwd_body<CB>(m.seg[s], blk - m.wg0[s]);
-    else mlp_bwd_body<CA>(m.seg[s], blk - m.wg0[s]);
+    if (m.is_b[s]) mlp_bwd_body<CB>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    else mlp_bwd_body<CA>(m.seg[s], blk - m.wg0[s], blockIdx.y);
 }
 
 // =================================================================================================
@@ -500,15 +499,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
 // thread: a broadcast).  Groups are combined in LDS, one set of 644 atomics per block (few, long blocks: round 1
 // launched 1024 small blocks per segment and spent most of its time on those same-address atomics).
 constexpr int HG_GROUPS = 4;
-__global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
-                                                    const float *__restrict__ dact, int W2, long row0, long n_rows,
-                                                    const int32_t *__restrict__ n_units_dev, int rows_per_unit,
-                                                    float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
-                                                    float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb) {
+__device__ __forceinline__ void head_grads_body(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
+                                                const float *__restrict__ dact, int W2, long row0, long n_rows,
+                                                const int32_t *__restrict__ n_units_dev, int rows_per_unit,
+                                                float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
+                                                float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb, int block, int n_blocks) {
     __shared__ float red[HG_GROUPS][256 + 3 * 128 + 8];
     const long n = n_units_dev ? (long)(*n_units_dev) * rows_per_unit : n_rows;
-    const long per = ((n + gridDim.x - 1) / gridDim.x + 7) / 8 * 8;            // whole 8-row chunks per block
-    const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
+    const long per = ((n + n_blocks - 1) / n_blocks + 7) / 8 * 8;            // whole 8-row chunks per block
+    const long rb = (long)block * per, re = min(n, rb + per);
     if (rb >= re) return;
     const long r0 = row0 + rb, r1 = row0 + re;
     const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
@@ -666,6 +665,49 @@ static int fill_bwd_args(MlpBwdArgs &a, const ModelLayout &m, const void *packed
     return MNR_OK;
 }
 
+namespace mnr {
+__global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
+                                                    const float *__restrict__ dact, int W2, long row0, long n_rows,
+                                                    const int32_t *__restrict__ n_units_dev, int rows_per_unit,
+                                                    float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
+                                                    float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb) {
+    head_grads_body(dheads, a_last, W, dact, W2, row0, n_rows, n_units_dev, rows_per_unit, d_sigma_w, d_sigma_b, d_rgb_w, d_rgb_b, with_rgb,
+                    (int)blockIdx.x, (int)gridDim.x);
+}
+
+// several (tape, row range) jobs in one launch: blockIdx.y = job, blocks past the job's own block count exit
+struct HeadJobs { HeadJob job[HEAD_MAX_JOBS]; };
+__global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads_jobs(HeadJobs js, int W) {
+    const HeadJob &j = js.job[blockIdx.y];
+    if ((int)blockIdx.x >= j.n_blocks) return;
+    head_grads_body(j.dheads, j.a_last, W, j.dact, W / 2, j.row0, j.n_rows, j.n_units_dev, j.rows_per_unit, j.d_sigma_w, j.d_sigma_b,
+                    j.d_rgb_w, j.d_rgb_b, 1, (int)blockIdx.x, j.n_blocks);
+}
+
+}  // namespace mnr
+
+int mnr::head_job_of(const mnr_model_desc *d, const mnr_mlp_grad_io *io, HeadJob &job) {
+    const mnr_model_grads &G = io->grad;
+    MNR_REQUIRE(G.sigma_w && G.sigma_b && G.rgb_w && G.rgb_b, "missing head gradient pointers");
+    MNR_REQUIRE(d->layer_dim == 256 && d->rgb_dim == 3, "head-gradient job kernel: layer_dim 256, rgb_dim 3");
+    const TapeLayout tl = tape_layout(arch_of(d));
+    const long cap = io->tape_rows;
+    const long blocks = io->n_units_dev ? 48 : (io->n_rows + 767) / 768;
+    job = HeadJob{io->dheads, io->tape + (long)tl.act_off[d->layers - 1] * cap, io->tape + (long)tl.dact_off * cap, (long)io->tape_row0,
+                  (long)io->n_rows, io->n_units_dev, io->rows_per_unit, (int)(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), G.sigma_w,
+                  G.sigma_b, G.rgb_w, G.rgb_b};
+    return MNR_OK;
+}
+
+int mnr::head_grads_jobs(const HeadJob *jobs, int n_jobs, int W, hipStream_t s) {
+    MNR_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= HEAD_MAX_JOBS && W == 256, "1..%d head-gradient jobs per launch (layer_dim 256)", HEAD_MAX_JOBS);
+    HeadJobs js{};
+    int max_blocks = 1;
+    for (int i = 0; i < n_jobs; ++i) { js.job[i] = jobs[i]; max_blocks = jobs[i].n_blocks > max_blocks ? jobs[i].n_blocks : max_blocks; }
+    hipLaunchKernelGGL(k_head_grads_jobs, dim3((unsigned)max_blocks, (unsigned)n_jobs), dim3(256 * HG_GROUPS), 0, s, js, W);
+    return check_launch("k_head_grads_jobs");
+}
+
 // sigma / rgb head weight gradients of the rows of one segment (dheads was just written by the chain kernel)
 static int launch_head_grads(const mnr_model_desc *d, const mnr_mlp_grad_io *io, hipStream_t s) {
     if (io->n_rows == 0) return MNR_OK;
@@ -718,7 +760,7 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 
 // Data-gradient chains of several segments (coarse + fine rows of the foreground and background models) in ONE launch,
 // then the head gradients of every segment.  Default 8x256 fg / bg architectures only (MNR_E_UNSUPPORTED otherwise).
-extern "C" int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+int mnr::mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
     using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
     using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
     MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
@@ -740,16 +782,32 @@ extern "C" int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int
         if (rc != MNR_OK) return rc;
         rc = fill_bwd_args(mm.seg[i], m, L.packed_fwd_dev, L.packed_bwd_dev, d, L.io);
         if (rc != MNR_OK) return rc;
+        if (cells && cells[i].dcells) {
+            MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % CfgFG::ROWS_PER_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
+                        "segment %d: rows per cell must be a multiple of %d", i, CfgFG::ROWS_PER_WG);
+            mm.seg[i].dcells = cells[i].dcells;
+            mm.seg[i].cell_rows = cells[i].cell_rows;
+            mm.seg[i].aux_byte_off = (long)m.total_chunks * CHUNK_BYTES;
+        }
         mm.is_b[i] = d->xyz_dim == 4 ? 1 : 0;
         mm.wg0[i] = (int32_t)wg;
+        if (cells) {                       // grid = (workgroups per cell, cells)
+            MNR_REQUIRE(cells[i].dcells && L.io->n_rows / cells[i].cell_rows == segs[0].io->n_rows / cells[0].cell_rows,
+                        "multi-cell launch: every segment needs a cell table over the same number of cells");
+            wg += cells[i].cell_rows / CfgFG::ROWS_PER_WG;
+        } else
         wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one launch");
     }
     for (int i = n_segs; i <= MLP_BWD_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     if (wg == 0) return MNR_OK;
-    hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL((k_mlp_bwd_multi<CfgFG, CfgBG>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    const unsigned ny = cells ? (unsigned)(segs[0].io->n_rows / cells[0].cell_rows) : 1u;
+    hipLaunchKernelGGL((k_mlp_bwd_multi<CfgFG, CfgBG>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
     return check_launch("k_mlp_bwd_multi");
+}
+
+extern "C" int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {
+    return mlp_backward_chain_multi_impl(segs, n_segs, nullptr, as_stream(stream));
 }
 
 extern "C" int mnr_mlp_head_grads_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {

@@ -39,6 +39,18 @@ struct MlpCfg {
 
 
 
+// One cell's share of a multi-cell segment (training step of several submodules in one launch, csrc/step.hip): the rows of
+// cell c occupy [c * cell_rows, (c + 1) * cell_rows) of the segment's input / output arrays (same architecture, private
+// weights); everything here is uniform per workgroup.  Device table, one entry per cell.
+struct MlpCellSeg {
+    const void *packed;        // forward weight image of the cell's model (mnr_pack_model)
+    const void *packed_bwd;    // transposed image (mnr_pack_model_bwd; data-gradient chain only)
+    const float *emb_a;        // its appearance table
+    float *d_emb_a;            // ... and that table's gradient (data-gradient chain only)
+    long tape_row0;            // tape row of the cell's first row of this pass
+    const int32_t *n_units;    // device-side unit count of the cell (compacted background rays) or NULL
+};
+
 // ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
 // `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at
 // (wave-uniform LDS base) + lane*16 -- the packed image is lane-linear, so no staging registers and no
@@ -53,6 +65,11 @@ __device__ __forceinline__ const char *uniform_ptr(const char *p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ long uniform_long(long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long)(((unsigned long long)hi << 32) | lo);
 }
 
 struct WStream {

@@ -21,6 +21,8 @@ struct MlpFwdArgs {
     const mnr_mlp_cell *cells;   // batched routed evaluation: per-cell weights / row lists / outputs (device array), else NULL
     int n_cells;
     long aux_byte_off;           // offset of the aux block inside a packed image (same for all cells of one architecture)
+    const MlpCellSeg *dcells;    // several cells' rows side by side in one segment (device table), else NULL
+    long cell_rows;              // ... rows per cell (capacity; a multiple of the rows per workgroup)
     float *tape;              // training only: activation tape (TapeLayout planes), else NULL
     long tape_rows;           // row capacity of every tape plane
     long tape_row0;           // tape row of this launch's row 0
@@ -87,7 +89,7 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
 }
 
 template <class C, bool TRAIN>
-__device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
+__device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int cidx = 0) {
     constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
     extern __shared__ float4 lds_ring[];
@@ -97,7 +99,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     const float *aux = a.aux, *emb_a = a.emb_a;
     const int32_t *row_index = io.row_index;
     float *outp = io.out;
-    long n_rows;
+    long n_rows, row_base = 0, tape_row0 = a.tape_row0;
     if (a.cells) {
         // One launch for all cells of a routed evaluation: workgroups are laid out cell after cell, ceil(count_c / rows
         // per workgroup) each; everything below is uniform per workgroup, so the per-cell pointers stay in SGPRs.
@@ -115,6 +117,18 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
         emb_a = cell.embedding_a;
         row_index = cell.row_index;
         outp = cell.out;
+    } else if (a.dcells) {
+        // Training step of several submodules: cell c = blockIdx.y owns rows [c * cell_rows, (c + 1) * cell_rows) of the
+        // segment's arrays; `blk` is the workgroup index inside the cell, `row_base` the cell's offset into the shared arrays.
+        // (cidx = blockIdx.y: no division; the table entry comes through vector loads -> everything is moved to SGPRs at once)
+        const MlpCellSeg cell = a.dcells[cidx];
+        n_rows = cell.n_units ? (long)__builtin_amdgcn_readfirstlane(*cell.n_units) * io.rows_per_unit : a.cell_rows;
+        if (blk * C::ROWS_PER_WG >= n_rows) return;
+        chunks = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(cell.packed)));
+        aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(chunks) + a.aux_byte_off);
+        emb_a = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(cell.emb_a)));
+        row_base = (long)cidx * a.cell_rows;
+        tape_row0 = uniform_long(cell.tape_row0);
     } else {
         n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
         if (blk * C::ROWS_PER_WG >= n_rows) return;             // uniform per workgroup
@@ -130,11 +144,12 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk) {
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
-    const long row = (blk * 4 + wave) * TILE + (lane % TILE);
-    const bool valid = row < n_rows;
+    const long lrow = (blk * 4 + wave) * TILE + (lane % TILE);          // row inside the segment (inside the cell: dcells)
+    const bool valid = lrow < n_rows;
+    const long row = row_base + lrow;
     // first tape row of this wave (training; uniform -> SGPR; tapes hold < 2^32 rows)
-    const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * 4 + wave) * TILE + a.tape_row0));
-    const long rc = valid ? row : n_rows - 1;
+    const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * 4 + wave) * TILE + tape_row0));
+    const long rc = row_base + (valid ? lrow : n_rows - 1);
     const long src = row_index ? (long)row_index[rc] : rc;           // gathered evaluation (MegaNeRF router)
     const long ray = src / io.rows_per_ray;
 
@@ -326,8 +341,8 @@ template <class CA, class CB, bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_mlp_fwd_multi(MlpFwdMulti m) {
     const int blk = blockIdx.x;
     const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
-    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN>(m.seg[s], blk - m.wg0[s]);
-    else mlp_fwd_body<CA, TRAIN>(m.seg[s], blk - m.wg0[s]);
+    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    else mlp_fwd_body<CA, TRAIN>(m.seg[s], blk - m.wg0[s], blockIdx.y);
 }
 
 template <class C>
@@ -344,6 +359,8 @@ static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed
     a.emb_a = d->embedding_a;
     a.cells = cells;
     a.n_cells = n_cells;
+    a.dcells = nullptr;
+    a.cell_rows = 0;
     a.aux_byte_off = (long)m.total_chunks * CHUNK_BYTES;
     a.io = *io;
     for (int i = 0; i < MAX_MFMA_LAYERS; ++i) a.bias_off[i] = i < m.n_mfma_layers ? m.layer[i].bias_off : 0;

@@ -1,6 +1,7 @@
 // mlp_fwd_multi.hip -- mnr_mlp_forward_multi: the foreground AND the background model's rows of one pass in ONE launch
 // (k_mlp_fwd_multi, mlp_fwd_kernels.h); its own translation unit so that it compiles beside mlp_fwd.hip.
 #include "mlp_fwd_kernels.h"
+#include "step_internal.h"
 
 using namespace mnr;
 
@@ -13,7 +14,9 @@ static bool desc_is(const mnr_model_desc *d, int xyz) {
            d->layers == 8 && d->skip_mask == 16 && d->rgb_dim == 3;
 }
 
-extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {
+static long n_cells_of(const mnr_mlp_launch &L, const CellTable &c) { return c.cell_rows > 0 ? L.io->n_rows / c.cell_rows : 0; }
+
+int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
     MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_MAX_SEGS, "1..%d segments per launch", MLP_MAX_SEGS);
     MlpFwdMulti mm{};
     const bool train = segs[0].tape_dev != nullptr;
@@ -34,16 +37,31 @@ extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, voi
         rc = is_fg ? fill_fwd_args<CfgFG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0)
                    : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0);
         if (rc != MNR_OK) return rc;
+        if (cells && cells[i].dcells) {
+            MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % CfgFG::ROWS_PER_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
+                        "segment %d: rows per cell must be a multiple of %d", i, CfgFG::ROWS_PER_WG);
+            mm.seg[i].dcells = cells[i].dcells;
+            mm.seg[i].cell_rows = cells[i].cell_rows;
+        }
         mm.is_b[i] = is_bg ? 1 : 0;
         mm.wg0[i] = (int32_t)wg;
+        if (cells) {                       // grid = (workgroups per cell, cells): every segment spans the same cells
+            MNR_REQUIRE(cells[i].dcells && n_cells_of(L, cells[i]) == n_cells_of(segs[0], cells[0]) && n_cells_of(L, cells[i]) >= 1,
+                        "multi-cell launch: every segment needs a cell table over the same number of cells");
+            wg += cells[i].cell_rows / CfgFG::ROWS_PER_WG;
+        } else
         wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     mm.nseg = n_segs;
     if (wg == 0) return MNR_OK;
-    hipStream_t s = as_stream(stream);
-    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
-    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false>), dim3((unsigned)wg), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    const unsigned ny = cells ? (unsigned)n_cells_of(segs[0], cells[0]) : 1u;
+    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
     return check_launch("k_mlp_fwd_multi");
+}
+
+extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {
+    return mlp_forward_multi_impl(segs, n_segs, nullptr, as_stream(stream));
 }

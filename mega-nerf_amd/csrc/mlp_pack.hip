@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "mlp_layout.h"
+#include "pack_device.h"
 
 namespace mnr {
 
@@ -35,64 +36,8 @@ int layout_from_desc(const mnr_model_desc *d, ModelLayout &m) {
     return MNR_OK;
 }
 
-// One thread per float4 of the chunk stream, then one thread per float of the aux image.
 __global__ void k_pack_model(ModelLayout m, float4 *__restrict__ chunks, float *__restrict__ aux) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n_f4 = (long)m.total_chunks * CHUNK_F4;
-    const int P = m.parts, tile = m.tile;
-    if (tid < n_f4) {
-        const int chunk = (int)(tid / CHUNK_F4), within = (int)(tid % CHUNK_F4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int li = -1;
-        for (int i = 0; i < m.n_mfma_layers; ++i)
-            if (chunk >= m.layer[i].chunk0 && chunk < m.layer[i].chunk0 + m.layer[i].nchunks) li = i;
-        if (li >= 0) {
-            const LayerLayout &l = m.layer[li];
-            const int lane = within & 63, blk = within >> 6;           // blk = gic * nob + ob
-            const int gic = blk / l.nob, ob = blk % l.nob;
-            const int g = (chunk - l.chunk0) * l.gpc + gic;
-            if (gic < l.gpc && g < l.ngroups) {
-                const int row = ob * tile + lane % tile, part = lane / tile;
-                float t[4];
-                for (int c = 0; c < 4; ++c) {
-                    const int col = layer_src_col(l, P, 4 * g + c, part);
-                    t[c] = (col >= 0 && row < l.n_out) ? l.w[(long)row * l.ld + col] : 0.f;
-                }
-                v = make_float4(t[0], t[1], t[2], t[3]);
-            }
-        }
-        chunks[tid] = v;
-        return;
-    }
-    const long a = tid - n_f4;
-    if (a >= m.aux_floats) return;
-    float v = 0.f;
-    // biases: [P][n_out/P] per layer, flat register i <-> feature 4P*(i/4) + 4*part + i%4
-    for (int i = 0; i < m.n_mfma_layers; ++i) {
-        const LayerLayout &l = m.layer[i];
-        const long o = a - l.bias_off;
-        if (o >= 0 && o < l.n_out) {
-            const int regs = l.n_out / P, part = (int)(o / regs), r = (int)(o % regs);
-            v = l.b[hid_src(P, r, part)];
-        }
-    }
-    {
-        const long o = a - m.sigma_off;
-        const int H = m.sigma_in_regs;
-        if (o >= 0 && o < P * H) v = m.sigma_w[hid_src(P, (int)(o % H), (int)(o / H))];
-        else if (o == P * H) v = m.sigma_b[0];
-    }
-    {
-        const long o = a - m.rgb_off;
-        const int H = m.rgb_in_regs, per = P * H;
-        if (o >= 0 && o < (long)m.rgb_dim * per) {
-            const int c = (int)(o / per), q = (int)(o % per);
-            v = m.rgb_w[(long)c * (P * H) + hid_src(P, q % H, q / H)];
-        } else if (o >= (long)m.rgb_dim * per && o < (long)m.rgb_dim * per + m.rgb_dim) {
-            v = m.rgb_b[o - (long)m.rgb_dim * per];
-        }
-    }
-    aux[a] = v;
+    pack_model_thread(m, chunks, aux, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 }  // namespace mnr

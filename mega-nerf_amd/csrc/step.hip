@@ -1,0 +1,1126 @@
+// step.hip -- one whole training step per call (mnr_train_step): runner.py:244-277 over rendering.py:15-173 for one or
+// several independent submodules ("cells"), as a fixed sequence of 13 launches + one memset on one stream.
+//
+//   memset            gradients, background-ray counts, error flags, loss, weight-gradient queue heads (one region)
+//   k_step_begin      one 1024-thread workgroup per cell: batch -> workspace, _intersect_sphere + near/far (rendering.py:33-45,
+//                     396-417), stable compaction of the rays with a background segment (+ their rays / image indices)
+//   k_step_samples    coarse samples of both branches (rendering.py:47-56, 82-87, 420-483; the background ones stored in the
+//                     flipped order the MLP sees, quirk Q1/Q2), every random number of the step (counter-based Philox)
+//   MLP coarse        fg + bg rows of ALL cells: k_mlp_fwd_multi<fg, bg, true>, grid = (workgroups per cell, cells)
+//   k_step_mid        one wavefront per ray: coarse compositing weights -> _sample_pdf -> fine points (rendering.py:212-225)
+//   MLP fine
+//   k_step_tail       one wavefront per ray: coarse/fine merge, compositing of both branches, fg/bg blend, MSE, and the adjoints
+//                     of all of these down to dL/d(raw MLP outputs) (rendering.py:102-131, 336-393; runner.py:370)
+//   k_mlp_bwd_multi   data-gradient chains of all four (branch, pass) segments of all cells
+//   k_head_grads_jobs sigma / rgb head gradients of every (cell, branch, pass)
+//   k_wgrad2 (+ reduce) per cell
+//   k_step_adam       torch.optim.Adam's update of every parameter of every cell (independent optimisers: parscripts/run_8.txt)
+//   k_step_pack       every forward / transposed weight image
+//
+// The ray-parallel kernels restate csrc/render.hip's stage kernels (same operations in the same order, so the step's
+// gradients equal the stage-by-stage path's: tests/test_gpu_step.py) with the intermediate arrays of a ray kept in LDS /
+// registers.  Compiled with -ffp-contract=off like render.hip (bit-exact sample positions).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "mlp_layout.h"
+#include "pack_device.h"
+#include "step_internal.h"
+
+namespace mnr {
+
+static constexpr int WPB = 4;                 // wavefronts per block in the ray-parallel kernels
+static constexpr int MAXC = MNR_STEP_MAX_CELLS;
+
+struct SSphere { float cx, cy, cz, rx, ry, rz; };
+
+__device__ __forceinline__ void s_norm_ray(const SSphere &sp, const float *ray, float (&o)[3], float (&d)[3]) {
+    o[0] = (ray[0] - sp.cx) / sp.rx; o[1] = (ray[1] - sp.cy) / sp.ry; o[2] = (ray[2] - sp.cz) / sp.rz;
+    d[0] = ray[3] / sp.rx; d[1] = ray[4] / sp.ry; d[2] = ray[5] / sp.rz;
+}
+__device__ __forceinline__ float s_dot3(const float (&a)[3], const float (&b)[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// rendering.py:472-483 (as render.hip::perturb_z)
+__device__ __forceinline__ float s_perturb_z(float zc, float zl, float zr, bool first, bool last, float perturb, float rnd) {
+    const float upper = last ? zc : 0.5f * (zc + zr);
+    const float lower = first ? zc : 0.5f * (zl + zc);
+    return lower + (upper - lower) * (perturb * rnd);
+}
+
+// _depth2pts_outside (rendering.py:420-469) for one sample: q[0..4) = (point on the unit sphere, inverse depth)
+__device__ __forceinline__ void s_bg_point(const SSphere &sp, const float *ray, float depth, float *q, float &depth_real) {
+    float o[3], d[3];
+    s_norm_ray(sp, ray, o, d);
+    const float dd = s_dot3(d, d);
+    const float d1 = -s_dot3(d, o) / dd;
+    const float pm[3] = {o[0] + d1 * d[0], o[1] + d1 * d[1], o[2] + d1 * d[2]};
+    const float pm_norm = sqrtf(s_dot3(pm, pm));
+    const float ray_d_cos = 1.f / sqrtf(dd);
+    const float d2 = sqrtf(1.f - pm_norm * pm_norm) * ray_d_cos;
+    const float dsum = d1 + d2;
+    const float ps[3] = {o[0] + dsum * d[0], o[1] + dsum * d[1], o[2] + dsum * d[2]};
+    float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
+    const float an = sqrtf(s_dot3(ax, ax)) + 1e-8f;
+    ax[0] /= an; ax[1] /= an; ax[2] /= an;
+    const float phi = asinf(pm_norm);
+    const float theta = asinf(pm_norm * depth);
+    const float ang = phi - theta;
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+    const float adp = s_dot3(ax, ps);
+    float pn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pn[c] = ps[c] * ca + cr[c] * sa + ax[c] * adp * (1.f - ca);
+    const float nn = sqrtf(s_dot3(pn, pn));
+    depth_real = 1.f / (depth + 1e-8f) * cosf(theta) + d1;
+    q[0] = pn[0] / nn; q[1] = pn[1] / nn; q[2] = pn[2] / nn; q[3] = depth;
+}
+
+// ---- counter-based random numbers (Philox4x32-10) ----------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }     // [0, 1), 24 bits
+
+// ---- workspace layout ------------------------------------------------------------------------------------------------------
+struct StepWs {
+    size_t zero_begin, grads, scal, loss, wcount, zero_end;
+    size_t rays, idx, target, far, last_delta, bg_slot, bg_list, rays_bg, idx_bg;
+    size_t z_c, xyz_c, z_f, xyz_f, raw_c, raw_f, draw_c, draw_f;
+    size_t zb_asc, zb_c, pts_c, dr_c, zb_f, pts_f, dr_f, braw_c, braw_f, bdraw_c, bdraw_f;
+    size_t noise_fc, noise_ff, noise_bc, noise_bf, u_f, u_b;
+    size_t rgb, depth_var, bg_lambda;
+    size_t tape_f, gtape_f, dheads_f, tape_b, gtape_b, dheads_b;
+    size_t ep_job, slab;
+    size_t tab_cells, tab_pack, tab_adam, t_c, t_bc, t_f, t_bf;
+    size_t grad_stride, total;
+};
+struct StepDims {
+    long C, N, Nc, Nf, Sb, Sfb, cap_f, cap_b, fpr_f, fpr_b;
+};
+
+static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mnr_model_desc *bg, StepDims &D) {
+    MNR_REQUIRE(cfg && fg && bg, "NULL argument");
+    MNR_REQUIRE(cfg->n_cells >= 1 && cfg->n_cells <= MAXC, "n_cells must be 1..%d", MAXC);
+    MNR_REQUIRE(cfg->n_rays >= 1 && cfg->coarse_samples >= 4 && cfg->fine_samples >= 2 && cfg->coarse_samples % 2 == 0 &&
+                cfg->fine_samples % 2 == 0, "bad ray / sample counts");
+    D.C = cfg->n_cells; D.N = cfg->n_rays; D.Nc = cfg->coarse_samples; D.Nf = cfg->fine_samples; D.Sb = D.Nc / 2; D.Sfb = D.Nf / 2;
+    if ((D.N * D.Sb) % 64 || (D.N * D.Sfb) % 64)
+        return set_err(MNR_E_UNSUPPORTED, "the fused step needs n_rays * samples / 2 to be a multiple of 64 (one workgroup tile)");
+    const bool shapes = (D.Nc == 64 && D.Nf == 128) || (D.Nc == 256 && D.Nf == 512);
+    if (!shapes) return set_err(MNR_E_UNSUPPORTED, "the fused step is instantiated for 64 + 128 and 256 + 512 samples per ray");
+    D.cap_f = D.N * (D.Nc + D.Nf); D.cap_b = D.N * (D.Sb + D.Sfb);
+    D.fpr_f = mnr_tape_floats_per_row(fg); D.fpr_b = mnr_tape_floats_per_row(bg);
+    if (D.fpr_f <= 0 || D.fpr_b <= 0) return set_err(MNR_E_UNSUPPORTED, "no training kernels for this architecture");
+    const bool arch = fg->xyz_dim == 3 && bg->xyz_dim == 4 && fg->pos_xyz_dim == 12 && bg->pos_xyz_dim == 12 && fg->pos_dir_dim == 4 &&
+                      bg->pos_dir_dim == 4 && fg->appearance_dim == 48 && bg->appearance_dim == 48 && fg->layer_dim == 256 &&
+                      bg->layer_dim == 256 && fg->layers == 8 && bg->layers == 8 && fg->skip_mask == 16 && bg->skip_mask == 16 &&
+                      fg->rgb_dim == 3 && bg->rgb_dim == 3 && (fg->mfma_tile == 0 || fg->mfma_tile == 16) &&
+                      (bg->mfma_tile == 0 || bg->mfma_tile == 16);
+    if (!arch) return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models");
+    return MNR_OK;
+}
+
+static void step_layout(const mnr_step_cfg *cfg, const StepDims &D, StepWs &L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const long C = D.C, N = D.N, CN = C * N;
+    L.zero_begin = off;
+    L.grad_stride = ((size_t)cfg->grad_floats_per_cell * 4 + 255) / 256 * 256;
+    L.grads = take(L.grad_stride * C);
+    L.scal = take(2 * MAXC * 4);             // n_bg[MAXC], then err[MAXC]
+    L.loss = take(C * 4);
+    L.wcount = take(C * 256);
+    L.zero_end = off;
+    L.rays = take(CN * 32); L.idx = take(CN * 4); L.target = take(CN * 12);
+    L.far = take(CN * 4); L.last_delta = take(CN * 4); L.bg_slot = take(CN * 4); L.bg_list = take(CN * 4);
+    L.rays_bg = take(CN * 32); L.idx_bg = take(CN * 4);
+    L.z_c = take(CN * D.Nc * 4); L.xyz_c = take(CN * D.Nc * 12); L.z_f = take(CN * D.Nf * 4); L.xyz_f = take(CN * D.Nf * 12);
+    L.raw_c = take(CN * D.Nc * 16); L.raw_f = take(CN * D.Nf * 16); L.draw_c = take(CN * D.Nc * 16); L.draw_f = take(CN * D.Nf * 16);
+    L.zb_asc = take(CN * D.Sb * 4); L.zb_c = take(CN * D.Sb * 4); L.pts_c = take(CN * D.Sb * 16); L.dr_c = take(CN * D.Sb * 4);
+    L.zb_f = take(CN * D.Sfb * 4); L.pts_f = take(CN * D.Sfb * 16); L.dr_f = take(CN * D.Sfb * 4);
+    L.braw_c = take(CN * D.Sb * 16); L.braw_f = take(CN * D.Sfb * 16); L.bdraw_c = take(CN * D.Sb * 16); L.bdraw_f = take(CN * D.Sfb * 16);
+    L.noise_fc = take(CN * D.Nc * 4); L.noise_ff = take(CN * D.Nf * 4); L.noise_bc = take(CN * D.Sb * 4); L.noise_bf = take(CN * D.Sfb * 4);
+    L.u_f = take(CN * D.Nf * 4); L.u_b = take(CN * D.Sfb * 4);
+    L.rgb = take(CN * 12); L.depth_var = take(CN * 4); L.bg_lambda = take(CN * 4);
+    L.tape_f = take((size_t)D.fpr_f * C * D.cap_f * 4); L.gtape_f = take((size_t)D.fpr_f * C * D.cap_f * 4); L.dheads_f = take((size_t)C * D.cap_f * 16);
+    L.tape_b = take((size_t)D.fpr_b * C * D.cap_b * 4); L.gtape_b = take((size_t)D.fpr_b * C * D.cap_b * 4); L.dheads_b = take((size_t)C * D.cap_b * 16);
+    L.ep_job = take(C * wgrad_ep_job_bytes()); L.slab = take(wgrad_slab_bytes());
+    L.tab_cells = take(4 * C * sizeof(MlpCellSeg));
+    L.tab_pack = take(0);       // sized below (depends on the plan's tables); placeholder keeps the order explicit
+    L.tab_adam = take(0);
+    L.t_c = take(D.Nc * 4); L.t_bc = take(D.Sb * 4); L.t_f = take(D.Nf * 4); L.t_bf = take(D.Sfb * 4);
+    L.total = off;
+}
+
+// ---- k_step_begin ------------------------------------------------------------------------------------------------------------
+struct BeginArgs { mnr_step_batch b[MAXC]; };
+
+__global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphere sp, float *__restrict__ rays_o, uint32_t *__restrict__ idx_o,
+                                                     float *__restrict__ target_o, float *__restrict__ far_o, float *__restrict__ last_delta_o,
+                                                     int32_t *__restrict__ slot_o, int32_t *__restrict__ list_o, float *__restrict__ rays_bg_o,
+                                                     uint32_t *__restrict__ idx_bg_o, int32_t *__restrict__ scal) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int cell = blockIdx.x;
+    const mnr_step_batch &b = ba.b[cell];
+    const long base = (long)cell * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (long start = 0; start < N; start += 1024) {
+        const long i = start + threadIdx.x;
+        int f = 0;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+        uint32_t ix = 0;
+        if (i < N) {
+            r0 = reinterpret_cast<const float4 *>(b.rays)[2 * i];
+            r1 = reinterpret_cast<const float4 *>(b.rays)[2 * i + 1];
+            ix = reinterpret_cast<const uint32_t *>(b.idx)[i];
+            reinterpret_cast<float4 *>(rays_o)[2 * (base + i)] = r0;
+            reinterpret_cast<float4 *>(rays_o)[2 * (base + i) + 1] = r1;
+            idx_o[base + i] = ix;
+            target_o[3 * (base + i)] = b.target[3 * i]; target_o[3 * (base + i) + 1] = b.target[3 * i + 1];
+            target_o[3 * (base + i) + 2] = b.target[3 * i + 2];
+            // rendering.py:33-45, 396-417 (as render.hip::k_ray_setup)
+            const float ray[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            float o[3], d[3];
+            s_norm_ray(sp, ray, o, d);
+            const float dd = s_dot3(d, d);
+            const float d1 = -s_dot3(d, o) / dd;
+            const float p[3] = {o[0] + d1 * d[0], o[1] + d1 * d[1], o[2] + d1 * d[2]};
+            const float ray_d_cos = 1.f / sqrtf(dd);
+            const float pn = s_dot3(p, p);
+            if (pn >= 1.f) atomicOr(scal + MAXC + cell, 1);
+            const float d2 = sqrtf(1.f - pn) * ray_d_cos;
+            const float near = ray[6], far = ray[7];
+            const float fg_far = fmaxf(d1 + d2, near);
+            f = far > fg_far;
+            far_o[base + i] = fminf(far, fg_far);
+            last_delta_o[base + i] = f ? fg_far : 1e10f;
+        }
+        // stable compaction (ascending ray order, like the boolean-mask indexing of rendering.py:37)
+        const unsigned long long m = __ballot(f);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (i < N) {
+            const int k = f ? off + before : -1;
+            slot_o[base + i] = k;
+            if (f) {
+                list_o[base + k] = (int32_t)i;
+                reinterpret_cast<float4 *>(rays_bg_o)[2 * (base + k)] = r0;
+                reinterpret_cast<float4 *>(rays_bg_o)[2 * (base + k) + 1] = r1;
+                idx_bg_o[base + k] = ix;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scal[cell] = base_s;
+}
+
+// ---- k_step_samples ----------------------------------------------------------------------------------------------------------
+struct SamplesArgs {
+    mnr_step_randoms inj[MAXC];
+    long C, N;
+    int Nc, Nf, Sb, Sfb;
+    float perturb;
+    int noise, has_inj;
+    unsigned seed_lo, seed_hi, step_lo, step_hi;
+    SSphere sp;
+    const float *rays, *far, *rays_bg, *t_c, *t_bc;
+    const int32_t *scal;
+    float *z_c, *xyz_c, *zb_asc, *zb_c, *pts_c, *dr_c;
+    float *noise_fc, *noise_ff, *noise_bc, *noise_bf, *u_f, *u_b;
+};
+
+__global__ __launch_bounds__(256) void k_step_samples(SamplesArgs a) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long CN = a.C * a.N;
+    if (t >= CN * (a.Nc + a.Nf)) return;
+    // element t of a random stream laid out [cell][per_cell]: the injected value if the caller supplied that stream for the cell
+    // (parity tests), else Philox with key (seed + cell) and counter (element inside the cell, stream, step) -- a cell draws the
+    // same numbers whether it shares the launch with other cells or runs alone with seed + cell.  `unit` > 0: the stream belongs
+    // to the compacted background rays -- rows past the cell's count do not exist in an injected array (and are never read)
+    auto pick = [&](const float *mnr_step_randoms::*member, long per_cell, unsigned stream, int unit) -> float {
+        const long cell = t / per_cell, local = t - cell * per_cell;
+        const float *p = a.has_inj ? a.inj[cell].*member : nullptr;
+        if (!p) {
+            const unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + (unsigned long long)cell;
+            return u01(philox4x32(make_uint4((unsigned)local, (unsigned)((unsigned long long)local >> 32), stream, a.step_lo),
+                                  make_uint2((unsigned)sd, (unsigned)(sd >> 32) ^ a.step_hi)).x);
+        }
+        if (unit > 0 && local / unit >= (long)a.scal[cell]) return 0.f;
+        return p[local];
+    };
+    // sigma noise of the MLP rows (rendering.py:294, 321) -- row order = the MLP's (cell-major arrays, one per pass)
+    if (a.noise) {
+        if (t < CN * a.Nc) a.noise_fc[t] = pick(&mnr_step_randoms::fg_noise_coarse, a.N * a.Nc, 0u, 0);
+        if (t < CN * a.Nf) a.noise_ff[t] = pick(&mnr_step_randoms::fg_noise_fine, a.N * a.Nf, 1u, 0);
+        if (t < CN * a.Sb) a.noise_bc[t] = pick(&mnr_step_randoms::bg_noise_coarse, a.N * a.Sb, 2u, a.Sb);
+        if (t < CN * a.Sfb) a.noise_bf[t] = pick(&mnr_step_randoms::bg_noise_fine, a.N * a.Sfb, 3u, a.Sfb);
+    }
+    if (a.perturb > 0.f) {
+        if (t < CN * a.Nf) a.u_f[t] = pick(&mnr_step_randoms::fg_u, a.N * a.Nf, 4u, 0);
+        if (t < CN * a.Sfb) a.u_b[t] = pick(&mnr_step_randoms::bg_u, a.N * a.Sfb, 5u, a.Sfb);
+    }
+    // foreground coarse sample (rendering.py:82-87; as render.hip::k_fg_samples)
+    if (t < CN * a.Nc) {
+        const long r = t / a.Nc;
+        const int s = (int)(t - r * a.Nc), S = a.Nc;
+        const float *ray = a.rays + r * 8;
+        const float near = ray[6], far = a.far[r];
+        const float *tt = a.t_c;
+        float z = near * (1.f - tt[s]) + far * tt[s];
+        if (a.perturb > 0.f) {
+            const float zl = s > 0 ? near * (1.f - tt[s - 1]) + far * tt[s - 1] : z;
+            const float zr = s < S - 1 ? near * (1.f - tt[s + 1]) + far * tt[s + 1] : z;
+            z = s_perturb_z(z, zl, zr, s == 0, s == S - 1, a.perturb, pick(&mnr_step_randoms::fg_perturb, a.N * a.Nc, 6u, 0));
+        }
+        a.z_c[t] = z;
+        a.xyz_c[3 * t + 0] = ray[0] + ray[3] * z;
+        a.xyz_c[3 * t + 1] = ray[1] + ray[4] * z;
+        a.xyz_c[3 * t + 2] = ray[2] + ray[5] * z;
+    }
+    // background coarse sample (rendering.py:47-56; as render.hip::k_bg_samples), stored ascending for the sampler's bins and in
+    // the flipped order of rendering.py:271-273 for the MLP / compositing (depth_real is NOT flipped: quirk Q2)
+    if (t < CN * a.Sb) {
+        const long g = t / a.Sb;                        // compacted background unit: cell * N + k
+        const long cell = g / a.N, k = g - cell * a.N;
+        if (k < (long)a.scal[cell]) {
+            const int s = (int)(t - g * a.Sb), S = a.Sb;
+            const float *tt = a.t_bc;
+            float depth = tt[s];
+            if (a.perturb > 0.f)
+                depth = s_perturb_z(depth, s > 0 ? tt[s - 1] : depth, s < S - 1 ? tt[s + 1] : depth, s == 0, s == S - 1, a.perturb,
+                                    pick(&mnr_step_randoms::bg_perturb, a.N * a.Sb, 7u, a.Sb));
+            float q[4], dr;
+            s_bg_point(a.sp, a.rays_bg + g * 8, depth, q, dr);
+            a.zb_asc[t] = depth;
+            a.dr_c[t] = dr;
+            const long tf = g * a.Sb + (S - 1 - s);
+            a.zb_c[tf] = depth;
+            *reinterpret_cast<float4 *>(a.pts_c + 4 * tf) = make_float4(q[0], q[1], q[2], q[3]);
+        }
+    }
+}
+
+// ---- wave-level pieces of the ray kernels (restated from render.hip) -------------------------------------------------------
+template <class Tv>
+__device__ __forceinline__ Tv s_wave_sum(Tv v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ void s_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): LDS writes visible to the wave
+}
+__device__ __forceinline__ float s_wave_max(const float *p, int n, int lane) {
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, p[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+
+// per-lane state of one composited ray (lane owns the contiguous samples k = lane * E + e); forward as k_composite, kept for
+// the adjoint (k_composite_bwd)
+template <int E>
+struct Comp {
+    float alpha[E], ex[E], delta[E], tt[E], T[E], w[E], z[E];
+    float4 c[E];
+    float lambda;
+};
+
+// z(k) from an LDS array, raw(k) through a loader; computes weights (and lambda); render.hip::k_composite / k_composite_bwd
+template <int E, class LoadRaw>
+__device__ __forceinline__ void comp_forward(Comp<E> &st, const float *zl, int S, int lane, float last, int flip, LoadRaw load_raw) {
+    double prod = 1.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        st.alpha[e] = 0.f; st.ex[e] = 1.f; st.delta[e] = 0.f; st.tt[e] = 1.f; st.z[e] = 0.f; st.c[e] = make_float4(0, 0, 0, 0);
+        if (k < S) {
+            const float zk = zl[k];
+            st.z[e] = zk;
+            st.c[e] = load_raw(k);
+            st.delta[e] = (k == S - 1) ? last : (flip ? zk - zl[k + 1] : zl[k + 1] - zk);
+            st.ex[e] = expf(-st.delta[e] * st.c[e].w);
+            st.alpha[e] = 1.f - st.ex[e];
+            st.tt[e] = 1.f - st.alpha[e] + 1e-8f;
+            prod *= (double)st.tt[e];
+        }
+    }
+    double incl = prod;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if (lane >= o) incl *= up;
+    }
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0;
+    st.lambda = (float)__shfl(incl, 63);
+    double run = excl;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        st.T[e] = (float)run; st.w[e] = 0.f;
+        if (k < S) {
+            st.w[e] = st.alpha[e] * st.T[e];
+            run *= (double)st.tt[e];
+        }
+    }
+}
+
+// dL/d(raw) of one ray from dL/d(rgb) (gr, gg, gb) and dL/d(lambda); store(e, k, float4) receives the gradient of the lane's e-th sample k
+template <int E, class Store>
+__device__ __forceinline__ void comp_backward(const Comp<E> &st, int S, int lane, float gr, float gg, float gb, float dlam, Store store) {
+    float gk[E];
+    float gw_lane = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        gk[e] = 0.f;
+        if (k < S) {
+            gk[e] = gr * st.c[e].x + gg * st.c[e].y + gb * st.c[e].z;
+            gw_lane += gk[e] * st.w[e];
+        }
+    }
+    float suf = gw_lane;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float dn = __shfl_down(suf, o);
+        if (lane + o < 64) suf += dn;
+    }
+    float after = suf - gw_lane;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        const int k = lane * E + e;
+        if (k < S) {
+            const float dalpha = gk[e] * st.T[e] - (after + dlam * st.lambda) / st.tt[e];
+            const float dsigma = dalpha * st.delta[e] * st.ex[e];
+            store(e, k, make_float4(st.w[e] * gr, st.w[e] * gg, st.w[e] * gb, dsigma));
+            after += gk[e] * st.w[e];
+        }
+    }
+}
+
+// _sample_pdf / _sample_cdf (rendering.py:486-536) for one ray; bins / w / cdf are LDS arrays of nb + 1 / nb / nb + 1 floats,
+// already filled with the mid-points and the weights + 1e-8 (render.hip::k_sample_pdf<true>); emit(f, z) receives sample f
+template <class Emit>
+__device__ __forceinline__ void sample_pdf_wave(float *bins, float *w, float *cdf, int nb, int nf, int det, const float *u, int lane, Emit emit) {
+    const int V = 8, ILP = 4;
+    const int nv = nb / V, q = nv / ILP;
+    float p0 = 0.f;
+    if (lane < V) {
+        float part[ILP] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < q; ++i)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) part[k] += w[(i * ILP + k) * V + lane];
+        for (int j = q * ILP; j < nv; ++j) part[0] += w[j * V + lane];
+        part[0] += part[1];
+        part[0] += part[2];
+        part[0] += part[3];
+        p0 = part[0];
+    }
+    float total = 0.f;
+    for (int k = nv * V; k < nb; ++k) total += w[k];
+#pragma unroll
+    for (int l = 0; l < V; ++l) total += __shfl(p0, l);
+    for (int i = lane; i < nb; i += 64) w[i] = w[i] / total;
+    s_lds_fence();
+    if (lane == 0) {
+        double acc = 0.0;
+        cdf[0] = 0.f;
+        for (int i = 0; i < nb; ++i) {
+            acc += (double)w[i];
+            cdf[i + 1] = (float)acc;
+        }
+    }
+    s_lds_fence();
+    for (int f = lane; f < nf; f += 64) {
+        const float uu = u[f];
+        int lo = 0, hi = nb + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, nb);
+        const float cb = cdf[below], ca = cdf[above];
+        float denom = ca - cb;
+        if (denom < 1e-8f) denom = 1.f;
+        const float bb = bins[below], ba = bins[above];
+        emit(f, bb + (uu - cb) / denom * (ba - bb));
+    }
+    (void)det;
+}
+
+// ---- k_step_mid --------------------------------------------------------------------------------------------------------------
+struct MidArgs {
+    long C, N;
+    int Nc, Nf, Sb, Sfb, det;
+    SSphere sp;
+    const float *rays, *rays_bg, *last_delta, *z_c, *raw_c, *zb_asc, *zb_c, *braw_c, *u_f, *u_b, *t_f, *t_bf;
+    const int32_t *scal;
+    float *z_f, *xyz_f, *zb_f, *pts_f, *dr_f;
+};
+
+template <int EC, int EB>
+__global__ __launch_bounds__(64 * WPB) void k_step_mid(MidArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long unit = (long)blockIdx.x * WPB + wave;
+    const long CN = a.C * a.N;
+    if (unit >= 2 * CN) return;
+    const int per_wave = 4 * a.Nc + 8;
+    float *zl = smem + wave * per_wave;          // Nc      z of the ray as the compositing sees it
+    float *bins = zl + a.Nc;                     // <= Nc - 1
+    float *w = bins + a.Nc;                      // <= Nc - 2
+    float *cdf = w + a.Nc;                       // <= Nc - 1
+    if (unit < CN) {
+        // ---- foreground ray: rendering.py:195-225 ----
+        const long r = unit;
+        const int S = a.Nc, nb = S - 2;
+        for (int i = lane; i < S; i += 64) zl[i] = a.z_c[r * S + i];
+        s_lds_fence();
+        float last = a.last_delta[r];
+        if (last < 1e10f) last = last - s_wave_max(zl, S, lane);              // rendering.py:192-193
+        Comp<EC> st;
+        const float4 *raw = reinterpret_cast<const float4 *>(a.raw_c) + r * S;
+        comp_forward<EC>(st, zl, S, lane, last, 0, [&](int k) { return raw[k]; });
+        for (int i = lane; i <= nb; i += 64) bins[i] = 0.5f * (zl[i] + zl[i + 1]);           // rendering.py:213
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const int k = lane * EC + e;
+            if (k >= 1 && k <= nb) w[k - 1] = st.w[e] + 1e-8f;                                 // :215 [:, 1:-1], :497
+        }
+        s_lds_fence();
+        const float *ray = a.rays + r * 8;
+        const float o0 = ray[0], o1 = ray[1], o2 = ray[2], d0 = ray[3], d1 = ray[4], d2 = ray[5];
+        float *zf = a.z_f + r * a.Nf;
+        float *xf = a.xyz_f + r * a.Nf * 3;
+        sample_pdf_wave(bins, w, cdf, nb, a.Nf, a.det, a.det ? a.t_f : a.u_f + r * a.Nf, lane, [&](int f, float z) {
+            zf[f] = z;
+            xf[3 * f] = o0 + d0 * z; xf[3 * f + 1] = o1 + d1 * z; xf[3 * f + 2] = o2 + d2 * z;
+        });
+    } else {
+        // ---- compacted background ray (flip: rendering.py:271-273; weights in flipped order against ascending bins: quirk Q1) ----
+        const long g = unit - CN;
+        const long cell = g / a.N, k0 = g - cell * a.N;
+        if (k0 >= (long)a.scal[cell]) return;
+        const int S = a.Sb, nb = S - 2;
+        for (int i = lane; i < S; i += 64) zl[i] = a.zb_c[g * S + i];
+        s_lds_fence();
+        Comp<EB> st;
+        const float4 *raw = reinterpret_cast<const float4 *>(a.braw_c) + g * S;
+        comp_forward<EB>(st, zl, S, lane, 1e10f, 1, [&](int k) { return raw[k]; });
+        const float *za = a.zb_asc + g * S;
+        for (int i = lane; i <= nb; i += 64) bins[i] = 0.5f * (za[i] + za[i + 1]);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int k = lane * EB + e;
+            if (k >= 1 && k <= nb && k < S) w[k - 1] = st.w[e] + 1e-8f;
+        }
+        s_lds_fence();
+        const float *ray = a.rays_bg + g * 8;
+        float *zf = a.zb_f + g * a.Sfb;
+        sample_pdf_wave(bins, w, cdf, nb, a.Sfb, a.det, a.det ? a.t_bf : a.u_b + g * a.Sfb, lane, [&](int f, float z) {
+            zf[f] = z;
+            float q[4], dr;
+            s_bg_point(a.sp, ray, z, q, dr);
+            *reinterpret_cast<float4 *>(a.pts_f + 4 * (g * a.Sfb + f)) = make_float4(q[0], q[1], q[2], q[3]);
+            a.dr_f[g * a.Sfb + f] = dr;
+        });
+    }
+}
+
+// ---- k_step_tail -------------------------------------------------------------------------------------------------------------
+struct TailArgs {
+    long C, N;
+    int Nc, Nf, Sb, Sfb;
+    const float *z_c, *z_f, *raw_c, *raw_f, *zb_c, *zb_f, *braw_c, *braw_f, *last_delta, *target;
+    const int32_t *slot;
+    float *draw_c, *draw_f, *bdraw_c, *bdraw_f;
+    float *rgb, *depth_var, *bg_lambda, *loss;
+};
+
+// stable rank sort of cat([fine, coarse]) (rendering.py:336-350; render.hip::k_merge_sorted): zm[rank] = key, src[rank] = element
+__device__ __forceinline__ void merge_wave(float *key, float *zm, int *src, const float *zfine, int Sa, const float *zcoarse, int Sb, int flip,
+                                           int lane) {
+    const int St = Sa + Sb;
+    for (int i = lane; i < St; i += 64) key[i] = i < Sa ? zfine[i] : zcoarse[i - Sa];
+    s_lds_fence();
+    for (int e = lane; e < St; e += 64) {
+        const float ke = key[e];
+        int rank = 0;
+        if (flip) {
+            for (int j = 0; j < St; ++j) { const float kj = key[j]; rank += (kj > ke) || (kj == ke && j < e); }
+        } else {
+            for (int j = 0; j < St; ++j) { const float kj = key[j]; rank += (kj < ke) || (kj == ke && j < e); }
+        }
+        zm[rank] = ke;
+        src[rank] = e;
+    }
+    s_lds_fence();
+}
+
+template <int EF, int EB>
+__global__ __launch_bounds__(64 * WPB) void k_step_tail(TailArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * WPB + wave;
+    if (r >= a.C * a.N) return;
+    const long cell = r / a.N;
+    const int Sm = a.Nc + a.Nf, Smb = a.Sb + a.Sfb;
+    float *key = smem + wave * 3 * Sm;
+    float *zm = key + Sm;
+    int *src = reinterpret_cast<int *>(zm + Sm);
+
+    // ---- background branch of this ray (the wave of the ray does both branches: the blend couples them) ----
+    const int slot = a.slot[r];
+    Comp<EB> sb;
+    int srcb[EB];
+    float bgr = 0.f, bgg = 0.f, bgb = 0.f;
+    const long g = cell * a.N + (slot >= 0 ? slot : 0);
+    if (slot >= 0) {
+        merge_wave(key, zm, src, a.zb_f + g * a.Sfb, a.Sfb, a.zb_c + g * a.Sb, a.Sb, 1, lane);
+#pragma unroll
+        for (int e = 0; e < EB; ++e) { const int k = lane * EB + e; srcb[e] = k < Smb ? src[k] : 0; }
+        const float4 *rf = reinterpret_cast<const float4 *>(a.braw_f) + g * a.Sfb, *rc = reinterpret_cast<const float4 *>(a.braw_c) + g * a.Sb;
+        comp_forward<EB>(sb, zm, Smb, lane, 1e10f, 1, [&](int k) { const int s = src[k]; return s < a.Sfb ? rf[s] : rc[s - a.Sfb]; });
+        float rr = 0.f, gg = 0.f, bb = 0.f;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) { rr += sb.w[e] * sb.c[e].x; gg += sb.w[e] * sb.c[e].y; bb += sb.w[e] * sb.c[e].z; }
+        bgr = s_wave_sum(rr); bgg = s_wave_sum(gg); bgb = s_wave_sum(bb);
+        s_lds_fence();
+    }
+
+    // ---- foreground branch ----
+    const float *zf = a.z_f + r * a.Nf;
+    merge_wave(key, zm, src, zf, a.Nf, a.z_c + r * a.Nc, a.Nc, 0, lane);
+    int srcf[EF];
+#pragma unroll
+    for (int e = 0; e < EF; ++e) { const int k = lane * EF + e; srcf[e] = k < Sm ? src[k] : 0; }
+    float last = a.last_delta[r];
+    if (last < 1e10f) last = last - s_wave_max(zf, a.Nf, lane);                 // rendering.py:224-225 (fine-only max: quirk Q4)
+    Comp<EF> sf;
+    {
+        const float4 *rf = reinterpret_cast<const float4 *>(a.raw_f) + r * a.Nf, *rc = reinterpret_cast<const float4 *>(a.raw_c) + r * a.Nc;
+        comp_forward<EF>(sf, zm, Sm, lane, last, 0, [&](int k) { const int s = src[k]; return s < a.Nf ? rf[s] : rc[s - a.Nf]; });
+    }
+    float rr = 0.f, gg = 0.f, bb = 0.f, dsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EF; ++e) {
+        rr += sf.w[e] * sf.c[e].x; gg += sf.w[e] * sf.c[e].y; bb += sf.w[e] * sf.c[e].z;
+        dsum += sf.w[e] * sf.z[e];
+    }
+    rr = s_wave_sum(rr); gg = s_wave_sum(gg); bb = s_wave_sum(bb);
+    dsum = s_wave_sum(dsum);
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < EF; ++e) { const float df = sf.z[e] - dsum; var += sf.w[e] * (df * df); }
+    var = s_wave_sum(var);
+    const float lam = sf.lambda;
+
+    // ---- blend (rendering.py:102-131), loss (runner.py:370 mse_loss, mean over n_rays x 3) and their adjoints ----
+    float rgb[3] = {rr, gg, bb};
+    if (slot >= 0) { rgb[0] = rr + bgr * lam; rgb[1] = gg + bgg * lam; rgb[2] = bb + bgb * lam; }
+    const float *tg = a.target + r * 3;
+    const float inv = 1.f / (float)(3 * a.N);
+    float d[3], sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float df = rgb[c] - tg[c]; sq += df * df; d[c] = (2.f * inv) * df; }
+    if (lane == 0) {
+        a.rgb[3 * r] = rgb[0]; a.rgb[3 * r + 1] = rgb[1]; a.rgb[3 * r + 2] = rgb[2];
+        a.depth_var[r] = var;
+        a.bg_lambda[r] = lam;
+        atomicAdd(a.loss + cell, sq * inv);
+    }
+    float dlam = 0.f;
+    if (slot >= 0) { dlam += d[0] * bgr; dlam += d[1] * bgg; dlam += d[2] * bgb; }
+    {
+        float4 *df = reinterpret_cast<float4 *>(a.draw_f) + r * a.Nf, *dc = reinterpret_cast<float4 *>(a.draw_c) + r * a.Nc;
+        comp_backward<EF>(sf, Sm, lane, d[0], d[1], d[2], dlam, [&](int e, int, float4 v) {
+            const int s = srcf[e];
+            if (s < a.Nf) df[s] = v; else dc[s - a.Nf] = v;
+        });
+    }
+    if (slot >= 0) {
+        float4 *df = reinterpret_cast<float4 *>(a.bdraw_f) + g * a.Sfb, *dc = reinterpret_cast<float4 *>(a.bdraw_c) + g * a.Sb;
+        comp_backward<EB>(sb, Smb, lane, lam * d[0], lam * d[1], lam * d[2], 0.f, [&](int e, int, float4 v) {
+            const int s = srcb[e];
+            if (s < a.Sfb) df[s] = v; else dc[s - a.Sfb] = v;
+        });
+    }
+}
+
+// ---- optimiser + re-pack -----------------------------------------------------------------------------------------------------
+struct AdamTensor { float *p; const float *g; float *m, *v; long n, block0; };
+
+__global__ __launch_bounds__(256) void k_step_adam(const AdamTensor *__restrict__ tab, int n_tensors, float beta1, float beta2, float eps,
+                                                   float step_size, float bc2_sqrt) {
+    // binary search: the tensor whose block range holds this block
+    int lo = 0, hi = n_tensors - 1;
+    const long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const AdamTensor t = tab[lo];
+    const long i0 = ((b - t.block0) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long i = i0 + j;
+        if (i < t.n) {
+            // torch/optim/adam.py (_single_tensor_adam / the fused kernel), no weight decay, no amsgrad
+            const float g = t.g[i];
+            const float m = t.m[i] + (g - t.m[i]) * (1.f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+            const float v = beta2 * t.v[i] + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            t.p[i] = t.p[i] - step_size * (m / denom);
+            t.m[i] = m; t.v[i] = v;
+        }
+    }
+}
+
+struct PackJob {
+    int kind;                  // 0: forward image (ModelLayout), 1: transposed image (BwdLayout)
+    long block0, nblocks;
+    float4 *chunks;
+    float *aux;
+    ModelLayout m;
+    BwdLayout b;
+};
+__global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ jobs, int n_jobs) {
+    int j = 0;
+    const long blk = blockIdx.x;
+    for (int i = 1; i < n_jobs; ++i) j += blk >= jobs[i].block0;
+    const PackJob &job = jobs[j];
+    const long tid = (blk - job.block0) * 256 + threadIdx.x;
+    if (job.kind == 0) pack_model_thread(job.m, job.chunks, job.aux, tid);
+    else pack_bwd_thread(job.b, job.chunks, tid);
+}
+
+}  // namespace mnr
+
+using namespace mnr;
+
+// =====================================================================================================================
+struct mnr_step_plan {
+    mnr_step_cfg cfg;
+    std::vector<mnr_step_model> models;
+    StepDims D;
+    StepWs L;
+    char *ws;
+    std::vector<float> tables;        // host copies of the four linspace tables (cfg's pointers are not kept)
+    int n_pack_jobs, n_adam_tensors;
+    long pack_blocks, adam_blocks;
+    SSphere sp;
+    std::vector<hipEvent_t> events;   // profiling: n_slots x MNR_STEP_SPANS x (start, stop)
+    int prof_slots = 0;
+    long prof_step = 0;
+    ~mnr_step_plan() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+};
+
+static size_t pack_table_bytes(int C) { return (size_t)4 * C * sizeof(PackJob); }
+static size_t adam_table_bytes(int C) { return (size_t)2 * C * 32 * sizeof(AdamTensor); }
+
+static void finish_layout(const mnr_step_cfg *cfg, const StepDims &D, StepWs &L) {
+    step_layout(cfg, D, L);
+    // the two variable-size tables go behind everything else
+    size_t off = L.total;
+    L.tab_pack = off; off += (pack_table_bytes((int)D.C) + 255) / 256 * 256;
+    L.tab_adam = off; off += (adam_table_bytes((int)D.C) + 255) / 256 * 256;
+    L.total = off;
+}
+
+extern "C" int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mnr_model_desc *bg, mnr_step_layout *out) {
+    MNR_REQUIRE(out, "NULL argument");
+    StepDims D;
+    int rc = step_dims(cfg, fg, bg, D);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(cfg->grad_floats_per_cell > 0, "grad_floats_per_cell must be positive");
+    StepWs L;
+    finish_layout(cfg, D, L);
+    out->workspace_bytes = L.total;
+    out->grad_offset = L.grads; out->grad_stride = L.grad_stride;
+    out->loss_offset = L.loss; out->rgb_offset = L.rgb; out->depth_var_offset = L.depth_var; out->bg_lambda_offset = L.bg_lambda;
+    out->n_bg_offset = L.scal; out->err_offset = L.scal + MAXC * 4;
+    return MNR_OK;
+}
+
+// tensors of one model in (param, grad, m, v) form
+static int adam_tensors_of(const mnr_step_model &M, std::vector<AdamTensor> &out) {
+    const mnr_model_desc &d = M.desc;
+    const int W = d.layer_dim, E = emb_cols(d.xyz_dim, d.pos_xyz_dim), ED = emb_cols(3, d.pos_dir_dim);
+    int err = 0;
+    auto add = [&](const float *p, float *g, float *m, float *v, long n) {
+        if (!p || !g || !m || !v) { err = 1; return; }
+        out.push_back(AdamTensor{const_cast<float *>(p), g, m, v, n, 0});
+    };
+    for (int l = 0; l < d.layers; ++l) {
+        const long in = l == 0 ? E : (((d.skip_mask >> l) & 1) ? E + W : W);
+        add(d.layer_w[l], M.grad.layer_w[l], M.adam_m.layer_w[l], M.adam_v.layer_w[l], (long)W * in);
+        add(d.layer_b[l], M.grad.layer_b[l], M.adam_m.layer_b[l], M.adam_v.layer_b[l], W);
+    }
+    add(d.embedding_a, M.grad.embedding_a, M.adam_m.embedding_a, M.adam_v.embedding_a, (long)d.appearance_count * d.appearance_dim);
+    add(d.final_w, M.grad.final_w, M.adam_m.final_w, M.adam_v.final_w, (long)W * W);
+    add(d.final_b, M.grad.final_b, M.adam_m.final_b, M.adam_v.final_b, W);
+    add(d.dir_a_w, M.grad.dir_a_w, M.adam_m.dir_a_w, M.adam_v.dir_a_w, (long)(W / 2) * (W + ED + d.appearance_dim));
+    add(d.dir_a_b, M.grad.dir_a_b, M.adam_m.dir_a_b, M.adam_v.dir_a_b, W / 2);
+    add(d.sigma_w, M.grad.sigma_w, M.adam_m.sigma_w, M.adam_v.sigma_w, W);
+    add(d.sigma_b, M.grad.sigma_b, M.adam_m.sigma_b, M.adam_v.sigma_b, 1);
+    add(d.rgb_w, M.grad.rgb_w, M.adam_m.rgb_w, M.adam_v.rgb_w, (long)d.rgb_dim * (W / 2));
+    add(d.rgb_b, M.grad.rgb_b, M.adam_m.rgb_b, M.adam_v.rgb_b, d.rgb_dim);
+    MNR_REQUIRE(!err, "mnr_step_create: a parameter / gradient / Adam-moment pointer is missing");
+    return MNR_OK;
+}
+
+extern "C" int mnr_step_repack(mnr_step_plan *p, void *stream) {
+    MNR_REQUIRE(p, "NULL plan");
+    hipLaunchKernelGGL(k_step_pack, dim3((unsigned)p->pack_blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const PackJob *>(p->ws + p->L.tab_pack), p->n_pack_jobs);
+    return check_launch("k_step_pack");
+}
+
+extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, const mnr_step_model *models, void *workspace_dev,
+                               size_t workspace_bytes, void *stream) {
+    MNR_REQUIRE(out && cfg && models && workspace_dev, "NULL argument");
+    StepDims D;
+    int rc = step_dims(cfg, &models[0].desc, &models[1].desc, D);
+    if (rc != MNR_OK) return rc;
+    MNR_REQUIRE(cfg->t_coarse && cfg->t_bg_coarse && cfg->t_fine && cfg->t_bg_fine, "linspace tables missing");
+    MNR_REQUIRE(cfg->sphere_radius[0] > 0 && cfg->sphere_radius[1] > 0 && cfg->sphere_radius[2] > 0, "sphere_radius must be positive");
+    StepWs L;
+    finish_layout(cfg, D, L);
+    MNR_REQUIRE(workspace_bytes >= L.total, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+    const int C = (int)D.C;
+    hipStream_t s = as_stream(stream);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    auto *plan = new mnr_step_plan();
+    plan->cfg = *cfg; plan->D = D; plan->L = L; plan->ws = ws;
+    plan->models.assign(models, models + 2 * C);
+    plan->cfg.t_coarse = plan->cfg.t_bg_coarse = plan->cfg.t_fine = plan->cfg.t_bg_fine = nullptr;
+    plan->sp = SSphere{cfg->sphere_center[0], cfg->sphere_center[1], cfg->sphere_center[2], cfg->sphere_radius[0], cfg->sphere_radius[1],
+                       cfg->sphere_radius[2]};
+    auto fail = [&](int code) { delete plan; return code; };
+    // every cell: same architectures, all pointers present, gradient views inside the workspace's gradient area
+    std::vector<MlpCellSeg> cells(4 * C);
+    std::vector<PackJob> jobs;
+    std::vector<AdamTensor> adam;
+    long pack_blocks = 0;
+    for (int c = 0; c < C; ++c) {
+        for (int k = 0; k < 2; ++k) {
+            const mnr_step_model &M = models[2 * c + k];
+            const mnr_model_desc &d0 = models[k].desc, &d = M.desc;
+            if (d.xyz_dim != d0.xyz_dim || d.pos_xyz_dim != d0.pos_xyz_dim || d.pos_dir_dim != d0.pos_dir_dim || d.layers != d0.layers ||
+                d.skip_mask != d0.skip_mask || d.layer_dim != d0.layer_dim || d.appearance_dim != d0.appearance_dim ||
+                d.appearance_count != d0.appearance_count || d.rgb_dim != d0.rgb_dim || d.sigma_activation != d0.sigma_activation)
+                return fail(set_err(MNR_E_INVALID, "mnr_step_create: every cell must have the architecture of cell 0"));
+            if (!M.packed_dev || !M.packed_bwd_dev || !d.embedding_a || !M.grad.embedding_a)
+                return fail(set_err(MNR_E_INVALID, "mnr_step_create: cell %d: packed image / embedding pointers missing", c));
+            const char *g0 = ws + L.grads + (size_t)c * L.grad_stride;
+            const char *ge = g0 + (size_t)cfg->grad_floats_per_cell * 4;
+            const char *gp = reinterpret_cast<const char *>(M.grad.sigma_b);
+            if (gp < g0 || gp >= ge) return fail(set_err(MNR_E_INVALID, "mnr_step_create: cell %d: gradients must live in the workspace's gradient area", c));
+            ModelLayout ml;
+            BwdLayout bl;
+            if ((rc = layout_from_desc(&d, ml)) != MNR_OK || (rc = bwd_layout_from_desc(&d, bl)) != MNR_OK) return fail(rc);
+            PackJob jf{};
+            jf.kind = 0; jf.m = ml; jf.chunks = reinterpret_cast<float4 *>(M.packed_dev);
+            jf.aux = reinterpret_cast<float *>(reinterpret_cast<char *>(M.packed_dev) + (size_t)ml.total_chunks * CHUNK_BYTES);
+            jf.block0 = pack_blocks; jf.nblocks = ((long)ml.total_chunks * CHUNK_F4 + ml.aux_floats + 255) / 256;
+            pack_blocks += jf.nblocks;
+            jobs.push_back(jf);
+            PackJob jb{};
+            jb.kind = 1; jb.b = bl; jb.chunks = reinterpret_cast<float4 *>(M.packed_bwd_dev);
+            jb.block0 = pack_blocks; jb.nblocks = ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
+            pack_blocks += jb.nblocks;
+            jobs.push_back(jb);
+            if ((rc = adam_tensors_of(M, adam)) != MNR_OK) return fail(rc);
+            // the four (branch, pass) cell tables: fg coarse, fg fine, bg coarse, bg fine
+            for (int pass = 0; pass < 2; ++pass) {
+                MlpCellSeg &e = cells[(2 * k + pass) * C + c];
+                e.packed = M.packed_dev; e.packed_bwd = M.packed_bwd_dev; e.emb_a = d.embedding_a; e.d_emb_a = M.grad.embedding_a;
+                const long cap = k == 0 ? D.cap_f : D.cap_b, first = k == 0 ? D.N * D.Nc : D.N * D.Sb;
+                e.tape_row0 = (long)c * cap + (pass ? first : 0);
+                e.n_units = k == 0 ? nullptr : reinterpret_cast<const int32_t *>(ws + L.scal) + c;
+            }
+        }
+    }
+    MNR_REQUIRE((int)adam.size() <= 2 * C * 32, "internal: Adam table overflow");
+    long ab = 0;
+    for (AdamTensor &t : adam) { t.block0 = ab; ab += (t.n + 1023) / 1024; }
+    plan->n_pack_jobs = (int)jobs.size(); plan->pack_blocks = pack_blocks;
+    plan->n_adam_tensors = (int)adam.size(); plan->adam_blocks = ab;
+    plan->tables.assign(cfg->t_coarse, cfg->t_coarse + D.Nc);
+    plan->tables.insert(plan->tables.end(), cfg->t_bg_coarse, cfg->t_bg_coarse + D.Sb);
+    plan->tables.insert(plan->tables.end(), cfg->t_fine, cfg->t_fine + D.Nf);
+    plan->tables.insert(plan->tables.end(), cfg->t_bg_fine, cfg->t_bg_fine + D.Sfb);
+    bool ok = true;
+    auto up = [&](size_t off, const void *src, size_t bytes) { ok = ok && hipMemcpyAsync(ws + off, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess; };
+    up(L.tab_cells, cells.data(), cells.size() * sizeof(MlpCellSeg));
+    up(L.tab_pack, jobs.data(), jobs.size() * sizeof(PackJob));
+    up(L.tab_adam, adam.data(), adam.size() * sizeof(AdamTensor));
+    up(L.t_c, plan->tables.data(), D.Nc * 4);
+    up(L.t_bc, plan->tables.data() + D.Nc, D.Sb * 4);
+    up(L.t_f, plan->tables.data() + D.Nc + D.Sb, D.Nf * 4);
+    up(L.t_bf, plan->tables.data() + D.Nc + D.Sb + D.Nf, D.Sfb * 4);
+    // the host vectors above die with this scope: the copies must have left them
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return fail(set_err(MNR_E_LAUNCH, "mnr_step_create: table upload failed: %s", hipGetErrorString(hipGetLastError())));
+    rc = mnr_step_repack(plan, stream);
+    if (rc != MNR_OK) return fail(rc);
+    *out = plan;
+    return MNR_OK;
+}
+
+extern "C" void mnr_step_destroy(mnr_step_plan *p) { delete p; }
+
+extern "C" int mnr_step_profile(mnr_step_plan *p, int n_slots) {
+    MNR_REQUIRE(p && n_slots >= 0 && n_slots <= 4096, "bad arguments to mnr_step_profile");
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->events.clear();
+    p->prof_slots = 0;
+    p->prof_step = 0;
+    for (int i = 0; i < n_slots * MNR_STEP_SPANS * 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipEventCreate failed");
+        p->events.push_back(e);
+    }
+    p->prof_slots = n_slots;
+    return MNR_OK;
+}
+
+extern "C" int mnr_step_kernel_times(mnr_step_plan *p, int slot, float *ms_out) {
+    MNR_REQUIRE(p && ms_out && slot >= 0 && slot < p->prof_slots, "bad arguments to mnr_step_kernel_times");
+    for (int i = 0; i < MNR_STEP_SPANS; ++i) {
+        const hipEvent_t a = p->events[(size_t)(slot * MNR_STEP_SPANS + i) * 2], b = p->events[(size_t)(slot * MNR_STEP_SPANS + i) * 2 + 1];
+        if (hipEventElapsedTime(&ms_out[i], a, b) != hipSuccess) { (void)hipGetLastError(); ms_out[i] = -1.f; }
+    }
+    return MNR_OK;
+}
+
+extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, const mnr_step_randoms *randoms, float lr, int64_t adam_step,
+                              uint64_t seed, int flags, void *stream) {
+    MNR_REQUIRE(p && batches && adam_step >= 1, "bad arguments to mnr_train_step");
+    const StepDims &D = p->D;
+    const StepWs &L = p->L;
+    const int C = (int)D.C;
+    char *ws = p->ws;
+    hipStream_t s = as_stream(stream);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+    for (int c = 0; c < C; ++c) {
+        MNR_REQUIRE(batches[c].rays && batches[c].idx && batches[c].target, "cell %d: NULL batch pointer", c);
+        MNR_REQUIRE(batches[c].idx_is_float == batches[0].idx_is_float, "all cells must pass image indices of the same type");
+    }
+    if (hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(step)");
+    int32_t *scal = I(L.scal);
+    // profiling (mnr_step_profile): span i of this step's slot
+    const long slot = p->prof_slots ? p->prof_step++ % p->prof_slots : -1;
+    auto mark = [&](int span, int end) { if (slot >= 0) (void)hipEventRecord(p->events[(size_t)(slot * MNR_STEP_SPANS + span) * 2 + end], s); };
+    mark(0, 0);
+    // ---- begin ----
+    {
+        BeginArgs ba{};
+        for (int c = 0; c < C; ++c) ba.b[c] = batches[c];
+        hipLaunchKernelGGL(k_step_begin, dim3(C), dim3(1024), 0, s, ba, D.N, p->sp, F(L.rays), reinterpret_cast<uint32_t *>(ws + L.idx), F(L.target),
+                           F(L.far), F(L.last_delta), I(L.bg_slot), I(L.bg_list), F(L.rays_bg), reinterpret_cast<uint32_t *>(ws + L.idx_bg), scal);
+        int rc = check_launch("k_step_begin");
+        if (rc) return rc;
+    }
+    const bool noise = p->cfg.sigma_noise != 0, rnd_u = p->cfg.perturb > 0.f;
+    // ---- coarse samples + random numbers ----
+    {
+        SamplesArgs a{};
+        if (randoms) { for (int c = 0; c < C; ++c) a.inj[c] = randoms[c]; a.has_inj = 1; }
+        a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb;
+        a.perturb = p->cfg.perturb; a.noise = noise ? 1 : 0;
+        a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step_lo = (unsigned)adam_step; a.step_hi = (unsigned)((uint64_t)adam_step >> 32);
+        a.sp = p->sp;
+        a.rays = F(L.rays); a.far = F(L.far); a.rays_bg = F(L.rays_bg); a.t_c = F(L.t_c); a.t_bc = F(L.t_bc); a.scal = scal;
+        a.z_c = F(L.z_c); a.xyz_c = F(L.xyz_c); a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.pts_c = F(L.pts_c); a.dr_c = F(L.dr_c);
+        a.noise_fc = F(L.noise_fc); a.noise_ff = F(L.noise_ff); a.noise_bc = F(L.noise_bc); a.noise_bf = F(L.noise_bf);
+        a.u_f = F(L.u_f); a.u_b = F(L.u_b);
+        const long total = D.C * D.N * (D.Nc + D.Nf);
+        hipLaunchKernelGGL(k_step_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        int rc = check_launch("k_step_samples");
+        if (rc) return rc;
+    }
+    mark(0, 1);
+    // ---- MLP passes: segment descriptions over the cell-major arrays ----
+    const mnr_step_model &M0f = p->models[0], &M0b = p->models[1];
+    const MlpCellSeg *tabs = reinterpret_cast<const MlpCellSeg *>(ws + L.tab_cells);
+    const long capT_f = D.C * D.cap_f, capT_b = D.C * D.cap_b;
+    auto fwd_pass = [&](int pass) -> int {
+        mnr_mlp_io io[2] = {};
+        const long Sf = pass ? D.Nf : D.Nc, Sbb = pass ? D.Sfb : D.Sb;
+        io[0].xyz = F(pass ? L.xyz_f : L.xyz_c); io[0].xyz_stride = 3;
+        io[0].dir = F(L.rays) + 3; io[0].dir_stride = 8;
+        io[0].idx = ws + L.idx; io[0].idx_stride = 1; io[0].idx_is_float = batches[0].idx_is_float;
+        io[0].rows_per_ray = (int32_t)Sf;
+        io[0].sigma_noise = noise ? F(pass ? L.noise_ff : L.noise_fc) : nullptr;
+        io[0].out = F(pass ? L.raw_f : L.raw_c); io[0].out_stride = 4;
+        io[0].n_rows = D.C * D.N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = -1;
+        io[1].xyz = F(pass ? L.pts_f : L.pts_c); io[1].xyz_stride = 4;
+        io[1].dir = F(L.rays_bg) + 3; io[1].dir_stride = 8;
+        io[1].idx = ws + L.idx_bg; io[1].idx_stride = 1; io[1].idx_is_float = batches[0].idx_is_float;
+        io[1].rows_per_ray = (int32_t)Sbb;
+        io[1].sigma_noise = noise ? F(pass ? L.noise_bf : L.noise_bc) : nullptr;
+        io[1].out = F(pass ? L.braw_f : L.braw_c); io[1].out_stride = 4;
+        io[1].n_rows = D.C * D.N * Sbb; io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = -1;
+        mnr_mlp_launch seg[2] = {};
+        seg[0].packed_dev = M0f.packed_dev; seg[0].desc = &M0f.desc; seg[0].io = &io[0];
+        seg[0].tape_dev = F(L.tape_f); seg[0].tape_rows = capT_f; seg[0].tape_row0 = 0;
+        seg[1].packed_dev = M0b.packed_dev; seg[1].desc = &M0b.desc; seg[1].io = &io[1];
+        seg[1].tape_dev = F(L.tape_b); seg[1].tape_rows = capT_b; seg[1].tape_row0 = 0;
+        const CellTable ct[2] = {{tabs + (0 + pass) * C, D.N * Sf}, {tabs + (2 + pass) * C, D.N * Sbb}};
+        return mlp_forward_multi_impl(seg, 2, ct, s);
+    };
+    mark(1, 0);
+    int rc = fwd_pass(0);
+    if (rc) return rc;
+    mark(1, 1);
+    // ---- coarse weights -> fine samples ----
+    mark(2, 0);
+    {
+        MidArgs a{};
+        a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb; a.det = rnd_u ? 0 : 1;
+        a.sp = p->sp;
+        a.rays = F(L.rays); a.rays_bg = F(L.rays_bg); a.last_delta = F(L.last_delta); a.z_c = F(L.z_c); a.raw_c = F(L.raw_c);
+        a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.braw_c = F(L.braw_c); a.u_f = F(L.u_f); a.u_b = F(L.u_b); a.t_f = F(L.t_f); a.t_bf = F(L.t_bf);
+        a.scal = scal;
+        a.z_f = F(L.z_f); a.xyz_f = F(L.xyz_f); a.zb_f = F(L.zb_f); a.pts_f = F(L.pts_f); a.dr_f = F(L.dr_f);
+        const long units = 2 * D.C * D.N;
+        const size_t sh = (size_t)WPB * (4 * D.Nc + 8) * sizeof(float);
+        const dim3 grid((unsigned)((units + WPB - 1) / WPB)), block(64 * WPB);
+        if (D.Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, s, a);
+        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, s, a);
+        rc = check_launch("k_step_mid");
+        if (rc) return rc;
+    }
+    mark(2, 1);
+    mark(3, 0);
+    rc = fwd_pass(1);
+    if (rc) return rc;
+    mark(3, 1);
+    // ---- merge, compositing, blend, loss and their adjoints ----
+    mark(4, 0);
+    {
+        TailArgs a{};
+        a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb;
+        a.z_c = F(L.z_c); a.z_f = F(L.z_f); a.raw_c = F(L.raw_c); a.raw_f = F(L.raw_f); a.zb_c = F(L.zb_c); a.zb_f = F(L.zb_f);
+        a.braw_c = F(L.braw_c); a.braw_f = F(L.braw_f); a.last_delta = F(L.last_delta); a.target = F(L.target); a.slot = I(L.bg_slot);
+        a.draw_c = F(L.draw_c); a.draw_f = F(L.draw_f); a.bdraw_c = F(L.bdraw_c); a.bdraw_f = F(L.bdraw_f);
+        a.rgb = F(L.rgb); a.depth_var = F(L.depth_var); a.bg_lambda = F(L.bg_lambda); a.loss = F(L.loss);
+        const long rays = D.C * D.N;
+        const size_t sh = (size_t)WPB * 3 * (D.Nc + D.Nf) * sizeof(float);
+        const dim3 grid((unsigned)((rays + WPB - 1) / WPB)), block(64 * WPB);
+        if (D.Nc == 64) hipLaunchKernelGGL((k_step_tail<3, 2>), grid, block, sh, s, a);
+        else hipLaunchKernelGGL((k_step_tail<12, 6>), grid, block, sh, s, a);
+        rc = check_launch("k_step_tail");
+        if (rc) return rc;
+    }
+    mark(4, 1);
+    // ---- data-gradient chains: fg coarse, fg fine, bg coarse, bg fine (all cells each) ----
+    mark(5, 0);
+    {
+        mnr_mlp_grad_io g[4] = {};
+        mnr_mlp_grad_launch seg[4] = {};
+        CellTable ct[4];
+        for (int k = 0; k < 2; ++k)
+            for (int pass = 0; pass < 2; ++pass) {
+                const int i = 2 * k + pass;
+                const long S = k == 0 ? (pass ? D.Nf : D.Nc) : (pass ? D.Sfb : D.Sb);
+                const mnr_step_model &M = p->models[k];
+                g[i].tape = F(k ? L.tape_b : L.tape_f); g[i].gtape = F(k ? L.gtape_b : L.gtape_f);
+                g[i].tape_rows = k ? capT_b : capT_f; g[i].tape_row0 = 0;
+                g[i].d_out = F(k ? (pass ? L.bdraw_f : L.bdraw_c) : (pass ? L.draw_f : L.draw_c)); g[i].d_out_stride = 4;
+                g[i].out = F(k ? (pass ? L.braw_f : L.braw_c) : (pass ? L.raw_f : L.raw_c)); g[i].out_stride = 4;
+                g[i].dheads = F(k ? L.dheads_b : L.dheads_f);
+                g[i].idx = ws + (k ? L.idx_bg : L.idx); g[i].idx_stride = 1; g[i].idx_is_float = batches[0].idx_is_float;
+                g[i].rows_per_ray = (int32_t)S; g[i].n_rows = D.C * D.N * S; g[i].rows_per_unit = (int32_t)S;
+                g[i].grad = M.grad;
+                seg[i].packed_fwd_dev = M.packed_dev; seg[i].packed_bwd_dev = M.packed_bwd_dev; seg[i].desc = &M.desc; seg[i].io = &g[i];
+                ct[i] = CellTable{tabs + i * C, D.N * S};
+            }
+        rc = mlp_backward_chain_multi_impl(seg, 4, ct, s);
+        if (rc) return rc;
+    }
+    mark(5, 1);
+    // ---- head gradients: per cell one dense foreground job + two device-counted background jobs ----
+    mark(6, 0);
+    {
+        const TapeLayout tlf = tape_layout(ArchDims{M0f.desc.xyz_dim, M0f.desc.pos_xyz_dim, M0f.desc.pos_dir_dim, M0f.desc.layers, M0f.desc.skip_mask,
+                                                    M0f.desc.layer_dim, M0f.desc.appearance_dim, M0f.desc.rgb_dim, M0f.desc.mfma_tile});
+        const TapeLayout tlb = tape_layout(ArchDims{M0b.desc.xyz_dim, M0b.desc.pos_xyz_dim, M0b.desc.pos_dir_dim, M0b.desc.layers, M0b.desc.skip_mask,
+                                                    M0b.desc.layer_dim, M0b.desc.appearance_dim, M0b.desc.rgb_dim, M0b.desc.mfma_tile});
+        std::vector<HeadJob> jobs;
+        for (int c = 0; c < C; ++c) {
+            const mnr_model_grads &Gf = p->models[2 * c].grad, &Gb = p->models[2 * c + 1].grad;
+            const long bf = (D.cap_f + 767) / 768;
+            jobs.push_back(HeadJob{F(L.dheads_f), F(L.tape_f) + (long)tlf.act_off[M0f.desc.layers - 1] * capT_f, F(L.tape_f) + (long)tlf.dact_off * capT_f,
+                                   c * D.cap_f, D.cap_f, nullptr, 0, (int)(bf > 256 ? 256 : bf), Gf.sigma_w, Gf.sigma_b, Gf.rgb_w, Gf.rgb_b});
+            for (int pass = 0; pass < 2; ++pass)
+                jobs.push_back(HeadJob{F(L.dheads_b), F(L.tape_b) + (long)tlb.act_off[M0b.desc.layers - 1] * capT_b, F(L.tape_b) + (long)tlb.dact_off * capT_b,
+                                       c * D.cap_b + (pass ? D.N * D.Sb : 0), D.N * (pass ? D.Sfb : D.Sb), scal + c, (int)(pass ? D.Sfb : D.Sb), 48,
+                                       Gb.sigma_w, Gb.sigma_b, Gb.rgb_w, Gb.rgb_b});
+        }
+        for (size_t i = 0; i < jobs.size() && rc == MNR_OK; i += HEAD_MAX_JOBS)
+            rc = head_grads_jobs(jobs.data() + i, (int)std::min<size_t>(HEAD_MAX_JOBS, jobs.size() - i), 256, s);
+        if (rc) return rc;
+    }
+    mark(6, 1);
+    // ---- weight gradients, cell by cell (persistent launches: no tail to share between cells) ----
+    mark(7, 0);
+    for (int c = 0; c < C; ++c) {
+        mnr_wgrad_region rg[2] = {};
+        const mnr_step_model &Mf = p->models[2 * c], &Mb = p->models[2 * c + 1];
+        rg[0].desc = &Mf.desc; rg[0].tape = F(L.tape_f); rg[0].gtape = F(L.gtape_f); rg[0].tape_rows = capT_f;
+        rg[0].n_ranges = 1; rg[0].row0[0] = c * D.cap_f; rg[0].n_rows[0] = D.cap_f; rg[0].grad = Mf.grad;
+        rg[1].desc = &Mb.desc; rg[1].tape = F(L.tape_b); rg[1].gtape = F(L.gtape_b); rg[1].tape_rows = capT_b;
+        rg[1].n_ranges = 2;
+        rg[1].row0[0] = c * D.cap_b; rg[1].n_rows[0] = D.N * D.Sb; rg[1].n_units_dev[0] = scal + c; rg[1].rows_per_unit[0] = (int32_t)D.Sb;
+        rg[1].row0[1] = c * D.cap_b + D.N * D.Sb; rg[1].n_rows[1] = D.N * D.Sfb; rg[1].n_units_dev[1] = scal + c; rg[1].rows_per_unit[1] = (int32_t)D.Sfb;
+        rg[1].grad = Mb.grad;
+        rc = wgrad_regions_launch(rg, 2, reinterpret_cast<int32_t *>(ws + L.wcount + (size_t)c * 256),
+                                  reinterpret_cast<int32_t *>(ws + L.ep_job + (size_t)c * wgrad_ep_job_bytes()), F(L.slab), s);
+        if (rc) return rc;
+    }
+    mark(7, 1);
+    if (flags & MNR_STEP_NO_OPTIMIZER) return MNR_OK;
+    // ---- Adam (torch.optim.Adam defaults of runner.py:169-171) + re-pack ----
+    mark(8, 0);
+    {
+        const double b1 = p->cfg.adam_beta1, b2 = p->cfg.adam_beta2;
+        const double bc1 = 1.0 - pow(b1, (double)adam_step), bc2 = 1.0 - pow(b2, (double)adam_step);
+        hipLaunchKernelGGL(k_step_adam, dim3((unsigned)p->adam_blocks), dim3(256), 0, s, reinterpret_cast<const AdamTensor *>(ws + L.tab_adam),
+                           p->n_adam_tensors, (float)b1, (float)b2, p->cfg.adam_eps, (float)((double)lr / bc1), (float)sqrt(bc2));
+        rc = check_launch("k_step_adam");
+        if (rc) return rc;
+    }
+    rc = mnr_step_repack(p, stream);
+    mark(8, 1);
+    return rc;
+}

@@ -26,6 +26,7 @@
 #include <initializer_list>
 
 #include "lds_asm.h"
+#include "step_internal.h"
 
 namespace mnr {
 
@@ -579,7 +580,7 @@ static double wgrad_tile_cost(int shape) {
 }
 
 // shared tail of the two entry points: reduce-block table, workspace carving, the two launches
-static int launch_wgrad2(WArgs &wa, int nj, void *workspace_dev, hipStream_t s, int family) {
+static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev, bool zero_counters, hipStream_t s, int family) {
     wa.njobs = nj;
     {
         const int cap = (int)env_d("MNR_WGRAD_MAX_EPISODES", (double)W2_MAX_EPISODES);
@@ -591,10 +592,9 @@ static int launch_wgrad2(WArgs &wa, int nj, void *workspace_dev, hipStream_t s, 
         wa.job[i].red_block0 = red_blocks;
         red_blocks += si.M * si.NP / 4 / 256 + (wa.job[i].db ? 1 : 0);
     }
-    char *ws = reinterpret_cast<char *>(workspace_dev);
-    wa.counters = reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS);
-    wa.ep_job = reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB);
-    wa.slab = reinterpret_cast<float *>(ws + W2Workspace::SLAB);
+    wa.counters = counters_dev;
+    wa.ep_job = ep_job_dev;
+    wa.slab = slab_dev;
     wa.prof = getenv("MNR_WGRAD_PROF") ? reinterpret_cast<long long *>(wa.slab + (size_t)(W2_MAX_EPISODES - 1) * W2_EP_FLOATS) : nullptr;   // diagnostics: borrows the last slab slot
     size_t lds = 0;
     for (int i = 0; i < nj; ++i) {
@@ -609,7 +609,7 @@ static int launch_wgrad2(WArgs &wa, int nj, void *workspace_dev, hipStream_t s, 
         }
         lds_enabled = true;
     }
-    if (hipMemsetAsync(wa.counters, 0, 256, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(wgrad counters)");
+    if (zero_counters && hipMemsetAsync(wa.counters, 0, 256, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(wgrad counters)");
     const int grid = (int)env_d("MNR_WGRAD_WGS", 256.0);
     if (family == 0) hipLaunchKernelGGL(k_wgrad2<0>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
     else hipLaunchKernelGGL(k_wgrad2<1>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
@@ -625,11 +625,9 @@ using namespace mnr;
 
 extern "C" size_t mnr_wgrad_workspace_bytes(void) { return W2Workspace::BYTES; }
 
-extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev,
-                                              size_t workspace_bytes, void *stream) {
+static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,
+                              bool zero_counters, hipStream_t s) {
     MNR_REQUIRE(regions && n_regions >= 1 && n_regions <= W2_MAX_REGIONS, "1..%d weight-gradient regions per launch", W2_MAX_REGIONS);
-    MNR_REQUIRE(workspace_dev && workspace_bytes >= W2Workspace::BYTES, "workspace missing or smaller than mnr_wgrad_workspace_bytes()");
-    hipStream_t s = as_stream(stream);
     WArgs wa{};
     int nj = 0;
     long rows_bound = 0;
@@ -707,8 +705,25 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
         MNR_REQUIRE(!err, "weight-gradient job table: unsupported layer shape or too many jobs (region %d)", ri);
     }
     if (rows_bound == 0) return MNR_OK;
-    return launch_wgrad2(wa, nj, workspace_dev, s, 0);
+    return launch_wgrad2(wa, nj, counters_dev, ep_job_dev, slab_dev, zero_counters, s, 0);
 }
+
+extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev,
+                                              size_t workspace_bytes, void *stream) {
+    MNR_REQUIRE(workspace_dev && workspace_bytes >= W2Workspace::BYTES, "workspace missing or smaller than mnr_wgrad_workspace_bytes()");
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    return wgrad_regions_impl(regions, n_regions, reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS),
+                              reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB), reinterpret_cast<float *>(ws + W2Workspace::SLAB), true,
+                              as_stream(stream));
+}
+
+// the step's form (csrc/step.hip): control words placed by the caller and already zeroed by its one memset
+int mnr::wgrad_regions_launch(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,
+                              hipStream_t s) {
+    return wgrad_regions_impl(regions, n_regions, counters_dev, ep_job_dev, slab_dev, false, s);
+}
+size_t mnr::wgrad_ep_job_bytes() { return (size_t)W2_MAX_EPISODES * 4; }
+size_t mnr::wgrad_slab_bytes() { return (size_t)W2_MAX_EPISODES * W2_EP_FLOATS * 4; }
 
 extern "C" int mnr_wgrad_jobs(const mnr_wgrad_job *jobs, int n_jobs, int64_t rows, void *workspace_dev, size_t workspace_bytes,
                               void *stream) {
@@ -747,5 +762,7 @@ extern "C" int mnr_wgrad_jobs(const mnr_wgrad_job *jobs, int n_jobs, int64_t row
         const int tpi = (int)(item_tiles * cost_big / wgrad_tile_cost(shape) + 0.5);
         J.tiles_per_item = tpi < 1 ? 1 : tpi;
     }
-    return launch_wgrad2(wa, n_jobs, workspace_dev, as_stream(stream), 1);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    return launch_wgrad2(wa, n_jobs, reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS), reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB),
+                         reinterpret_cast<float *>(ws + W2Workspace::SLAB), true, as_stream(stream), 1);
 }

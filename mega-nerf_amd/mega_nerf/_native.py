@@ -123,6 +123,44 @@ class CompositeGradIO(C.Structure):
                 ('S', C.c_int32), ('d_rgb', C.c_void_p), ('d_bg_lambda', C.c_void_p), ('d_raw', C.c_void_p)]
 
 
+MNR_STEP_MAX_CELLS = 16
+MNR_STEP_NO_OPTIMIZER = 1
+MNR_STEP_SPANS = 9
+STEP_SPAN_NAMES = ('samples', 'fwd_c', 'mid', 'fwd_f', 'tail', 'bwd', 'head_grads', 'wgrad', 'adam_pack')
+
+
+class StepModel(C.Structure):
+    """struct mnr_step_model"""
+    _fields_ = [('desc', ModelDesc), ('grad', ModelGrads), ('adam_m', ModelGrads), ('adam_v', ModelGrads),
+                ('packed_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p)]
+
+
+class StepCfg(C.Structure):
+    """struct mnr_step_cfg"""
+    _fields_ = [('n_cells', C.c_int32), ('n_rays', C.c_int32), ('coarse_samples', C.c_int32), ('fine_samples', C.c_int32),
+                ('perturb', C.c_float), ('sigma_noise', C.c_int32), ('sphere_center', C.c_float * 3), ('sphere_radius', C.c_float * 3),
+                ('grad_floats_per_cell', C.c_int64), ('adam_beta1', C.c_float), ('adam_beta2', C.c_float), ('adam_eps', C.c_float),
+                ('t_coarse', c_float_p), ('t_bg_coarse', c_float_p), ('t_fine', c_float_p), ('t_bg_fine', c_float_p)]
+
+
+class StepLayout(C.Structure):
+    """struct mnr_step_layout"""
+    _fields_ = [('workspace_bytes', C.c_size_t), ('grad_offset', C.c_size_t), ('grad_stride', C.c_size_t), ('loss_offset', C.c_size_t),
+                ('rgb_offset', C.c_size_t), ('depth_var_offset', C.c_size_t), ('bg_lambda_offset', C.c_size_t),
+                ('n_bg_offset', C.c_size_t), ('err_offset', C.c_size_t)]
+
+
+class StepBatch(C.Structure):
+    """struct mnr_step_batch"""
+    _fields_ = [('rays', C.c_void_p), ('idx', C.c_void_p), ('idx_is_float', C.c_int32), ('target', C.c_void_p)]
+
+
+class StepRandoms(C.Structure):
+    """struct mnr_step_randoms"""
+    _fields_ = [('fg_perturb', C.c_void_p), ('bg_perturb', C.c_void_p), ('fg_noise_coarse', C.c_void_p), ('fg_noise_fine', C.c_void_p),
+                ('bg_noise_coarse', C.c_void_p), ('bg_noise_fine', C.c_void_p), ('fg_u', C.c_void_p), ('bg_u', C.c_void_p)]
+
+
 EXPORTS = [
     'mnr_version', 'mnr_last_error', 'mnr_device_available', 'mnr_ray_directions', 'mnr_get_rays',
     'mnr_packed_model_bytes', 'mnr_pack_model', 'mnr_layout_src_col', 'mnr_layout_num_steps', 'mnr_layout_parts',
@@ -135,6 +173,7 @@ EXPORTS = [
     'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
+    'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -242,6 +281,15 @@ def lib() -> C.CDLL:
                                            C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib.mnr_cluster_min_ratios.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_float, C.c_void_p]
+        _lib.mnr_step_query.argtypes = [C.POINTER(StepCfg), C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.POINTER(StepLayout)]
+        _lib.mnr_step_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(StepCfg), C.POINTER(StepModel), C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.mnr_step_destroy.argtypes = [C.c_void_p]
+        _lib.mnr_step_destroy.restype = None
+        _lib.mnr_step_repack.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
+        _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
+        _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_float, C.c_int64, C.c_uint64, C.c_int,
+                                        C.c_void_p]
     return _lib
 
 

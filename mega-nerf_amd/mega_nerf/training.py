@@ -714,6 +714,162 @@ def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     return results, aux.get('n_bg'), aux.get('err')
 
 
+def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int) -> bool:
+    """True if mnr_train_step (csrc/step.hip) covers this configuration: the default foreground / background architectures,
+    no cascade, 64 + 128 or 256 + 512 samples per ray, background rows of a batch filling whole 64-row tiles."""
+    import os
+    from mega_nerf.models.nerf import NeRF
+    if os.environ.get('MNR_NO_FUSED_STEP') or bg_nerf is None or not _fast_path_ok(nerf, bg_nerf, hparams):
+        return False
+    if not (isinstance(nerf, NeRF) and isinstance(bg_nerf, NeRF) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
+        return False
+    if nerf.xyz_dim != 3 or bg_nerf.xyz_dim != 4 or hparams.container_path is not None or hparams.train_mega_nerf is not None:
+        return False
+    if (hparams.coarse_samples, hparams.fine_samples) not in ((64, 128), (256, 512)):
+        return False
+    return (n_rays * (hparams.coarse_samples // 2)) % 64 == 0 and (n_rays * (hparams.fine_samples // 2)) % 64 == 0
+
+
+class FusedTrainStep:
+    """The reference trainer's iteration (runner.py:244-277: render_rays with the training flags, mse_loss, backward, Adam on the
+    foreground and the background model, ExponentialLR) for ONE OR SEVERAL independent cells a rank owns, as one call of
+    ``mnr_train_step``: 13 launches + one memset, no torch kernels, no host synchronisation.  Every cell keeps its own models,
+    optimiser moments and batch (parscripts/run_8.txt: one trainer per cell).  After a call ``param.grad`` of every model
+    parameter is that step's gradient (a view into the step's workspace)."""
+
+    def __init__(self, cells, hparams: Namespace, sphere_center, sphere_radius, n_rays: int, lr: float = 5e-4,
+                 lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None):
+        lib = N.lib()
+        self.cells = [(f, b) for f, b in cells]
+        assert 1 <= len(self.cells) <= N.MNR_STEP_MAX_CELLS
+        f0, b0 = self.cells[0]
+        dev = next(f0.parameters()).device
+        self.dev, self.hparams, self.n_rays = dev, hparams, n_rays
+        self.lr0, self.gamma = lr, lr_decay_factor ** (1 / train_iterations)
+        self.step_count = 0
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xffffffffffffffff
+        c, r = R._host_vec(sphere_center), R._host_vec(sphere_radius)
+        Nc, Nf = hparams.coarse_samples, hparams.fine_samples
+        self._tables = [R.linspace01(n, torch.device('cpu')).numpy().astype('float32').copy() for n in (Nc, Nc // 2, Nf, Nf // 2)]
+        cfg = N.StepCfg()
+        cfg.n_cells, cfg.n_rays, cfg.coarse_samples, cfg.fine_samples = len(self.cells), n_rays, Nc, Nf
+        cfg.perturb = float(hparams.perturb) if f0.training else 0.0
+        cfg.sigma_noise = 1 if f0.training else 0
+        for i in range(3):
+            cfg.sphere_center[i], cfg.sphere_radius[i] = c[i], r[i]
+        cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
+        cfg.t_coarse, cfg.t_bg_coarse, cfg.t_fine, cfg.t_bg_fine = [t.ctypes.data_as(N.c_float_p) for t in self._tables]
+        # gradient area of a cell: every parameter of its fg model, then of its bg model, each padded to 16 bytes
+        def sizes(m):
+            return [(k, p, (p.numel() + 3) // 4 * 4) for k, p in m.named_parameters()]
+        per_cell = sum(n for m in (f0, b0) for _, _, n in sizes(m))
+        cfg.grad_floats_per_cell = per_cell
+        lay = N.StepLayout()
+        N.check(lib.mnr_step_query(C.byref(cfg), C.byref(f0.model_desc()), C.byref(b0.model_desc()), C.byref(lay)))
+        self.workspace = torch.empty(lay.workspace_bytes, dtype=torch.uint8, device=dev)
+        self.layout = lay
+        wsf = self.workspace.view(torch.float32)
+        self.adam_m = torch.zeros(len(self.cells), per_cell, device=dev)
+        self.adam_v = torch.zeros(len(self.cells), per_cell, device=dev)
+        self._packed = []
+        models = (N.StepModel * (2 * len(self.cells)))()
+        self.grad_views = []
+        for ci, (f, b) in enumerate(self.cells):
+            g0 = (lay.grad_offset + ci * lay.grad_stride) // 4
+            o = 0
+            for k, m in enumerate((f, b)):
+                N.require_device(next(m.parameters()), 'NeRF parameter')
+                sm = models[2 * ci + k]
+                sm.desc = m.model_desc()
+                views = [{}, {}, {}]
+                for name, p, n in sizes(m):
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise N.NativeError('NeRF parameters must be contiguous float32')
+                    views[0][name] = wsf[g0 + o:g0 + o + p.numel()].view(p.shape)
+                    views[1][name] = self.adam_m[ci, o:o + p.numel()].view(p.shape)
+                    views[2][name] = self.adam_v[ci, o:o + p.numel()].view(p.shape)
+                    o += n
+                sm.grad, sm.adam_m, sm.adam_v = m.grad_struct(views[0]), m.grad_struct(views[1]), m.grad_struct(views[2])
+                pk = torch.empty(lib.mnr_packed_model_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                pb = torch.empty(lib.mnr_packed_bwd_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                sm.packed_dev, sm.packed_bwd_dev = pk.data_ptr(), pb.data_ptr()
+                self._packed.append((pk, pb))
+                self.grad_views.append(views[0])
+        self._models = models
+        plan = C.c_void_p()
+        N.check(lib.mnr_step_create(C.byref(plan), C.byref(cfg), models, self.workspace.data_ptr(), self.workspace.numel(), N.stream_ptr()))
+        self._plan = plan
+        nc = len(self.cells)
+        self.loss = wsf[lay.loss_offset // 4:lay.loss_offset // 4 + nc]
+        self.rgb = wsf[lay.rgb_offset // 4:lay.rgb_offset // 4 + nc * n_rays * 3].view(nc, n_rays, 3)
+        self.depth_variance = wsf[lay.depth_var_offset // 4:lay.depth_var_offset // 4 + nc * n_rays].view(nc, n_rays)
+        self.bg_lambda = wsf[lay.bg_lambda_offset // 4:lay.bg_lambda_offset // 4 + nc * n_rays].view(nc, n_rays)
+        wsi = self.workspace.view(torch.int32)
+        self.n_bg = wsi[lay.n_bg_offset // 4:lay.n_bg_offset // 4 + nc]
+        self.err = wsi[lay.err_offset // 4:lay.err_offset // 4 + nc]
+
+    def __del__(self):
+        plan = getattr(self, '_plan', None)
+        if plan is not None and plan.value:
+            N.lib().mnr_step_destroy(plan)
+            self._plan = None
+
+    def profile(self, n_slots: int) -> None:
+        """Record HIP events around every kernel group of the next steps (slot = step index mod n_slots); 0 = off."""
+        N.check(N.lib().mnr_step_profile(self._plan, n_slots))
+
+    def kernel_times(self, slot: int) -> dict:
+        """{span name: ms} of a finished profiled step (synchronise first)."""
+        ms = (C.c_float * N.MNR_STEP_SPANS)()
+        N.check(N.lib().mnr_step_kernel_times(self._plan, slot, ms))
+        return dict(zip(N.STEP_SPAN_NAMES, [float(v) for v in ms]))
+
+    def repack(self) -> None:
+        """After the parameters were changed from outside (checkpoint load): refresh the step's weight images."""
+        N.check(N.lib().mnr_step_repack(self._plan, N.stream_ptr()))
+
+    def __call__(self, batches, _randoms=None, optimize: bool = True):
+        """batches: one (rays [n_rays, 8], image_indices [n_rays], rgbs [n_rays, 3]) per cell.  Returns (loss [cells], n_bg
+        [cells], err [cells]) as device tensors (views of the workspace: valid until the next call)."""
+        nc = len(self.cells)
+        assert len(batches) == nc
+        arr = (N.StepBatch * nc)()
+        keep = []
+        for i, (rays, idx, rgbs) in enumerate(batches):
+            N.require_device(rays, 'rays')
+            rays, rgbs = rays.contiguous().float(), rgbs.contiguous().float()
+            if idx.dtype not in (torch.float32, torch.int32):
+                idx = idx.float()
+            idx = idx.contiguous()
+            if rays.shape != (self.n_rays, 8) or rgbs.shape != (self.n_rays, 3) or idx.numel() != self.n_rays:
+                raise N.NativeError('FusedTrainStep was planned for batches of {} rays'.format(self.n_rays))
+            keep.append((rays, idx, rgbs))
+            arr[i].rays, arr[i].idx, arr[i].target = rays.data_ptr(), idx.data_ptr(), rgbs.data_ptr()
+            arr[i].idx_is_float = 1 if idx.dtype == torch.float32 else 0
+        inj = None
+        if _randoms is not None:
+            inj = (N.StepRandoms * nc)()
+            for i, rd in enumerate(_randoms):
+                for k in ('fg_perturb', 'bg_perturb', 'fg_noise_coarse', 'fg_noise_fine', 'bg_noise_coarse', 'bg_noise_fine', 'fg_u', 'bg_u'):
+                    if rd is not None and rd.get(k) is not None:
+                        t = rd[k].contiguous().float()
+                        keep.append(t)
+                        setattr(inj[i], k, t.data_ptr())
+        self.step_count += 1
+        lr = self.lr0 * self.gamma ** (self.step_count - 1)
+        N.check(N.lib().mnr_train_step(self._plan, arr, inj, lr, self.step_count, self.seed, 0 if optimize else N.MNR_STEP_NO_OPTIMIZER,
+                                       N.stream_ptr()))
+        self._keep = keep                    # inputs stay alive until the enqueued step has read them (next call at the latest)
+        for ci, (f, b) in enumerate(self.cells):
+            for k, m in enumerate((f, b)):
+                gv = self.grad_views[2 * ci + k]
+                for name, p in m.named_parameters():
+                    p.grad = gv[name]
+                if optimize:
+                    m.weights_changed()     # the parameters moved without a version bump: NeRF.packed()'s own cache is stale
+        return self.loss, self.n_bg, self.err
+
+
 class TrainStep:
     """One optimisation step of the reference trainer (runner.py:244-277, fp32): render -> MSE -> backward ->
     Adam on fg and bg -> LR decay.  No host synchronisation inside the step."""
@@ -722,6 +878,7 @@ class TrainStep:
                  lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000):
         self.nerf, self.bg_nerf, self.hparams = nerf, bg_nerf, hparams
         self.sc, self.sr = sphere_center, sphere_radius
+        self._fused, self._lr, self._decay, self._iters = None, lr, lr_decay_factor, train_iterations
         # same update rule as runner.py:169-171 (Adam, default betas / eps); ``fused`` = torch's single-launch multi-tensor
         # implementation (the default "foreach" form is ~6 launches of ~20 us per optimiser on this GPU)
         import os
@@ -733,6 +890,12 @@ class TrainStep:
         self.scheds = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=gamma) for o in self.opts]
 
     def __call__(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
+        if self._fused is None and image_indices is not None and fused_step_supported(self.nerf, self.bg_nerf, self.hparams, rays.shape[0]):
+            self._fused = FusedTrainStep([(self.nerf, self.bg_nerf)], self.hparams, self.sc, self.sr, rays.shape[0], self._lr,
+                                         self._decay, self._iters)
+        if self._fused is not None and rays.shape[0] == self._fused.n_rays and image_indices is not None:
+            loss, n_bg, err = self._fused([(rays, image_indices, rgbs)])
+            return loss[0], n_bg[0:1], err[0:1]
         for o in self.opts:
             o.zero_grad(set_to_none=True)
         results, n_bg, err = render_rays_train(self.nerf, self.bg_nerf, rays, image_indices, self.hparams, self.sc, self.sr,

@@ -1,0 +1,181 @@
+"""mnr_train_step (csrc/step.hip): the whole training iteration of one or several cells as one C call -- against the
+stage-by-stage path (the autograd node of mega_nerf/training.py, itself pinned to the reference's outputs and gradients), against
+the reference's own recorded gradients, and for the independence of the cells that share its launches."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from test_gpu_parity import DEV, T, check_gradients_against_reference, native_models
+from test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _randoms_of(g):
+    return {k[4:]: T(v).reshape(-1) if 'noise' in k else T(v) for k, v in g.items() if k.startswith('rnd_')}
+
+
+def _grads(models):
+    return {'%s.%s' % (t, k): p.grad.detach().cpu().numpy().copy() for t, m in models for k, p in m.named_parameters()}
+
+
+def test_fused_step_equals_the_stagewise_path_and_the_reference():
+    """render_fgbg_train (the reference's captured random draws): loss, rgb_fine, depth variance, bg_lambda and every parameter
+    gradient of ONE mnr_train_step call against (i) the stage-by-stage path on the same random numbers -- same kernels for the
+    MLP, restated kernels for the ray stages: equal up to the summation order of the atomically accumulated head / embedding
+    gradients -- and (ii) the reference's own outputs and gradients."""
+    from mega_nerf.rendering import render_rays
+    from mega_nerf.training import FusedTrainStep, fused_step_supported
+    name = 'render_fgbg_train'
+    g = load(name)
+    s = common.SCENE
+    rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    # (i) stage by stage
+    hp, nerf, bg_nerf = native_models(name)
+    hpn = Namespace(**vars(hp))
+    res, _ = render_rays(nerf, bg_nerf, rays, idx, hpn, sc, sr, False, True, False, _randoms=_randoms_of(g))
+    loss = torch.nn.functional.mse_loss(res['rgb_fine'], tgt)
+    loss.backward()
+    ref = _grads((('fg', nerf), ('bg', bg_nerf)))
+    ref_out = {k: v.detach().cpu().numpy() for k, v in res.items()}
+    # (ii) one call
+    hp, nerf2, bg2 = native_models(name)
+    assert fused_step_supported(nerf2, bg2, hpn, rays.shape[0])
+    step = FusedTrainStep([(nerf2, bg2)], hpn, sc, sr, rays.shape[0])
+    l2, n_bg, err = step([(rays, idx, tgt)], _randoms=[_randoms_of(g)], optimize=False)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0 and int(n_bg[0]) > 0
+    np.testing.assert_allclose(float(l2[0]), float(loss.detach()), rtol=2e-6)
+    np.testing.assert_allclose(float(l2[0]), float(g['loss']), rtol=1e-4)
+    np.testing.assert_array_equal(step.rgb[0].cpu().numpy(), ref_out['rgb_fine'])
+    np.testing.assert_array_equal(step.depth_variance[0].cpu().numpy(), ref_out['depth_variance_fine'])
+    np.testing.assert_array_equal(step.bg_lambda[0].cpu().numpy(), ref_out['bg_lambda_fine'])
+    got = _grads((('fg', nerf2), ('bg', bg2)))
+    worst = {k: float(np.abs(got[k] - ref[k]).max()) / max(float(np.abs(ref[k]).max()), 1e-30) for k in ref}
+    print({k: '%.1e' % v for k, v in worst.items()})
+    assert max(worst.values()) < 2e-5, {k: v for k, v in worst.items() if v >= 2e-5}
+    check_gradients_against_reference(g, (('fg', nerf2), ('bg', bg2)))
+
+
+def _cell(seed, n_rays):
+    """A cell of the benchmark's kind: default fg + bg models with their own weights, their own batch."""
+    from oracle import nerf_oracle as O
+    from test_gpu_parity import native_nerf
+    s = common.SCENE
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128)
+    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    fg = native_nerf(fcfg, common.make_weights(fcfg, s['appearance_count'], seed)).train()
+    bg = native_nerf(bcfg, common.make_weights(bcfg, s['appearance_count'], seed + 500)).train()
+    d = O.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True)
+    rays_all = O.get_rays(d, s['c2w'], s['near'], s['far'], s['ray_altitude_range']).reshape(-1, 8)
+    rays, idx = common.pick_rays(rays_all, n_rays, seed)
+    tgt = np.random.default_rng(seed).uniform(0, 1, (n_rays, 3)).astype(f32)
+    return hp, fg, bg, (T(rays), T(idx.astype(np.int32)), T(tgt))
+
+
+def test_cells_sharing_a_step_are_independent():
+    """Three cells (own weights, own batches, own optimiser moments) stepped by ONE plan -- their rows side by side in every MLP
+    launch -- against the same cells stepped one plan each (cell c of a plan draws its random numbers with key seed + c, so a
+    lone plan seeded seed + c sees the same numbers): per-cell loss, rendered colours and gradients of the first step agree --
+    colours exactly, gradients to the summation order of the atomics and of the weight-gradient partials -- and so do the weights
+    after three Adam steps (parscripts/run_8.txt: independent trainers)."""
+    from mega_nerf.training import FusedTrainStep
+    s = common.SCENE
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    n_rays, seeds = 128, (11, 12, 13)
+
+    def run(groups):
+        cells = [_cell(sd, n_rays) for sd in seeds]
+        hpn = Namespace(**vars(cells[0][0]))
+        first = {}
+        for grp in groups:
+            step = FusedTrainStep([(cells[i][1], cells[i][2]) for i in grp], hpn, sc, sr, n_rays, seed=77 + grp[0])
+            for it in range(3):
+                loss, n_bg, err = step([cells[i][3] for i in grp])
+                if it == 0:
+                    torch.cuda.synchronize()
+                    assert int(err.max()) == 0 and int(n_bg.min()) > 0
+                    for j, i in enumerate(grp):
+                        first[i] = (float(loss[j]), step.rgb[j].cpu().numpy().copy(),
+                                    {'%d.%s' % (k, n): v.cpu().numpy().copy() for k in range(2) for n, v in step.grad_views[2 * j + k].items()})
+        torch.cuda.synchronize()
+        return first, [{'%d.%s' % (q, k): p.detach().cpu().numpy().copy() for q, m in enumerate((c[1], c[2])) for k, p in m.named_parameters()}
+                       for c in cells]
+
+    (a, wa), (b, wb) = run([(0, 1, 2)]), run([(0,), (1,), (2,)])
+    for i in range(len(seeds)):
+        np.testing.assert_allclose(a[i][0], b[i][0], rtol=2e-6)
+        np.testing.assert_array_equal(a[i][1], b[i][1])
+        for k in a[i][2]:
+            sc_ = max(float(np.abs(b[i][2][k]).max()), 1e-30)
+            assert float(np.abs(a[i][2][k] - b[i][2][k]).max()) / sc_ < 2e-5, (i, k)
+        for k in wa[i]:
+            # three Adam steps move a weight by <= 3 lr; two summation orders of a noise-level gradient may disagree on its sign
+            assert float(np.abs(wa[i][k] - wb[i][k]).max()) <= 3 * 5e-4 * 2 + 1e-6, (i, k)
+            assert float(np.abs(wa[i][k] - wb[i][k]).mean()) <= 2e-5, (i, k)
+
+
+def test_fused_adam_equals_torch_adam():
+    """Six optimisation steps of the fused step (its own Adam kernel + ExponentialLR, re-pack) against the reference-style loop
+    (render_rays, mse_loss, backward, torch.optim.Adam.step, runner.py:244-277) on eval-mode models (deterministic render):
+    same loss trajectory, same final weights."""
+    from mega_nerf.rendering import render_rays
+    from mega_nerf.training import FusedTrainStep
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    hp, nerf, bg_nerf = native_models('render_fgbg_train')
+    hpn = Namespace(**vars(hp))
+    nerf.eval(), bg_nerf.eval()
+    step = FusedTrainStep([(nerf, bg_nerf)], hpn, sc, sr, rays.shape[0])
+    fused = [float(step([(rays, idx, tgt)])[0][0]) for _ in range(6)]
+    hp, n2, b2 = native_models('render_fgbg_train')
+    n2.eval(), b2.eval()
+    opts = [torch.optim.Adam(m.parameters(), lr=5e-4) for m in (n2, b2)]
+    gamma = 0.1 ** (1 / 500000)
+    plain = []
+    for it in range(6):
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        res, _ = render_rays(n2, b2, rays, idx, hpn, sc, sr, False, True, False)
+        loss = torch.nn.functional.mse_loss(res['rgb_fine'], tgt)
+        loss.backward()
+        for o in opts:
+            o.step()
+            for pg in o.param_groups:
+                pg['lr'] = 5e-4 * gamma ** (it + 1)
+        plain.append(float(loss.detach()))
+    np.testing.assert_allclose(fused, plain, rtol=5e-5)
+    assert fused[-1] < fused[0]
+    # the images the kernels run on are the current weights (the bug class of the fused torch optimiser: tests/test_gpu_parity.py)
+    with torch.no_grad():
+        a = render_rays(nerf, bg_nerf, rays, idx, hpn, sc, sr, False, True, False)[0]['rgb_fine'].cpu().numpy()
+        b = render_rays(n2, b2, rays, idx, hpn, sc, sr, False, True, False)[0]['rgb_fine'].cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+def test_generated_random_numbers_are_uniform_and_keyed():
+    """The step's own random numbers (training mode, nothing injected): two steps differ, the same (seed, step) repeats, and the
+    loss stays in the range of the injected-randoms run."""
+    from mega_nerf.training import FusedTrainStep
+    s = common.SCENE
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    hp, fg, bg, batch = _cell(31, 128)
+    hpn = Namespace(**vars(hp))
+    st = FusedTrainStep([(fg, bg)], hpn, sc, sr, 128, seed=5)
+    l1 = float(st([batch], optimize=False)[0][0])
+    rgb1 = st.rgb[0].cpu().numpy().copy()
+    l2 = float(st([batch], optimize=False)[0][0])
+    rgb2 = st.rgb[0].cpu().numpy().copy()
+    assert np.isfinite([l1, l2]).all() and not np.array_equal(rgb1, rgb2)
+    hp, fg, bg, batch = _cell(31, 128)
+    st2 = FusedTrainStep([(fg, bg)], hpn, sc, sr, 128, seed=5)
+    np.testing.assert_allclose(float(st2([batch], optimize=False)[0][0]), l1, rtol=2e-6)      # (the loss is an atomic sum over the rays)
+    np.testing.assert_array_equal(st2.rgb[0].cpu().numpy(), rgb1)
+    assert abs(l1 - l2) < 0.05 * max(l1, l2)
