@@ -463,6 +463,25 @@ def main():
         extras['eval_65536_ray_batches_whole_step'] = {'tflops': round(fl_big / t_big / 1e12, 1),
                                                        'frac_of_f32_mfma_peak': round(fl_big / t_big / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                                        'bg_rays': nbg_big}
+        # opt-in split-precision inference (csrc/mlp_fwd_h2.hip): NOT part of `value` -- its own arithmetic, its own peak
+        rendering.SPLIT_PRECISION = True
+        try:
+            t_sp = timed(ev_fn(w['batch'], hp), args.steps, 3)
+            t_sp_big = timed(ev_fn(big, hp), 3, 1)
+            with torch.no_grad():
+                a_ = render_rays_async(fgm, bgm, w['batch'][0], w['batch'][1], hp, sc, sr, True, False, True)[0]['rgb_fine']
+            rendering.SPLIT_PRECISION = False
+            with torch.no_grad():
+                b_ = render_rays_async(fgm, bgm, w['batch'][0], w['batch'][1], hp, sc, sr, True, False, True)[0]['rgb_fine']
+            extras['eval_split_precision'] = {
+                'dtype': 'f16 hi/lo split operands, 3 x v_mfma_f32_16x16x32_f16 per layer, f32 accumulate (opt-in; fp32 kernels are the default)',
+                'rays_per_sec': args.rays / t_sp, 'rays_per_sec_65536_ray_batches': 65536 / t_sp_big,
+                'whole_step_65536': {'f32_equivalent_tflops': round(fl_big / t_sp_big / 1e12, 1),
+                                     'issued_f16_mfma_tflops': round(3 * fl_big / t_sp_big / 1e12, 1), 'peak_f16_mfma_tflops': 2500.0,
+                                     'frac_of_f16_mfma_peak_issued': round(3 * fl_big / t_sp_big / 1e12 / 2500.0, 4)},
+                'max_abs_rgb_difference_to_f32_kernels': float((a_ - b_).abs().max())}
+        finally:
+            rendering.SPLIT_PRECISION = False
         hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
         extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
         fgm.train(), bgm.train()

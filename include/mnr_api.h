@@ -256,6 +256,16 @@ typedef struct mnr_mlp_launch {
 } mnr_mlp_launch;
 int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream);
 
+/* ---- opt-in split-precision inference (csrc/mlp_fwd_h2.hip) ------------------------------------------------
+ * Same contract as mnr_mlp_forward_multi (inference segments only, default 8 x 256 fg / bg architectures), computed on the
+ * 16-bit matrix pipe: every fp32 operand is split into two f16 halves and every layer is three v_mfma_f32_16x16x32_f16
+ * products accumulated in fp32 (w_hi x_hi + w_lo x_hi + w_hi x_lo; heads, biases, activations, encodings stay fp32 VALU).
+ * Measured 4.6e-7 relative error per layer against fp64 -- the fp32 kernel's class -- at ~2.5x its speed; it needs its own weight
+ * image (mnr_pack_model_h2: (hi, lo) fragment pairs, same size as the fp32 image).  NOT the default: the fp32 kernels are. */
+size_t mnr_packed_model_h2_bytes(const mnr_model_desc *desc);
+int mnr_pack_model_h2(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
+int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, void *stream);
+
 /* Transposed weight image for the data-gradient chain (re-pack after every optimiser step). */
 size_t mnr_packed_bwd_bytes(const mnr_model_desc *desc);
 int mnr_pack_model_bwd(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);

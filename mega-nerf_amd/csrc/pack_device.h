@@ -7,6 +7,8 @@
 
 namespace mnr {
 
+__device__ __forceinline__ void pack_model_aux_thread(const ModelLayout &m, float *__restrict__ aux, long a);
+
 // One thread per float4 of the chunk stream, then one thread per float of the aux image.
 __device__ __forceinline__ void pack_model_thread(const ModelLayout &m, float4 *__restrict__ chunks, float *__restrict__ aux, long tid) {
     const long n_f4 = (long)m.total_chunks * CHUNK_F4;
@@ -35,8 +37,13 @@ __device__ __forceinline__ void pack_model_thread(const ModelLayout &m, float4 *
         chunks[tid] = v;
         return;
     }
-    const long a = tid - n_f4;
-    if (a >= m.aux_floats) return;
+    pack_model_aux_thread(m, aux, tid - n_f4);
+}
+
+// element `a` of the aux block (biases in lane order, sigma / rgb head weights): shared by the fp32 and the split-precision image
+__device__ __forceinline__ void pack_model_aux_thread(const ModelLayout &m, float *__restrict__ aux, long a) {
+    const int P = m.parts;
+    if (a < 0 || a >= m.aux_floats) return;
     float v = 0.f;
     // biases: [P][n_out/P] per layer, flat register i <-> feature 4P*(i/4) + 4*part + i%4
     for (int i = 0; i < m.n_mfma_layers; ++i) {

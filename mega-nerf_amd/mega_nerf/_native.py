@@ -174,6 +174,7 @@ EXPORTS = [
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
+    'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -286,6 +287,10 @@ def lib() -> C.CDLL:
         _lib.mnr_step_destroy.argtypes = [C.c_void_p]
         _lib.mnr_step_destroy.restype = None
         _lib.mnr_step_repack.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mnr_packed_model_h2_bytes.restype = C.c_size_t
+        _lib.mnr_packed_model_h2_bytes.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_pack_model_h2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
+        _lib.mnr_mlp_forward_multi_h2.argtypes = [C.POINTER(MlpLaunch), C.c_int, C.c_void_p]
         _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
         _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_float, C.c_int64, C.c_uint64, C.c_int,

@@ -192,7 +192,7 @@ class NeRF(nn.Module):
     def weights_changed(self) -> None:
         """Tell the packed-weight caches that the parameters were updated by something that does not bump their version
         counters (``torch.optim.Adam(fused=True)`` does not)."""
-        self._packed_key = self._packed_bwd_key = None
+        self._packed_key = self._packed_bwd_key = self._packed_h2_key = None
 
     def packed(self):
         """(desc, packed device buffer); re-packs when any parameter changed (in-place updates bump ``_version``; storage
@@ -225,6 +225,20 @@ class NeRF(nn.Module):
             N.check(N.lib().mnr_pack_model(self._packed.data_ptr(), nbytes, C.byref(desc), N.stream_ptr()))
             self._packed_key = key
         return desc, self._packed
+
+    def packed_h2(self):
+        """(desc, weight image of the split-precision forward, csrc/mlp_fwd_h2.hip); cached like :meth:`packed`."""
+        desc, _ = self.packed()
+        key = self._packed_key
+        if getattr(self, '_packed_h2', None) is None or getattr(self, '_packed_h2_key', None) != key:
+            nbytes = N.lib().mnr_packed_model_h2_bytes(C.byref(desc))
+            if nbytes == 0:
+                raise N.NativeError(N.lib().mnr_last_error().decode())
+            if getattr(self, '_packed_h2', None) is None or self._packed_h2.numel() != nbytes:
+                self._packed_h2 = torch.empty(nbytes, dtype=torch.uint8, device=self._packed.device)
+            N.check(N.lib().mnr_pack_model_h2(self._packed_h2.data_ptr(), nbytes, C.byref(desc), N.stream_ptr()))
+            self._packed_h2_key = key
+        return desc, self._packed_h2
 
     def evaluate(self, xyz: torch.Tensor, xyz_stride: int, dirs: Optional[torch.Tensor], dir_stride: int,
                  idx: Optional[torch.Tensor], idx_stride: int, rows_per_ray: int, n_rows: int, out: torch.Tensor,

@@ -29,6 +29,11 @@ _ERR_TEXT = ('Not all your cameras are bounded by the unit sphere; please make s
 # the launch stream (kernel-level timing without a profiler); None = no events.
 KERNEL_EVENTS = None
 
+# Opt-in: inference MLP passes of the default architectures on the 16-bit matrix pipe with split-precision operands
+# (csrc/mlp_fwd_h2.hip: fp32-class accuracy -- 4.6e-7 per layer against fp64 -- at ~2.5x the speed).  The fp32 kernels are the
+# default and what every headline number is measured with.
+SPLIT_PRECISION = False
+
 _tables: Dict[Tuple[int, str], torch.Tensor] = {}
 _host_cache: Dict[int, tuple] = {}          # id(tensor) -> (weakref to it, version, host list)
 
@@ -143,7 +148,8 @@ def _serve(reqs) -> list:
     model of a render) go out as ONE launch (mnr_mlp_forward_multi): the compacted background rows alone fill half the
     chip at best, side by side with the foreground's they only lengthen its tail.  Everything else: one launch each."""
     from mega_nerf.models.nerf import NeRF
-    if len(reqs) > 1 and all(isinstance(q.nerf, NeRF) and q.nerf.is_default_arch() for q in reqs):
+    split = SPLIT_PRECISION and not torch.is_grad_enabled()
+    if (len(reqs) > 1 or split) and all(isinstance(q.nerf, NeRF) and q.nerf.is_default_arch() and q.part.idx is not None for q in reqs):
         segs = (N.MlpLaunch * len(reqs))()
         outs, keep = [], []
         for sg, q in zip(segs, reqs):
@@ -151,13 +157,16 @@ def _serve(reqs) -> list:
             out = _f(n, q.S, 4, device=q.xyz.device)
             io = q.nerf.mlp_io(q.xyz, q.xyz.shape[-1], q.part.dirs, q.part.dirs.stride(0), q.part.idx, 1, q.S, n * q.S,
                                out.view(-1, 4), q.noise, q.part.n_units, q.S)
-            desc, packed = q.nerf.packed()
+            desc, packed = q.nerf.packed_h2() if split else q.nerf.packed()
             keep.append((io, desc, packed))
             sg.packed_dev, sg.desc, sg.io = packed.data_ptr(), C.pointer(desc), C.pointer(io)
             outs.append(out)
 
         def launch():
-            N.check(N.lib().mnr_mlp_forward_multi(segs, len(reqs), N.stream_ptr()))
+            if split:
+                N.check(N.lib().mnr_mlp_forward_multi_h2(segs, len(reqs), N.stream_ptr()))
+            else:
+                N.check(N.lib().mnr_mlp_forward_multi(segs, len(reqs), N.stream_ptr()))
         if KERNEL_EVENTS is None:
             launch()
         else:
