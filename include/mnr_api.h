@@ -592,6 +592,29 @@ typedef struct mnr_step_randoms {    /* optional injected uniforms of one cell (
 int mnr_train_step(mnr_step_plan *plan, const mnr_step_batch *batches, const mnr_step_randoms *randoms, float lr, int64_t adam_step,
                    uint64_t seed, int flags, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * One inference render per call -- rendering.render_rays with the evaluation flags (runner.py:569-578: get_depth,
+ * get_bg_fg_rgb), default 8 x 256 fg + bg models, no cascade: six launches on one stream (k_step_begin, k_step_samples, MLP coarse
+ * pass, k_step_mid, MLP fine pass, k_render_tail), stateless, all memory the caller's.  split_precision != 0: the MLP passes run on
+ * mnr_mlp_forward_multi_h2 and fg_packed / bg_packed must be mnr_pack_model_h2 images.  t_*_dev: DEVICE copies of the CPU
+ * torch.linspace(0, 1, n) tables for n = coarse, coarse / 2, fine, fine / 2.  Outputs [n_rays][3] / [n_rays]; depth, fg_*, bg_* may
+ * be NULL.  *n_bg / *err: device scalars (background-ray count; 1 if a camera lies outside the unit ellipsoid, rendering.py:412-414).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mnr_render_io {
+    const mnr_model_desc *fg, *bg;
+    const void *fg_packed, *bg_packed;
+    const float *rays;  const void *idx;  int32_t idx_is_float;
+    int64_t n_rays;
+    int32_t coarse_samples, fine_samples, split_precision;
+    float sphere_center[3], sphere_radius[3];
+    const float *t_coarse_dev, *t_bg_coarse_dev, *t_fine_dev, *t_bg_fine_dev;
+    float *rgb, *depth, *fg_rgb, *bg_rgb, *fg_depth, *bg_depth, *bg_lambda;
+    int32_t *n_bg, *err;
+    void *workspace;  size_t workspace_bytes;
+} mnr_render_io;
+size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples);
+int mnr_render_fwd(const mnr_render_io *io, void *stream);
+
 /* Kernel-level timing without a profiler (bench.py's roofline): after mnr_step_profile(plan, n) every step records HIP events on
  * its launch stream around its kernels, into slot (step index mod n); mnr_step_kernel_times reads a finished slot (the caller
  * synchronises first): ms[MNR_STEP_SPANS] = { samples stage (begin + samples), MLP coarse pass, mid stage, MLP fine pass, tail

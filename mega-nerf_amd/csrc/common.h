@@ -20,6 +20,14 @@ inline int check_launch(const char *what) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// index of the calling thread's current device for per-device one-time set-up flags (function attributes are per device)
+constexpr int MAX_DEVICES = 64;
+inline int device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d < 0 ? 0 : (d >= MAX_DEVICES ? MAX_DEVICES - 1 : d);
+}
+
 struct F3 { float x, y, z; };
 
 }  // namespace mnr

@@ -374,7 +374,8 @@ extern "C" int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, 
     }
     for (int i = n_segs; i <= H2_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     if (wg == 0) return MNR_OK;
-    static bool lds_enabled = false;       // raise the dynamic-LDS cap once (benign if raced)
+    static bool lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (benign if raced)
+    bool &lds_enabled = lds_enabled_dev[device_slot()];
     if (!lds_enabled) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_fwd_h2<H2FG, H2BG>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2_CHUNK_BYTES);
         if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_mlp_fwd_h2): %s", hipGetErrorString(e));

@@ -170,7 +170,7 @@ struct BeginArgs { mnr_step_batch b[MAXC]; };
 __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphere sp, float *__restrict__ rays_o, uint32_t *__restrict__ idx_o,
                                                      float *__restrict__ target_o, float *__restrict__ far_o, float *__restrict__ last_delta_o,
                                                      int32_t *__restrict__ slot_o, int32_t *__restrict__ list_o, float *__restrict__ rays_bg_o,
-                                                     uint32_t *__restrict__ idx_bg_o, int32_t *__restrict__ scal) {
+                                                     uint32_t *__restrict__ idx_bg_o, int32_t *__restrict__ n_bg_o, int32_t *__restrict__ err_o) {
     __shared__ int wave_cnt[16];
     __shared__ int base_s;
     const int cell = blockIdx.x;
@@ -191,8 +191,10 @@ __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphe
             reinterpret_cast<float4 *>(rays_o)[2 * (base + i)] = r0;
             reinterpret_cast<float4 *>(rays_o)[2 * (base + i) + 1] = r1;
             idx_o[base + i] = ix;
-            target_o[3 * (base + i)] = b.target[3 * i]; target_o[3 * (base + i) + 1] = b.target[3 * i + 1];
-            target_o[3 * (base + i) + 2] = b.target[3 * i + 2];
+            if (b.target) {
+                target_o[3 * (base + i)] = b.target[3 * i]; target_o[3 * (base + i) + 1] = b.target[3 * i + 1];
+                target_o[3 * (base + i) + 2] = b.target[3 * i + 2];
+            }
             // rendering.py:33-45, 396-417 (as render.hip::k_ray_setup)
             const float ray[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
             float o[3], d[3];
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphe
             const float p[3] = {o[0] + d1 * d[0], o[1] + d1 * d[1], o[2] + d1 * d[2]};
             const float ray_d_cos = 1.f / sqrtf(dd);
             const float pn = s_dot3(p, p);
-            if (pn >= 1.f) atomicOr(scal + MAXC + cell, 1);
+            if (pn >= 1.f) atomicOr(err_o + cell, 1);
             const float d2 = sqrtf(1.f - pn) * ray_d_cos;
             const float near = ray[6], far = ray[7];
             const float fg_far = fmaxf(d1 + d2, near);
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphe
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) scal[cell] = base_s;
+    if (threadIdx.x == 0) n_bg_o[cell] = base_s;
 }
 
 // ---- k_step_samples ----------------------------------------------------------------------------------------------------------
@@ -674,6 +676,76 @@ __global__ __launch_bounds__(64 * WPB) void k_step_tail(TailArgs a) {
     }
 }
 
+// ---- k_render_tail: the inference form of k_step_tail (rendering.py:102-139, 336-393 with get_depth / get_bg_fg_rgb) --------------
+struct RTailArgs {
+    long N;
+    int Nc, Nf, Sb, Sfb;
+    const float *z_c, *z_f, *raw_c, *raw_f, *zb_c, *zb_f, *braw_c, *braw_f, *dr_c, *dr_f, *last_delta;
+    const int32_t *slot;
+    float *rgb, *depth, *fg_rgb, *bg_rgb, *fg_depth, *bg_depth, *bg_lambda;
+};
+
+template <int EF, int EB>
+__global__ __launch_bounds__(64 * WPB) void k_render_tail(RTailArgs a) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * WPB + wave;
+    if (r >= a.N) return;
+    const int Sm = a.Nc + a.Nf, Smb = a.Sb + a.Sfb;
+    float *key = smem + wave * 3 * Sm;
+    float *zm = key + Sm;
+    int *src = reinterpret_cast<int *>(zm + Sm);
+    const int slot = a.slot[r];
+    float bgr = 0.f, bgg = 0.f, bgb = 0.f, bgd = 0.f;
+    if (slot >= 0) {
+        const long g = slot;
+        merge_wave(key, zm, src, a.zb_f + g * a.Sfb, a.Sfb, a.zb_c + g * a.Sb, a.Sb, 1, lane);
+        Comp<EB> sb;
+        const float4 *rf = reinterpret_cast<const float4 *>(a.braw_f) + g * a.Sfb, *rc = reinterpret_cast<const float4 *>(a.braw_c) + g * a.Sb;
+        comp_forward<EB>(sb, zm, Smb, lane, 1e10f, 1, [&](int k) { const int s = src[k]; return s < a.Sfb ? rf[s] : rc[s - a.Sfb]; });
+        float rr = 0.f, gg = 0.f, bb = 0.f, dd = 0.f;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int k = lane * EB + e;
+            rr += sb.w[e] * sb.c[e].x; gg += sb.w[e] * sb.c[e].y; bb += sb.w[e] * sb.c[e].z;
+            if (k < Smb) {
+                // depth_real of the merged sample: the fine pass's own, or the coarse pass's UNFLIPPED array (quirk Q2)
+                const int s = src[k];
+                dd += sb.w[e] * (s < a.Sfb ? a.dr_f[g * a.Sfb + s] : a.dr_c[g * a.Sb + (s - a.Sfb)]);
+            }
+        }
+        bgr = s_wave_sum(rr); bgg = s_wave_sum(gg); bgb = s_wave_sum(bb); bgd = s_wave_sum(dd);
+        s_lds_fence();
+    }
+    const float *zf = a.z_f + r * a.Nf;
+    merge_wave(key, zm, src, zf, a.Nf, a.z_c + r * a.Nc, a.Nc, 0, lane);
+    float last = a.last_delta[r];
+    if (last < 1e10f) last = last - s_wave_max(zf, a.Nf, lane);
+    Comp<EF> sf;
+    {
+        const float4 *rf = reinterpret_cast<const float4 *>(a.raw_f) + r * a.Nf, *rc = reinterpret_cast<const float4 *>(a.raw_c) + r * a.Nc;
+        comp_forward<EF>(sf, zm, Sm, lane, last, 0, [&](int k) { const int s = src[k]; return s < a.Nf ? rf[s] : rc[s - a.Nf]; });
+    }
+    float rr = 0.f, gg = 0.f, bb = 0.f, dsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EF; ++e) {
+        rr += sf.w[e] * sf.c[e].x; gg += sf.w[e] * sf.c[e].y; bb += sf.w[e] * sf.c[e].z;
+        dsum += sf.w[e] * sf.z[e];
+    }
+    rr = s_wave_sum(rr); gg = s_wave_sum(gg); bb = s_wave_sum(bb); dsum = s_wave_sum(dsum);
+    if (lane != 0) return;
+    const float lam = sf.lambda;
+    const float br = slot >= 0 ? bgr * lam : 0.f, bgv = slot >= 0 ? bgg * lam : 0.f, bbv = slot >= 0 ? bgb * lam : 0.f;
+    const float bd = slot >= 0 ? bgd * lam : 0.f;
+    a.rgb[3 * r] = rr + br; a.rgb[3 * r + 1] = gg + bgv; a.rgb[3 * r + 2] = bb + bbv;
+    a.bg_lambda[r] = lam;
+    if (a.fg_rgb) { a.fg_rgb[3 * r] = rr; a.fg_rgb[3 * r + 1] = gg; a.fg_rgb[3 * r + 2] = bb; }
+    if (a.bg_rgb) { a.bg_rgb[3 * r] = br; a.bg_rgb[3 * r + 1] = bgv; a.bg_rgb[3 * r + 2] = bbv; }
+    if (a.depth) a.depth[r] = dsum + bd;
+    if (a.fg_depth) a.fg_depth[r] = dsum;
+    if (a.bg_depth) a.bg_depth[r] = bd;
+}
+
 // ---- optimiser + re-pack -----------------------------------------------------------------------------------------------------
 struct AdamTensor { float *p; const float *g; float *m, *v; long n, block0; };
 
@@ -946,7 +1018,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         BeginArgs ba{};
         for (int c = 0; c < C; ++c) ba.b[c] = batches[c];
         hipLaunchKernelGGL(k_step_begin, dim3(C), dim3(1024), 0, s, ba, D.N, p->sp, F(L.rays), reinterpret_cast<uint32_t *>(ws + L.idx), F(L.target),
-                           F(L.far), F(L.last_delta), I(L.bg_slot), I(L.bg_list), F(L.rays_bg), reinterpret_cast<uint32_t *>(ws + L.idx_bg), scal);
+                           F(L.far), F(L.last_delta), I(L.bg_slot), I(L.bg_list), F(L.rays_bg), reinterpret_cast<uint32_t *>(ws + L.idx_bg), scal, scal + MAXC);
         int rc = check_launch("k_step_begin");
         if (rc) return rc;
     }
@@ -1123,4 +1195,115 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     rc = mnr_step_repack(p, stream);
     mark(8, 1);
     return rc;
+}
+
+// =====================================================================================================================
+// mnr_render_fwd: one inference render (rendering.py:15-173 with the evaluation flags) as six launches, stateless.
+struct RenderWs {
+    size_t far, last_delta, bg_slot, bg_list, rays_bg, idx_bg, rays, idx;
+    size_t z_c, xyz_c, z_f, xyz_f, raw_c, raw_f, zb_asc, zb_c, pts_c, dr_c, zb_f, pts_f, dr_f, braw_c, braw_f, total;
+};
+static void render_layout(long N, long Nc, long Nf, RenderWs &L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const long Sb = Nc / 2, Sfb = Nf / 2;
+    L.rays = take(N * 32); L.idx = take(N * 4);
+    L.far = take(N * 4); L.last_delta = take(N * 4); L.bg_slot = take(N * 4); L.bg_list = take(N * 4); L.rays_bg = take(N * 32); L.idx_bg = take(N * 4);
+    L.z_c = take(N * Nc * 4); L.xyz_c = take(N * Nc * 12); L.z_f = take(N * Nf * 4); L.xyz_f = take(N * Nf * 12);
+    L.raw_c = take(N * Nc * 16); L.raw_f = take(N * Nf * 16);
+    L.zb_asc = take(N * Sb * 4); L.zb_c = take(N * Sb * 4); L.pts_c = take(N * Sb * 16); L.dr_c = take(N * Sb * 4);
+    L.zb_f = take(N * Sfb * 4); L.pts_f = take(N * Sfb * 16); L.dr_f = take(N * Sfb * 4); L.braw_c = take(N * Sb * 16); L.braw_f = take(N * Sfb * 16);
+    L.total = off;
+}
+static int render_dims_ok(long N, long Nc, long Nf) {
+    if (N < 1 || !((Nc == 64 && Nf == 128) || (Nc == 256 && Nf == 512)))
+        return set_err(MNR_E_UNSUPPORTED, "mnr_render_fwd is instantiated for 64 + 128 and 256 + 512 samples per ray");
+    return MNR_OK;
+}
+
+extern "C" size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples) {
+    if (render_dims_ok(n_rays, coarse_samples, fine_samples) != MNR_OK) return 0;
+    RenderWs L;
+    render_layout(n_rays, coarse_samples, fine_samples, L);
+    return L.total;
+}
+
+extern "C" int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, void *stream);
+
+extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
+    MNR_REQUIRE(r && r->fg && r->bg && r->fg_packed && r->bg_packed && r->rays && r->idx && r->rgb && r->bg_lambda && r->n_bg && r->err &&
+                r->workspace && r->t_coarse_dev && r->t_bg_coarse_dev && r->t_fine_dev && r->t_bg_fine_dev, "NULL argument to mnr_render_fwd");
+    const long N = r->n_rays, Nc = r->coarse_samples, Nf = r->fine_samples, Sb = Nc / 2, Sfb = Nf / 2;
+    int rc = render_dims_ok(N, Nc, Nf);
+    if (rc != MNR_OK) return rc;
+    RenderWs L;
+    render_layout(N, Nc, Nf, L);
+    MNR_REQUIRE(r->workspace_bytes >= L.total, "workspace too small: %zu < %zu", r->workspace_bytes, L.total);
+    MNR_REQUIRE(r->sphere_radius[0] > 0 && r->sphere_radius[1] > 0 && r->sphere_radius[2] > 0, "sphere_radius must be positive");
+    char *ws = reinterpret_cast<char *>(r->workspace);
+    hipStream_t s = as_stream(stream);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+    const SSphere sp{r->sphere_center[0], r->sphere_center[1], r->sphere_center[2], r->sphere_radius[0], r->sphere_radius[1], r->sphere_radius[2]};
+    if (hipMemsetAsync(r->err, 0, 4, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(render)");
+    {
+        BeginArgs ba{};
+        ba.b[0].rays = r->rays; ba.b[0].idx = r->idx; ba.b[0].idx_is_float = r->idx_is_float; ba.b[0].target = nullptr;
+        hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(1024), 0, s, ba, N, sp, F(L.rays), reinterpret_cast<uint32_t *>(ws + L.idx), (float *)nullptr,
+                           F(L.far), F(L.last_delta), I(L.bg_slot), I(L.bg_list), F(L.rays_bg), reinterpret_cast<uint32_t *>(ws + L.idx_bg), r->n_bg, r->err);
+        if ((rc = check_launch("k_step_begin"))) return rc;
+    }
+    {
+        SamplesArgs a{};
+        a.C = 1; a.N = N; a.Nc = (int)Nc; a.Nf = 0; a.Sb = (int)Sb; a.Sfb = 0;       // (Nf = 0: no fine-pass random streams to fill)
+        a.perturb = 0.f; a.noise = 0; a.sp = sp;
+        a.rays = F(L.rays); a.far = F(L.far); a.rays_bg = F(L.rays_bg); a.t_c = r->t_coarse_dev; a.t_bc = r->t_bg_coarse_dev; a.scal = r->n_bg;
+        a.z_c = F(L.z_c); a.xyz_c = F(L.xyz_c); a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.pts_c = F(L.pts_c); a.dr_c = F(L.dr_c);
+        const long total = N * Nc;
+        hipLaunchKernelGGL(k_step_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        if ((rc = check_launch("k_step_samples"))) return rc;
+    }
+    auto fwd_pass = [&](int pass) -> int {
+        mnr_mlp_io io[2] = {};
+        const long Sf = pass ? Nf : Nc, Sbb = pass ? Sfb : Sb;
+        io[0].xyz = F(pass ? L.xyz_f : L.xyz_c); io[0].xyz_stride = 3; io[0].dir = F(L.rays) + 3; io[0].dir_stride = 8;
+        io[0].idx = ws + L.idx; io[0].idx_stride = 1; io[0].idx_is_float = r->idx_is_float; io[0].rows_per_ray = (int32_t)Sf;
+        io[0].out = F(pass ? L.raw_f : L.raw_c); io[0].out_stride = 4; io[0].n_rows = N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = -1;
+        io[1].xyz = F(pass ? L.pts_f : L.pts_c); io[1].xyz_stride = 4; io[1].dir = F(L.rays_bg) + 3; io[1].dir_stride = 8;
+        io[1].idx = ws + L.idx_bg; io[1].idx_stride = 1; io[1].idx_is_float = r->idx_is_float; io[1].rows_per_ray = (int32_t)Sbb;
+        io[1].out = F(pass ? L.braw_f : L.braw_c); io[1].out_stride = 4; io[1].n_rows = N * Sbb; io[1].n_units_dev = r->n_bg;
+        io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = -1;
+        mnr_mlp_launch seg[2] = {};
+        seg[0].packed_dev = r->fg_packed; seg[0].desc = r->fg; seg[0].io = &io[0];
+        seg[1].packed_dev = r->bg_packed; seg[1].desc = r->bg; seg[1].io = &io[1];
+        return r->split_precision ? mnr_mlp_forward_multi_h2(seg, 2, stream) : mlp_forward_multi_impl(seg, 2, nullptr, s);
+    };
+    if ((rc = fwd_pass(0))) return rc;
+    {
+        MidArgs a{};
+        a.C = 1; a.N = N; a.Nc = (int)Nc; a.Nf = (int)Nf; a.Sb = (int)Sb; a.Sfb = (int)Sfb; a.det = 1; a.sp = sp;
+        a.rays = F(L.rays); a.rays_bg = F(L.rays_bg); a.last_delta = F(L.last_delta); a.z_c = F(L.z_c); a.raw_c = F(L.raw_c);
+        a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.braw_c = F(L.braw_c); a.t_f = r->t_fine_dev; a.t_bf = r->t_bg_fine_dev; a.scal = r->n_bg;
+        a.z_f = F(L.z_f); a.xyz_f = F(L.xyz_f); a.zb_f = F(L.zb_f); a.pts_f = F(L.pts_f); a.dr_f = F(L.dr_f);
+        const size_t sh = (size_t)WPB * (4 * Nc + 8) * sizeof(float);
+        const dim3 grid((unsigned)((2 * N + WPB - 1) / WPB)), block(64 * WPB);
+        if (Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, s, a);
+        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, s, a);
+        if ((rc = check_launch("k_step_mid"))) return rc;
+    }
+    if ((rc = fwd_pass(1))) return rc;
+    {
+        RTailArgs a{};
+        a.N = N; a.Nc = (int)Nc; a.Nf = (int)Nf; a.Sb = (int)Sb; a.Sfb = (int)Sfb;
+        a.z_c = F(L.z_c); a.z_f = F(L.z_f); a.raw_c = F(L.raw_c); a.raw_f = F(L.raw_f); a.zb_c = F(L.zb_c); a.zb_f = F(L.zb_f);
+        a.braw_c = F(L.braw_c); a.braw_f = F(L.braw_f); a.dr_c = F(L.dr_c); a.dr_f = F(L.dr_f); a.last_delta = F(L.last_delta); a.slot = I(L.bg_slot);
+        a.rgb = r->rgb; a.depth = r->depth; a.fg_rgb = r->fg_rgb; a.bg_rgb = r->bg_rgb; a.fg_depth = r->fg_depth; a.bg_depth = r->bg_depth;
+        a.bg_lambda = r->bg_lambda;
+        const size_t sh = (size_t)WPB * 3 * (Nc + Nf) * sizeof(float);
+        const dim3 grid((unsigned)((N + WPB - 1) / WPB)), block(64 * WPB);
+        if (Nc == 64) hipLaunchKernelGGL((k_render_tail<3, 2>), grid, block, sh, s, a);
+        else hipLaunchKernelGGL((k_render_tail<12, 6>), grid, block, sh, s, a);
+        if ((rc = check_launch("k_render_tail"))) return rc;
+    }
+    return MNR_OK;
 }

@@ -318,8 +318,11 @@ extern "C" int mnr_tgemm_run(const mnr_tgemm *g, void *stream) {
     a.n_tiles = g->n / TG_BN;
     a.bias = g->bias; a.relu = g->relu; a.gate = g->gate; a.ldgate = g->ldgate;
     a.r1_row = g->r1_row; a.r1_stride = g->r1_stride; a.r1_col = g->r1_col;
-    static int n_cu = 0;
-    static bool lds_enabled = false;
+    static int n_cu_dev[MAX_DEVICES] = {};
+    static bool lds_enabled_dev[MAX_DEVICES] = {};               // per device: function attributes and the CU count are
+    const int slot = device_slot();
+    int &n_cu = n_cu_dev[slot];
+    bool &lds_enabled = lds_enabled_dev[slot];
     if (!lds_enabled) {
         int dev = 0;
         hipDeviceProp_t prop;

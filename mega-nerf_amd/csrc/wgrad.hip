@@ -601,7 +601,8 @@ static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_j
         const size_t need = (W2_CTRL_FLOATS + 2 * ((size_t)wshape_info(wa.job[i].shape).tile_bytes / 4 + 255) / 256 * 256 * 1 + 2 * 256) * sizeof(float);
         lds = need > lds ? need : lds;
     }
-    static bool lds_enabled = false;       // raise the dynamic-LDS cap once (benign if raced)
+    static bool lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (benign if raced)
+    bool &lds_enabled = lds_enabled_dev[device_slot()];
     if (!lds_enabled) {
         for (const void *f : {reinterpret_cast<const void *>(k_wgrad2<0>), reinterpret_cast<const void *>(k_wgrad2<1>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -161,6 +161,18 @@ class StepRandoms(C.Structure):
                 ('bg_noise_coarse', C.c_void_p), ('bg_noise_fine', C.c_void_p), ('fg_u', C.c_void_p), ('bg_u', C.c_void_p)]
 
 
+class RenderIO(C.Structure):
+    """struct mnr_render_io"""
+    _fields_ = [('fg', C.POINTER(ModelDesc)), ('bg', C.POINTER(ModelDesc)), ('fg_packed', C.c_void_p), ('bg_packed', C.c_void_p),
+                ('rays', C.c_void_p), ('idx', C.c_void_p), ('idx_is_float', C.c_int32), ('n_rays', C.c_int64),
+                ('coarse_samples', C.c_int32), ('fine_samples', C.c_int32), ('split_precision', C.c_int32),
+                ('sphere_center', C.c_float * 3), ('sphere_radius', C.c_float * 3),
+                ('t_coarse_dev', C.c_void_p), ('t_bg_coarse_dev', C.c_void_p), ('t_fine_dev', C.c_void_p), ('t_bg_fine_dev', C.c_void_p),
+                ('rgb', C.c_void_p), ('depth', C.c_void_p), ('fg_rgb', C.c_void_p), ('bg_rgb', C.c_void_p), ('fg_depth', C.c_void_p),
+                ('bg_depth', C.c_void_p), ('bg_lambda', C.c_void_p), ('n_bg', C.c_void_p), ('err', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
 EXPORTS = [
     'mnr_version', 'mnr_last_error', 'mnr_device_available', 'mnr_ray_directions', 'mnr_get_rays',
     'mnr_packed_model_bytes', 'mnr_pack_model', 'mnr_layout_src_col', 'mnr_layout_num_steps', 'mnr_layout_parts',
@@ -174,7 +186,7 @@ EXPORTS = [
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
-    'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2',
+    'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -291,6 +303,9 @@ def lib() -> C.CDLL:
         _lib.mnr_packed_model_h2_bytes.argtypes = [C.POINTER(ModelDesc)]
         _lib.mnr_pack_model_h2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
         _lib.mnr_mlp_forward_multi_h2.argtypes = [C.POINTER(MlpLaunch), C.c_int, C.c_void_p]
+        _lib.mnr_render_workspace_bytes.restype = C.c_size_t
+        _lib.mnr_render_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+        _lib.mnr_render_fwd.argtypes = [C.POINTER(RenderIO), C.c_void_p]
         _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
         _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_float, C.c_int64, C.c_uint64, C.c_int,
@@ -330,10 +345,12 @@ _WGRAD_WS: dict = {}
 
 
 def wgrad_workspace(dev):
-    """Scratch of the batched weight-gradient launches (partial-sum slabs, mnr_wgrad_workspace_bytes()), one per device."""
+    """Scratch of the batched weight-gradient launches (partial-sum slabs, mnr_wgrad_workspace_bytes()), one per device and stream."""
     import torch
     dev = torch.device(dev)
-    ws = _WGRAD_WS.get(dev)
+    # one per (device, stream): two renders enqueued on different streams must not share the queue heads / slabs
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WGRAD_WS.get(key)
     if ws is None:
-        ws = _WGRAD_WS[dev] = torch.empty(lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        ws = _WGRAD_WS[key] = torch.empty(lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
     return ws

@@ -372,6 +372,72 @@ def _empty_results(hparams: Namespace, has_bg: bool, get_depth: bool, get_depth_
     return out
 
 
+FUSED_RENDER = True          # inference renders of the default configuration go through mnr_render_fwd (six launches)
+_render_ws: Dict[str, torch.Tensor] = {}
+
+
+def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_depth_variance, rnd) -> bool:
+    import os
+    from mega_nerf.models.nerf import NeRF
+    if not FUSED_RENDER or os.environ.get('MNR_NO_FUSED_RENDER') or bg_nerf is None or image_indices is None or sphere_radius is None:
+        return False
+    if get_depth_variance or rnd or hparams.use_cascade or hparams.container_path is not None or hparams.train_mega_nerf is not None:
+        return False
+    if (hparams.coarse_samples, hparams.fine_samples) not in ((64, 128), (256, 512)):
+        return False
+    for m in (nerf, bg_nerf):
+        if not (isinstance(m, NeRF) and m.is_default_arch()) or m.training:
+            return False
+    return nerf.xyz_dim == 3 and bg_nerf.xyz_dim == 4
+
+
+def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth, get_bg_fg_rgb):
+    """render_rays (evaluation flags) as ONE call of mnr_render_fwd: csrc/step.hip."""
+    lib = N.lib()
+    dev = rays.device
+    n = rays.shape[0]
+    Nc, Nf = hparams.coarse_samples, hparams.fine_samples
+    key = str(dev)
+    need = lib.mnr_render_workspace_bytes(n, Nc, Nf)
+    ws = _render_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _render_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = _f(13 * n, device=dev)
+    scal = torch.empty(2, device=dev, dtype=torch.int32)
+    io = N.RenderIO()
+    split = 1 if SPLIT_PRECISION else 0
+    fd, fp = nerf.packed_h2() if split else nerf.packed()
+    bd, bp = bg_nerf.packed_h2() if split else bg_nerf.packed()
+    io.fg, io.bg, io.fg_packed, io.bg_packed = C.pointer(fd), C.pointer(bd), fp.data_ptr(), bp.data_ptr()
+    io.rays, io.idx, io.idx_is_float, io.n_rays = rays.data_ptr(), image_indices.data_ptr(), 1 if image_indices.dtype == torch.float32 else 0, n
+    io.coarse_samples, io.fine_samples, io.split_precision = Nc, Nf, split
+    c, r = _host_vec(sphere_center), _host_vec(sphere_radius)
+    for i in range(3):
+        io.sphere_center[i], io.sphere_radius[i] = c[i], r[i]
+    tabs = [linspace01(k, dev) for k in (Nc, Nc // 2, Nf, Nf // 2)]
+    io.t_coarse_dev, io.t_bg_coarse_dev, io.t_fine_dev, io.t_bg_fine_dev = [t.data_ptr() for t in tabs]
+    v = {'rgb': out[0:3 * n].view(n, 3), 'fg_rgb': out[3 * n:6 * n].view(n, 3), 'bg_rgb': out[6 * n:9 * n].view(n, 3), 'depth': out[9 * n:10 * n],
+         'fg_depth': out[10 * n:11 * n], 'bg_depth': out[11 * n:12 * n], 'bg_lambda': out[12 * n:13 * n]}
+    io.rgb, io.bg_lambda = v['rgb'].data_ptr(), v['bg_lambda'].data_ptr()
+    if get_depth:
+        io.depth = v['depth'].data_ptr()
+    if get_bg_fg_rgb:
+        io.fg_rgb, io.bg_rgb = v['fg_rgb'].data_ptr(), v['bg_rgb'].data_ptr()
+        if get_depth:
+            io.fg_depth, io.bg_depth = v['fg_depth'].data_ptr(), v['bg_depth'].data_ptr()
+    io.n_bg, io.err = scal[0:1].data_ptr(), scal[1:2].data_ptr()
+    io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+    N.check(lib.mnr_render_fwd(C.byref(io), N.stream_ptr()))
+    results = {'rgb_fine': v['rgb'], 'bg_lambda_fine': v['bg_lambda']}
+    if get_depth:
+        results['depth_fine'] = v['depth']
+    if get_bg_fg_rgb:
+        results['fg_rgb_fine'], results['bg_rgb_fine'] = v['fg_rgb'], v['bg_rgb']
+        if get_depth:
+            results['fg_depth_fine'], results['bg_depth_fine'] = v['fg_depth'], v['bg_depth']
+    return results, scal[0:1], scal[1:2]
+
+
 def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch.Tensor,
                       image_indices: Optional[torch.Tensor], hparams: Namespace, sphere_center, sphere_radius,
                       get_depth: bool, get_depth_variance: bool, get_bg_fg_rgb: bool, _randoms: Optional[dict] = None):
@@ -400,6 +466,8 @@ def render_rays_async(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     dirs = rays[:, 3:6]
     if n_rays == 0:
         return _empty_results(hparams, bg_nerf is not None, get_depth, get_depth_variance, get_bg_fg_rgb, dev), None, None
+    if _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_depth_variance, rnd):
+        return _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth, get_bg_fg_rgb)
 
     n_bg = err = bg_slot = None
     far = None

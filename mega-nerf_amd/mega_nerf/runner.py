@@ -139,6 +139,7 @@ class Runner:
                 # resume inside the epoch the checkpoint was taken in: same permutation (seeded by the epoch number), the
                 # batches already consumed are skipped (the reference's discard_index, runner.py:213-226)
                 epoch, discard = int(ckpt.get('epoch', 0)), int(ckpt.get('dataset_index', -1)) + 1
+                discard = -(-discard // world) * world         # rank 0's index closes a group of `world` batches: resume at the next group
             for key, opt in optimizers.items():
                 sd = opt.state_dict()
                 sd.update(ckpt['optimizers'][key])
@@ -170,8 +171,11 @@ class Runner:
                 dataset.load_chunk()                      # next chunk (prefetched on its own stream by a worker thread)
             chunk_ready = False
             gen = torch.Generator().manual_seed(int(hp.random_seed) + 1000003 * epoch)     # same shuffle on every rank / after a resume
+            # data-parallel ranks walk the epoch in groups of `world` consecutive batches (one each) and drop the ragged last group:
+            # every rank then takes the same number of steps per epoch and their collectives pair up
+            usable = (-(-len(dataset) // hp.batch_size) // world) * world
             for dataset_index, item in enumerate(dataset.batches(hp.batch_size, gen)):
-                if dataset_index < discard or dataset_index % world != rank:
+                if dataset_index < discard or dataset_index >= usable or dataset_index % world != rank:
                     continue
                 image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)

@@ -247,8 +247,9 @@ def _launch_backward(branches, dev: torch.device) -> None:
                 _timed('%s_bwd_%s' % (b.part.tag, t), lambda: N.check(lib.mnr_mlp_backward_data(
                     packed.data_ptr(), packed_bwd.data_ptr(), C.byref(desc), C.byref(g), N.stream_ptr())))
     regions = []
+    batched = _multi_ok(*[b.model for b in branches])      # the batched weight-gradient launch covers the same two architectures
     for b in branches:
-        if b.aligned:
+        if b.aligned and batched:
             regions.append(b.wgrad_region)
             continue
         # sample counts that are not multiples of the 32-row tile: per-branch launches with ragged-tile handling

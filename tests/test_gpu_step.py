@@ -179,3 +179,65 @@ def test_generated_random_numbers_are_uniform_and_keyed():
     np.testing.assert_allclose(float(st2([batch], optimize=False)[0][0]), l1, rtol=2e-6)      # (the loss is an atomic sum over the rays)
     np.testing.assert_array_equal(st2.rgb[0].cpu().numpy(), rgb1)
     assert abs(l1 - l2) < 0.05 * max(l1, l2)
+
+
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('name', ['render_fgbg_eval', 'render_default_samples_eval'])
+def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
+    """mnr_render_fwd (six launches) against the stage-by-stage render -- identical outputs, bit for bit, for the fp32 kernels --
+    and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
+    from mega_nerf import rendering as R
+    g = load(name)
+    hp, nerf, bg_nerf = native_models(name)
+    s = common.SCENE
+    hpn = Namespace(**vars(hp))
+    args = (nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    R.SPLIT_PRECISION = split
+    try:
+        with torch.no_grad():
+            assert R._fused_render_ok(nerf, bg_nerf, hpn, args[3], args[6], False, {})
+            fused, present = R.render_rays(*args)
+            R.FUSED_RENDER = False
+            stage, present2 = R.render_rays(*args)
+    finally:
+        R.FUSED_RENDER, R.SPLIT_PRECISION = True, False
+    assert present == present2 == bool(g['present']) and sorted(fused) == sorted(stage) == sorted(k[4:] for k in g if k.startswith('res_'))
+    for k in fused:
+        a, b = fused[k].cpu().numpy(), g['res_' + k]
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5, err_msg=k)
+        np.testing.assert_array_equal(a, stage[k].cpu().numpy(), err_msg=k)
+
+
+def test_fused_render_benchmark_shape_all_rays():
+    """The benchmark's 1024 x (64 + 128) render through mnr_render_fwd: every output of every ray within 1e-4 of the numpy oracle,
+    the error flag raised for cameras outside the ellipsoid, an empty background handled."""
+    from mega_nerf import ray_utils
+    from mega_nerf.rendering import render_rays
+    from oracle import nerf_oracle as O
+    from test_gpu_parity import native_nerf
+    s = common.SCENE
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128)
+    A = s['appearance_count']
+    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    fw, bw = common.make_weights(fcfg, A, 1000), common.make_weights(bcfg, A, 1500)
+    d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, torch.device(DEV))
+    rays_all = ray_utils.get_rays(d, T(s['c2w']), s['near'], s['far'], s['ray_altitude_range']).view(-1, 8).cpu().numpy()
+    rays, idx = common.pick_rays(rays_all, 1024, 7)
+    fg, bg = native_nerf(fcfg, fw), native_nerf(bcfg, bw)
+    hpn = Namespace(**vars(hp))
+    with torch.no_grad():
+        res, present = render_rays(fg, bg, T(rays), T(idx.astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    ores, opresent = O.render_rays(O.Model(fcfg, fw), O.Model(bcfg, bw), rays, idx.astype(f32), hp, s['sphere_center'], s['sphere_radius'], True, False, True)
+    assert present == opresent and sorted(res) == sorted(ores)
+    for k in ores:
+        np.testing.assert_allclose(res[k].cpu().numpy(), ores[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    bad = T(rays).clone()
+    bad[:, :3] *= 40
+    with pytest.raises(Exception, match='Not all your cameras are bounded by the unit sphere'):
+        render_rays(fg, bg, bad, T(idx.astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    # rays that all end inside the sphere: no background segment
+    inside = T(rays).clone()
+    inside[:, 7] = 0.3
+    with torch.no_grad():
+        res2, present2 = render_rays(fg, bg, inside, T(idx.astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    assert not present2 and float(res2['bg_rgb_fine'].abs().max()) == 0.0 and np.isfinite(res2['rgb_fine'].cpu().numpy()).all()

@@ -49,6 +49,16 @@ def _worker(rank, world, port, out):
         D.average_gradients(list(lin.parameters()))
         assert torch.allclose(lin.weight.grad, torch.full_like(lin.weight, 1.5))
         assert torch.allclose(lin.bias.grad, torch.arange(3.) * 0.5)
+        # gradients that are views of one flat buffer (the fused step's gradient area): reduced in place, padding included
+        flat = torch.zeros(4 * 3 + 4 + 3)
+        lin.weight.grad = flat[0:12].view(3, 4)
+        lin.bias.grad = flat[16:19]
+        flat[0:12] = float(rank + 1)
+        flat[16:19] = torch.arange(3.) * (rank + 1)
+        assert D._as_one_buffer([lin.weight.grad, lin.bias.grad]) is not None
+        D.average_gradients(list(lin.parameters()))
+        assert lin.weight.grad.data_ptr() == flat.data_ptr() and torch.allclose(flat[0:12], torch.full((12,), 1.5))
+        assert torch.allclose(flat[16:19], torch.arange(3.) * 1.5)
         assert D.any_rank(rank == 1, torch.device('cpu')) is True and D.any_rank(False, torch.device('cpu')) is False
         # strong-scaling cell -> rank -> batch mapping of bench.py --submodules 8: every cell exactly once over the ranks,
         # seeds independent of the world size
