@@ -360,7 +360,7 @@ def main():
     steppers = []
     fused = None
     if args.mode == 'train' and not wide:
-        # every cell this rank owns goes through ONE mnr_train_step call per step (csrc/step.hip): 13 launches + a memset for the
+        # every cell this rank owns goes through ONE mnr_train_step call per step (csrc/step.hip): 12 kernel launches + a memset for the
         # whole iteration, the cells' rows side by side in the MLP launches
         from mega_nerf.training import FusedTrainStep, fused_step_supported
         for w in work:

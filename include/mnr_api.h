@@ -520,7 +520,7 @@ int mnr_bg_blend_backward(const float *d_rgb_dev, const float *bg_lambda_dev, co
  * What the reference's trainer does per iteration (runner.py:347-358 render_rays with the training flags, :370 mse_loss,
  * :263-277 backward + Adam step on the foreground and the background model), for ONE OR SEVERAL independent submodules
  * ("cells": parscripts/run_8.txt runs one trainer per cell; a rank that owns several cells steps all of them here), enqueued
- * on one stream as a fixed sequence of 13 launches + one memset (csrc/step.hip):
+ * on one stream as a fixed sequence of 12 kernel launches + one memset for one cell, 2 more per further cell (csrc/step.hip):
  *     memset (gradients, counters) | k_step_begin (batch copy, _intersect_sphere, background compaction) | k_step_samples
  *     (coarse samples of both branches, random numbers) | MLP coarse pass, all cells, fg + bg rows | k_step_mid (coarse
  *     compositing weights -> _sample_pdf -> fine points) | MLP fine pass | k_step_tail (merge, compositing, fg/bg blend, MSE,

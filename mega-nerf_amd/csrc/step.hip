@@ -1,5 +1,5 @@
 // step.hip -- one whole training step per call (mnr_train_step): runner.py:244-277 over rendering.py:15-173 for one or
-// several independent submodules ("cells"), as a fixed sequence of 13 launches + one memset on one stream.
+// several independent submodules ("cells"), as a fixed sequence of 12 kernel launches + one memset on one stream (+ 2 per further cell).
 //
 //   memset            gradients, background-ray counts, error flags, loss, weight-gradient queue heads (one region)
 //   k_step_begin      one 1024-thread workgroup per cell: batch -> workspace, _intersect_sphere + near/far (rendering.py:33-45,

@@ -734,7 +734,7 @@ def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int) -> bool:
 class FusedTrainStep:
     """The reference trainer's iteration (runner.py:244-277: render_rays with the training flags, mse_loss, backward, Adam on the
     foreground and the background model, ExponentialLR) for ONE OR SEVERAL independent cells a rank owns, as one call of
-    ``mnr_train_step``: 13 launches + one memset, no torch kernels, no host synchronisation.  Every cell keeps its own models,
+    ``mnr_train_step``: 12 kernel launches + one memset (+ 2 per further cell), no torch kernels, no host synchronisation.  Every cell keeps its own models,
     optimiser moments and batch (parscripts/run_8.txt: one trainer per cell).  After a call ``param.grad`` of every model
     parameter is that step's gradient (a view into the step's workspace)."""
 
