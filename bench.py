@@ -509,6 +509,25 @@ def main():
                                                   'median_abs': float((a_ - b_).abs().median())}}
         finally:
             rendering.SPLIT_PRECISION = False
+        if args.mode == 'train':
+            # opt-in split-precision TRAINING step: tape-writing forward + data-gradient chain on the 16-bit pipe (tapes, weight
+            # gradients, heads, optimiser: the fp32 kernels).  Its own dtype; NOT `value`.
+            from mega_nerf.training import FusedTrainStep
+            fgm.train(), bgm.train()
+            fs = FusedTrainStep([(fgm, bgm)], hp, sc, sr, args.rays, split_precision=True)
+            t_ts = timed(lambda: fs([w['batch']]), args.steps, 3)
+            fs.profile(8)
+            for _ in range(8):
+                fs([w['batch']])
+            torch.cuda.synchronize()
+            sp = [fs.kernel_times(i) for i in range(8)]
+            extras['train_split_precision'] = {
+                'dtype': 'forward + data-gradient chain: f16 hi/lo split operands, 3 x v_mfma_f32_16x16x32_f16 per layer, f32 accumulate; '
+                         'weight gradients, heads, ray stages, Adam: f32 (opt-in; the f32 step is the default and `value`)',
+                'ms_per_step': t_ts * 1e3, 'rays_per_sec': args.rays / t_ts,
+                'step_spans_ms': {k: round(sum(d_[k] for d_ in sp) / len(sp), 4) for k in sp[0]}}
+            del fs
+            fgm.eval(), bgm.eval()
         hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
         extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
         fgm.train(), bgm.train()

@@ -264,6 +264,9 @@ int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream);
  * image (mnr_pack_model_h2: (hi, lo) fragment pairs, same size as the fp32 image).  NOT the default: the fp32 kernels are. */
 size_t mnr_packed_model_h2_bytes(const mnr_model_desc *desc);
 int mnr_pack_model_h2(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
+/* ... and the transposed image of the split-precision data-gradient chain (training through mnr_train_step only) */
+size_t mnr_packed_bwd_h2_bytes(const mnr_model_desc *desc);
+int mnr_pack_model_bwd_h2(void *packed_dev, size_t packed_bytes, const mnr_model_desc *desc, void *stream);
 int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, void *stream);
 
 /* Transposed weight image for the data-gradient chain (re-pack after every optimiser step). */
@@ -538,6 +541,8 @@ typedef struct mnr_step_model {
     mnr_model_grads adam_m, adam_v;  /* torch.optim.Adam's exp_avg / exp_avg_sq, same shapes (caller-owned, zero before step 1) */
     void *packed_dev;                /* mnr_packed_model_bytes(desc) bytes: re-packed at the end of every step */
     void *packed_bwd_dev;            /* mnr_packed_bwd_bytes(desc) bytes */
+    void *packed_h2_dev;             /* cfg.split_precision: mnr_packed_model_h2_bytes / mnr_packed_bwd_h2_bytes bytes INSTEAD of the */
+    void *packed_bwd_h2_dev;         /*   two fp32 images above (which may then be NULL) */
 } mnr_step_model;
 
 typedef struct mnr_step_cfg {
@@ -552,6 +557,9 @@ typedef struct mnr_step_cfg {
     const float *t_coarse;           /* HOST tables: torch.linspace(0, 1, n) as the CPU kernel computes it (values are data: */
     const float *t_bg_coarse;        /*   DESIGN.md) for n = coarse_samples, coarse_samples / 2, fine_samples, fine_samples / 2 */
     const float *t_fine, *t_bg_fine;
+    int32_t split_precision;         /* opt-in: the tape-writing forward and the data-gradient chain on the 16-bit matrix pipe with
+                                        split-precision operands (csrc/mlp_fwd_h2.hip, mlp_bwd_h2.hip); tapes stay fp32, the
+                                        weight gradients, heads, ray stages and the optimiser are the same fp32 kernels */
 } mnr_step_cfg;
 
 typedef struct mnr_step_layout {
@@ -562,6 +570,9 @@ typedef struct mnr_step_layout {
     size_t depth_var_offset;         /* float  [n_cells][n_rays]      depth_variance_fine */
     size_t bg_lambda_offset;         /* float  [n_cells][n_rays]      bg_lambda_fine */
     size_t n_bg_offset, err_offset;  /* int32  [n_cells]          rays with a background segment / camera-outside-sphere flag */
+    size_t tape_fg_offset, tape_bg_offset;   /* the activation tapes (mlp_layout.h TapeLayout planes, tape_*_rows rows each): cell c's coarse */
+    int64_t tape_fg_rows, tape_bg_rows;      /*   rows start at row c * (tape_*_rows / n_cells), its fine rows follow (tests read the ReLU masks here) */
+    size_t gtape_fg_offset, gtape_bg_offset; /* the gradient tapes (same planes: dL/d(pre-activation) of every layer) */
 } mnr_step_layout;
 int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg_arch, const mnr_model_desc *bg_arch, mnr_step_layout *out);
 

@@ -1,0 +1,220 @@
+// h2_device.h -- shared pieces of the split-precision kernels (csrc/mlp_fwd_h2.hip, csrc/mlp_bwd_h2.hip, csrc/step.hip): the image
+// layout of (hi, lo) f16 fragment pairs, the packers' per-element bodies, the LDS weight stream and the K-step runner.
+// Design notes: mlp_fwd_h2.hip.
+#pragma once
+#include "mlp_device.h"
+#include "pack_device.h"
+
+namespace mnr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+constexpr int H2_WAVES = 8, H2_THREADS = H2_WAVES * 64, H2_ROWS = H2_WAVES * 16;
+constexpr int H2_CHUNK_U4 = 4096;                      // 64 KiB
+constexpr int H2_CHUNK_BYTES = H2_CHUNK_U4 * 16;
+
+// ---- image layout (host + device) ----------------------------------------------------------------------------------------------
+// per layer: K-steps = sum over its segments of ceil(seg.nsteps / 8) (a segment's registers are padded to whole K-steps with
+// zeros); a chunk holds SPC = 4096 / (nob * 2 * 64) K-steps (2 for 16 output blocks, 4 for 8); a layer starts on a chunk boundary;
+// inside a chunk: [K-step][output block][hi | lo][lane] x 16 bytes.
+MNR_HD int h2_ksteps(const LayerLayout &l) {
+    int k = 0;
+    for (int i = 0; i < l.nseg; ++i) k += (l.seg[i].nsteps + 7) / 8;
+    return k;
+}
+MNR_HD int h2_spc(const LayerLayout &l) { return H2_CHUNK_U4 / (l.nob * 2 * 64); }
+MNR_HD int h2_layer_chunks(const LayerLayout &l) { return (h2_ksteps(l) + h2_spc(l) - 1) / h2_spc(l); }
+MNR_HD int h2_total_chunks(const ModelLayout &m) {
+    int c = 0;
+    for (int i = 0; i < m.n_mfma_layers; ++i) c += h2_layer_chunks(m.layer[i]);
+    return c + 1;                                      // + one trailing chunk: the stream prefetches one past the end
+}
+// source column of slot j of K-step S (lane-part p) of layer l, -1 = zero pad
+MNR_HD int h2_src_col(const LayerLayout &l, int P, int S, int p, int j) {
+    int s0 = 0;
+    for (int i = 0; i < l.nseg; ++i) {
+        const Seg &g = l.seg[i];
+        const int ks = (g.nsteps + 7) / 8;
+        if (S < s0 + ks) {
+            const int r = 8 * (S - s0) + j;
+            if (r >= g.nsteps) return -1;
+            int c = -1;
+            if (g.type == SEG_EMB) c = emb_src(g.D, g.L, P, r, p);
+            else if (g.type == SEG_HID) c = hid_src(P, r, p);
+            else if (g.type == SEG_APP) c = app_src(g.D, P, r, p);
+            return c < 0 ? -1 : g.col0 + c;
+        }
+        s0 += ks;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void h2_split_weight(float w, unsigned short &hi, unsigned short &lo) {
+    // hi = w rounded to 10 mantissa bits (round half up on the magnitude), lo = the rest, rounded the same way
+    const unsigned u = (__float_as_uint(w) + 0x1000u) & 0xffffe000u;
+    const _Float16 h = (_Float16)__uint_as_float(u);
+    const float r = w - (float)h;
+    const unsigned v = (__float_as_uint(r) + 0x1000u) & 0xffffe000u;
+    const _Float16 l = (_Float16)__uint_as_float(v);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// one thread per 16-byte fragment element of the chunk stream, then one thread per float of the aux image (= the fp32 image's)
+__device__ __forceinline__ void pack_model_h2_thread(const ModelLayout &m, uint4v *__restrict__ chunks, float *__restrict__ aux, long n_u4, long tid) {
+    if (tid >= n_u4) {
+        pack_model_aux_thread(m, aux, tid - n_u4);
+        return;
+    }
+    const int chunk = (int)(tid / H2_CHUNK_U4), within = (int)(tid % H2_CHUNK_U4);
+    uint4v v = {0u, 0u, 0u, 0u};
+    int c0 = 0;
+    for (int li = 0; li < m.n_mfma_layers; ++li) {
+        const LayerLayout &l = m.layer[li];
+        const int nc = h2_layer_chunks(l);
+        if (chunk >= c0 && chunk < c0 + nc) {
+            const int spc = h2_spc(l);
+            const int lane = within & 63, frag = within >> 6;                 // frag = (kstep_in_chunk * nob + ob) * 2 + hl
+            const int hl = frag & 1, ob = (frag >> 1) % l.nob, kc = (frag >> 1) / l.nob;
+            const int S = (chunk - c0) * spc + kc;
+            if (kc < spc && S < h2_ksteps(l)) {
+                const int row = ob * 16 + (lane & 15), part = lane >> 4;
+                unsigned short e[8];
+                for (int j = 0; j < 8; ++j) {
+                    const int col = h2_src_col(l, m.parts, S, part, j);
+                    const float w = (col >= 0 && row < l.n_out) ? l.w[(long)row * l.ld + col] : 0.f;
+                    unsigned short hi, lo;
+                    h2_split_weight(w, hi, lo);
+                    e[j] = hl ? lo : hi;
+                }
+                v = uint4v{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                           (unsigned)e[6] | ((unsigned)e[7] << 16)};
+            }
+        }
+        c0 += nc;
+    }
+    chunks[tid] = v;
+}
+
+
+struct H2Stream {
+    const uint4v *g;
+    uint4v *lds;
+    int cur;
+    __device__ __forceinline__ void issue() {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        uint4v *dst = lds + (cur ^ 1) * H2_CHUNK_U4 + wave * 64;
+        const unsigned lane_off = threadIdx.x * 16u;
+#pragma unroll
+        for (int i = 0; i < H2_CHUNK_U4 / H2_THREADS; ++i) {
+            unsigned lo = lane_off;
+            asm("" : "+v"(lo));
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + i * H2_THREADS)) + lo),
+                                             (lds_void_t *)(dst + i * H2_THREADS), 16, 0, 0);
+        }
+        g += H2_CHUNK_U4;
+    }
+    __device__ __forceinline__ void next_chunk() {
+        __syncthreads();
+        cur ^= 1;
+        issue();
+    }
+};
+
+__device__ __forceinline__ void h2_split8(const float (&x)[8], uint4v &hi, uint4v &lo) {
+    float h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = __uint_as_float(__float_as_uint(x[j]) & 0xffffe000u);
+        l[j] = x[j] - h[j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2 * q], h[2 * q + 1]));
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2 * q], l[2 * q + 1]));
+    }
+}
+
+__device__ __forceinline__ floatx4 h2_mfma(uint4v a, uint4v b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+
+// One segment of a layer: NK K-steps whose B operands are src[0 .. NSRC) (zero beyond); K0 = index of the segment's first K-step
+// inside the layer (chunk boundaries are static: a new chunk every SPC K-steps, the first at K-step 0 of the layer).
+template <int NOB, int NK, int K0, int NSRC>
+__device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane) {
+    constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64);
+    static_for<0, NK>([&](auto kc) {
+        constexpr int kl = decltype(kc)::value, k = K0 + kl;
+        if constexpr (k % SPC == 0) st.next_chunk();
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (8 * kl + j < NSRC) ? src[(8 * kl + j < NSRC) ? 8 * kl + j : 0] : 0.f;
+        uint4v bh, bl;
+        h2_split8(x, bh, bl);
+        const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
+#pragma unroll
+        for (int o0 = 0; o0 < NOB; o0 += 4) {
+            uint4v ah[4], al[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { ah[o] = p[((o0 + o) * 2) * 64]; al[o] = p[((o0 + o) * 2 + 1) * 64]; }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(al[o], bh, acc[o0 + o]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
+        }
+    });
+}
+
+
+}  // namespace mnr
+
+namespace mnr {
+
+// ---- transposed (data-gradient) image: bwd layer order of BwdLayout, K-steps of 32 output features ----------------------------
+MNR_HD int h2b_ksteps(const BwdLayerLayout &l) { return l.nsteps / 8; }
+MNR_HD int h2b_spc(const BwdLayerLayout &l) { const int s = H2_CHUNK_U4 / (l.nob * 2 * 64); return s < 1 ? 1 : s; }
+MNR_HD int h2b_layer_chunks(const BwdLayerLayout &l) { return (h2b_ksteps(l) + h2b_spc(l) - 1) / h2b_spc(l); }
+MNR_HD int h2b_total_chunks(const BwdLayout &b) {
+    int c = 0;
+    for (int i = 0; i < b.n_layers; ++i) c += h2b_layer_chunks(b.layer[i]);
+    return c + 1;
+}
+// element (row of the transposed product = input column of the nn.Linear, K-step S, lane-part p, slot j) = w[hid_src(P, 8S + j, p)][in_col(row)]
+__device__ __forceinline__ void pack_bwd_h2_thread(const BwdLayout &b, uint4v *__restrict__ chunks, long tid) {
+    if (tid >= (long)h2b_total_chunks(b) * H2_CHUNK_U4) return;
+    const int chunk = (int)(tid / H2_CHUNK_U4), within = (int)(tid % H2_CHUNK_U4);
+    uint4v v = {0u, 0u, 0u, 0u};
+    int c0 = 0;
+    for (int li = 0; li < b.n_layers; ++li) {
+        const BwdLayerLayout &l = b.layer[li];
+        const int nc = h2b_layer_chunks(l);
+        if (chunk >= c0 && chunk < c0 + nc) {
+            const int spc = h2b_spc(l);
+            const int lane = within & 63, frag = within >> 6;
+            const int hl = frag & 1, ob = (frag >> 1) % l.nob, kc = (frag >> 1) / l.nob;
+            const int S = (chunk - c0) * spc + kc;
+            if (kc < spc && S < h2b_ksteps(l)) {
+                const int row = ob * 16 + (lane & 15), part = lane >> 4;
+                if (row < l.n_rows) {
+                    const int in_col = row < l.split ? l.in_off + row : l.in_off2 + (row - l.split);
+                    unsigned short e[8];
+                    for (int j = 0; j < 8; ++j) {
+                        unsigned short hi, lo;
+                        h2_split_weight(l.w[(long)hid_src(b.parts, 8 * S + j, part) * l.ld + in_col], hi, lo);
+                        e[j] = hl ? lo : hi;
+                    }
+                    v = uint4v{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                               (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                }
+            }
+        }
+        c0 += nc;
+    }
+    chunks[tid] = v;
+}
+
+}  // namespace mnr

@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "mlp_layout.h"
+#include "h2_device.h"
 #include "pack_device.h"
 #include "step_internal.h"
 
@@ -120,6 +121,8 @@ static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mn
         return set_err(MNR_E_UNSUPPORTED, "the fused step needs n_rays * samples / 2 to be a multiple of 64 (one workgroup tile)");
     const bool shapes = (D.Nc == 64 && D.Nf == 128) || (D.Nc == 256 && D.Nf == 512);
     if (!shapes) return set_err(MNR_E_UNSUPPORTED, "the fused step is instantiated for 64 + 128 and 256 + 512 samples per ray");
+    if (cfg->split_precision && ((D.N * D.Sb) % 128 || (D.N * D.Sfb) % 128))
+        return set_err(MNR_E_UNSUPPORTED, "the split-precision step needs n_rays * samples / 2 to be a multiple of 128 (one workgroup tile)");
     D.cap_f = D.N * (D.Nc + D.Nf); D.cap_b = D.N * (D.Sb + D.Sfb);
     D.fpr_f = mnr_tape_floats_per_row(fg); D.fpr_b = mnr_tape_floats_per_row(bg);
     if (D.fpr_f <= 0 || D.fpr_b <= 0) return set_err(MNR_E_UNSUPPORTED, "no training kernels for this architecture");
@@ -570,7 +573,9 @@ struct TailArgs {
 __device__ __forceinline__ void merge_wave(float *key, float *zm, int *src, const float *zfine, int Sa, const float *zcoarse, int Sb, int flip,
                                            int lane) {
     const int St = Sa + Sb;
-    for (int i = lane; i < St; i += 64) key[i] = i < Sa ? zfine[i] : zcoarse[i - Sa];
+    // (zm / src start as the identity: with NaN depths -- a diverged model -- every rank below collapses to 0 and the entries not
+    // written there must still be valid sample numbers, not whatever the LDS held)
+    for (int i = lane; i < St; i += 64) { const float k = i < Sa ? zfine[i] : zcoarse[i - Sa]; key[i] = k; zm[i] = k; src[i] = i; }
     s_lds_fence();
     for (int e = lane; e < St; e += 64) {
         const float ke = key[e];
@@ -776,8 +781,8 @@ __global__ __launch_bounds__(256) void k_step_adam(const AdamTensor *__restrict_
 }
 
 struct PackJob {
-    int kind;                  // 0: forward image (ModelLayout), 1: transposed image (BwdLayout)
-    long block0, nblocks;
+    int kind;                  // 0: forward image (ModelLayout), 1: transposed image (BwdLayout), 2 / 3: their split-precision forms
+    long block0, nblocks, n_u4;
     float4 *chunks;
     float *aux;
     ModelLayout m;
@@ -790,7 +795,9 @@ __global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ j
     const PackJob &job = jobs[j];
     const long tid = (blk - job.block0) * 256 + threadIdx.x;
     if (job.kind == 0) pack_model_thread(job.m, job.chunks, job.aux, tid);
-    else pack_bwd_thread(job.b, job.chunks, tid);
+    else if (job.kind == 1) pack_bwd_thread(job.b, job.chunks, tid);
+    else if (job.kind == 2) pack_model_h2_thread(job.m, reinterpret_cast<uint4v *>(job.chunks), job.aux, job.n_u4, tid);
+    else pack_bwd_h2_thread(job.b, reinterpret_cast<uint4v *>(job.chunks), tid);
 }
 
 }  // namespace mnr
@@ -838,6 +845,8 @@ extern "C" int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg,
     out->grad_offset = L.grads; out->grad_stride = L.grad_stride;
     out->loss_offset = L.loss; out->rgb_offset = L.rgb; out->depth_var_offset = L.depth_var; out->bg_lambda_offset = L.bg_lambda;
     out->n_bg_offset = L.scal; out->err_offset = L.scal + MAXC * 4;
+    out->tape_fg_offset = L.tape_f; out->tape_bg_offset = L.tape_b; out->tape_fg_rows = D.C * D.cap_f; out->tape_bg_rows = D.C * D.cap_b;
+    out->gtape_fg_offset = L.gtape_f; out->gtape_bg_offset = L.gtape_b;
     return MNR_OK;
 }
 
@@ -909,7 +918,9 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
                 d.skip_mask != d0.skip_mask || d.layer_dim != d0.layer_dim || d.appearance_dim != d0.appearance_dim ||
                 d.appearance_count != d0.appearance_count || d.rgb_dim != d0.rgb_dim || d.sigma_activation != d0.sigma_activation)
                 return fail(set_err(MNR_E_INVALID, "mnr_step_create: every cell must have the architecture of cell 0"));
-            if (!M.packed_dev || !M.packed_bwd_dev || !d.embedding_a || !M.grad.embedding_a)
+            const bool split = cfg->split_precision != 0;
+            void *img_f = split ? M.packed_h2_dev : M.packed_dev, *img_b = split ? M.packed_bwd_h2_dev : M.packed_bwd_dev;
+            if (!img_f || !img_b || !d.embedding_a || !M.grad.embedding_a)
                 return fail(set_err(MNR_E_INVALID, "mnr_step_create: cell %d: packed image / embedding pointers missing", c));
             const char *g0 = ws + L.grads + (size_t)c * L.grad_stride;
             const char *ge = g0 + (size_t)cfg->grad_floats_per_cell * 4;
@@ -919,21 +930,30 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
             BwdLayout bl;
             if ((rc = layout_from_desc(&d, ml)) != MNR_OK || (rc = bwd_layout_from_desc(&d, bl)) != MNR_OK) return fail(rc);
             PackJob jf{};
-            jf.kind = 0; jf.m = ml; jf.chunks = reinterpret_cast<float4 *>(M.packed_dev);
-            jf.aux = reinterpret_cast<float *>(reinterpret_cast<char *>(M.packed_dev) + (size_t)ml.total_chunks * CHUNK_BYTES);
-            jf.block0 = pack_blocks; jf.nblocks = ((long)ml.total_chunks * CHUNK_F4 + ml.aux_floats + 255) / 256;
+            jf.m = ml; jf.chunks = reinterpret_cast<float4 *>(img_f);
+            if (split) {
+                jf.kind = 2; jf.n_u4 = (long)h2_total_chunks(ml) * H2_CHUNK_U4;
+                jf.aux = reinterpret_cast<float *>(reinterpret_cast<char *>(img_f) + (size_t)jf.n_u4 * 16);
+                jf.nblocks = (jf.n_u4 + ml.aux_floats + 255) / 256;
+            } else {
+                jf.kind = 0;
+                jf.aux = reinterpret_cast<float *>(reinterpret_cast<char *>(img_f) + (size_t)ml.total_chunks * CHUNK_BYTES);
+                jf.nblocks = ((long)ml.total_chunks * CHUNK_F4 + ml.aux_floats + 255) / 256;
+            }
+            jf.block0 = pack_blocks;
             pack_blocks += jf.nblocks;
             jobs.push_back(jf);
             PackJob jb{};
-            jb.kind = 1; jb.b = bl; jb.chunks = reinterpret_cast<float4 *>(M.packed_bwd_dev);
-            jb.block0 = pack_blocks; jb.nblocks = ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
+            jb.kind = split ? 3 : 1; jb.b = bl; jb.chunks = reinterpret_cast<float4 *>(img_b);
+            jb.block0 = pack_blocks;
+            jb.nblocks = split ? ((long)h2b_total_chunks(bl) * H2_CHUNK_U4 + 255) / 256 : ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
             pack_blocks += jb.nblocks;
             jobs.push_back(jb);
             if ((rc = adam_tensors_of(M, adam)) != MNR_OK) return fail(rc);
             // the four (branch, pass) cell tables: fg coarse, fg fine, bg coarse, bg fine
             for (int pass = 0; pass < 2; ++pass) {
                 MlpCellSeg &e = cells[(2 * k + pass) * C + c];
-                e.packed = M.packed_dev; e.packed_bwd = M.packed_bwd_dev; e.emb_a = d.embedding_a; e.d_emb_a = M.grad.embedding_a;
+                e.packed = img_f; e.packed_bwd = img_b; e.emb_a = d.embedding_a; e.d_emb_a = M.grad.embedding_a;
                 const long cap = k == 0 ? D.cap_f : D.cap_b, first = k == 0 ? D.N * D.Nc : D.N * D.Sb;
                 e.tape_row0 = (long)c * cap + (pass ? first : 0);
                 e.n_units = k == 0 ? nullptr : reinterpret_cast<const int32_t *>(ws + L.scal) + c;
@@ -1043,6 +1063,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     mark(0, 1);
     // ---- MLP passes: segment descriptions over the cell-major arrays ----
     const mnr_step_model &M0f = p->models[0], &M0b = p->models[1];
+    const bool split = p->cfg.split_precision != 0;
     const MlpCellSeg *tabs = reinterpret_cast<const MlpCellSeg *>(ws + L.tab_cells);
     const long capT_f = D.C * D.cap_f, capT_b = D.C * D.cap_b;
     auto fwd_pass = [&](int pass) -> int {
@@ -1063,12 +1084,12 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         io[1].out = F(pass ? L.braw_f : L.braw_c); io[1].out_stride = 4;
         io[1].n_rows = D.C * D.N * Sbb; io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = -1;
         mnr_mlp_launch seg[2] = {};
-        seg[0].packed_dev = M0f.packed_dev; seg[0].desc = &M0f.desc; seg[0].io = &io[0];
+        seg[0].packed_dev = split ? M0f.packed_h2_dev : M0f.packed_dev; seg[0].desc = &M0f.desc; seg[0].io = &io[0];
         seg[0].tape_dev = F(L.tape_f); seg[0].tape_rows = capT_f; seg[0].tape_row0 = 0;
-        seg[1].packed_dev = M0b.packed_dev; seg[1].desc = &M0b.desc; seg[1].io = &io[1];
+        seg[1].packed_dev = split ? M0b.packed_h2_dev : M0b.packed_dev; seg[1].desc = &M0b.desc; seg[1].io = &io[1];
         seg[1].tape_dev = F(L.tape_b); seg[1].tape_rows = capT_b; seg[1].tape_row0 = 0;
         const CellTable ct[2] = {{tabs + (0 + pass) * C, D.N * Sf}, {tabs + (2 + pass) * C, D.N * Sbb}};
-        return mlp_forward_multi_impl(seg, 2, ct, s);
+        return split ? mlp_forward_multi_h2_impl(seg, 2, ct, s) : mlp_forward_multi_impl(seg, 2, ct, s);
     };
     mark(1, 0);
     int rc = fwd_pass(0);
@@ -1134,10 +1155,11 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
                 g[i].idx = ws + (k ? L.idx_bg : L.idx); g[i].idx_stride = 1; g[i].idx_is_float = batches[0].idx_is_float;
                 g[i].rows_per_ray = (int32_t)S; g[i].n_rows = D.C * D.N * S; g[i].rows_per_unit = (int32_t)S;
                 g[i].grad = M.grad;
-                seg[i].packed_fwd_dev = M.packed_dev; seg[i].packed_bwd_dev = M.packed_bwd_dev; seg[i].desc = &M.desc; seg[i].io = &g[i];
+                seg[i].packed_fwd_dev = split ? M.packed_h2_dev : M.packed_dev; seg[i].packed_bwd_dev = split ? M.packed_bwd_h2_dev : M.packed_bwd_dev;
+                seg[i].desc = &M.desc; seg[i].io = &g[i];
                 ct[i] = CellTable{tabs + i * C, D.N * S};
             }
-        rc = mlp_backward_chain_multi_impl(seg, 4, ct, s);
+        rc = split ? mlp_backward_chain_multi_h2_impl(seg, 4, ct, s) : mlp_backward_chain_multi_impl(seg, 4, ct, s);
         if (rc) return rc;
     }
     mark(5, 1);

@@ -19,6 +19,10 @@ struct CellTable {
 
 int mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
 int mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
+// split-precision forms (csrc/mlp_fwd_h2.hip, csrc/mlp_bwd_h2.hip): packed pointers = the (hi, lo) f16 images
+int h2_layout(const mnr_model_desc *d, ModelLayout &m);
+int mlp_forward_multi_h2_impl(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
+int mlp_backward_chain_multi_h2_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
 
 // sigma / rgb head weight gradients of several (tape, row range) jobs in ONE launch
 struct HeadJob {

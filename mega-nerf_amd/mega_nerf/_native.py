@@ -132,7 +132,7 @@ STEP_SPAN_NAMES = ('samples', 'fwd_c', 'mid', 'fwd_f', 'tail', 'bwd', 'head_grad
 class StepModel(C.Structure):
     """struct mnr_step_model"""
     _fields_ = [('desc', ModelDesc), ('grad', ModelGrads), ('adam_m', ModelGrads), ('adam_v', ModelGrads),
-                ('packed_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p)]
+                ('packed_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p), ('packed_h2_dev', C.c_void_p), ('packed_bwd_h2_dev', C.c_void_p)]
 
 
 class StepCfg(C.Structure):
@@ -140,14 +140,15 @@ class StepCfg(C.Structure):
     _fields_ = [('n_cells', C.c_int32), ('n_rays', C.c_int32), ('coarse_samples', C.c_int32), ('fine_samples', C.c_int32),
                 ('perturb', C.c_float), ('sigma_noise', C.c_int32), ('sphere_center', C.c_float * 3), ('sphere_radius', C.c_float * 3),
                 ('grad_floats_per_cell', C.c_int64), ('adam_beta1', C.c_float), ('adam_beta2', C.c_float), ('adam_eps', C.c_float),
-                ('t_coarse', c_float_p), ('t_bg_coarse', c_float_p), ('t_fine', c_float_p), ('t_bg_fine', c_float_p)]
+                ('t_coarse', c_float_p), ('t_bg_coarse', c_float_p), ('t_fine', c_float_p), ('t_bg_fine', c_float_p), ('split_precision', C.c_int32)]
 
 
 class StepLayout(C.Structure):
     """struct mnr_step_layout"""
     _fields_ = [('workspace_bytes', C.c_size_t), ('grad_offset', C.c_size_t), ('grad_stride', C.c_size_t), ('loss_offset', C.c_size_t),
                 ('rgb_offset', C.c_size_t), ('depth_var_offset', C.c_size_t), ('bg_lambda_offset', C.c_size_t),
-                ('n_bg_offset', C.c_size_t), ('err_offset', C.c_size_t)]
+                ('n_bg_offset', C.c_size_t), ('err_offset', C.c_size_t), ('tape_fg_offset', C.c_size_t), ('tape_bg_offset', C.c_size_t),
+                ('tape_fg_rows', C.c_int64), ('tape_bg_rows', C.c_int64), ('gtape_fg_offset', C.c_size_t), ('gtape_bg_offset', C.c_size_t)]
 
 
 class StepBatch(C.Structure):
@@ -186,7 +187,7 @@ EXPORTS = [
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
-    'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd',
+    'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -303,6 +304,9 @@ def lib() -> C.CDLL:
         _lib.mnr_packed_model_h2_bytes.argtypes = [C.POINTER(ModelDesc)]
         _lib.mnr_pack_model_h2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
         _lib.mnr_mlp_forward_multi_h2.argtypes = [C.POINTER(MlpLaunch), C.c_int, C.c_void_p]
+        _lib.mnr_packed_bwd_h2_bytes.restype = C.c_size_t
+        _lib.mnr_packed_bwd_h2_bytes.argtypes = [C.POINTER(ModelDesc)]
+        _lib.mnr_pack_model_bwd_h2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(ModelDesc), C.c_void_p]
         _lib.mnr_render_workspace_bytes.restype = C.c_size_t
         _lib.mnr_render_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
         _lib.mnr_render_fwd.argtypes = [C.POINTER(RenderIO), C.c_void_p]

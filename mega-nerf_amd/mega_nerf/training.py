@@ -739,7 +739,7 @@ class FusedTrainStep:
     parameter is that step's gradient (a view into the step's workspace)."""
 
     def __init__(self, cells, hparams: Namespace, sphere_center, sphere_radius, n_rays: int, lr: float = 5e-4,
-                 lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None):
+                 lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None, split_precision: bool = False):
         lib = N.lib()
         self.cells = [(f, b) for f, b in cells]
         assert 1 <= len(self.cells) <= N.MNR_STEP_MAX_CELLS
@@ -760,6 +760,9 @@ class FusedTrainStep:
             cfg.sphere_center[i], cfg.sphere_radius[i] = c[i], r[i]
         cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
         cfg.t_coarse, cfg.t_bg_coarse, cfg.t_fine, cfg.t_bg_fine = [t.ctypes.data_as(N.c_float_p) for t in self._tables]
+        # opt-in: tape-writing forward + data-gradient chain on the 16-bit matrix pipe with split-precision operands
+        cfg.split_precision = 1 if split_precision else 0
+        self.split_precision = bool(split_precision)
         # gradient area of a cell: every parameter of its fg model, then of its bg model, each padded to 16 bytes
         def sizes(m):
             return [(k, p, (p.numel() + 3) // 4 * 4) for k, p in m.named_parameters()]
@@ -791,9 +794,14 @@ class FusedTrainStep:
                     views[2][name] = self.adam_v[ci, o:o + p.numel()].view(p.shape)
                     o += n
                 sm.grad, sm.adam_m, sm.adam_v = m.grad_struct(views[0]), m.grad_struct(views[1]), m.grad_struct(views[2])
-                pk = torch.empty(lib.mnr_packed_model_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
-                pb = torch.empty(lib.mnr_packed_bwd_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
-                sm.packed_dev, sm.packed_bwd_dev = pk.data_ptr(), pb.data_ptr()
+                if split_precision:
+                    pk = torch.empty(lib.mnr_packed_model_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                    pb = torch.empty(lib.mnr_packed_bwd_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                    sm.packed_h2_dev, sm.packed_bwd_h2_dev = pk.data_ptr(), pb.data_ptr()
+                else:
+                    pk = torch.empty(lib.mnr_packed_model_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                    pb = torch.empty(lib.mnr_packed_bwd_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
+                    sm.packed_dev, sm.packed_bwd_dev = pk.data_ptr(), pb.data_ptr()
                 self._packed.append((pk, pb))
                 self.grad_views.append(views[0])
         self._models = models
@@ -812,7 +820,10 @@ class FusedTrainStep:
     def __del__(self):
         plan = getattr(self, '_plan', None)
         if plan is not None and plan.value:
-            N.lib().mnr_step_destroy(plan)
+            try:
+                N.lib().mnr_step_destroy(plan)
+            except Exception:          # interpreter shutdown: the module globals may be gone already
+                pass
             self._plan = None
 
     def profile(self, n_slots: int) -> None:

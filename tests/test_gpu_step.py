@@ -241,3 +241,130 @@ def test_fused_render_benchmark_shape_all_rays():
     with torch.no_grad():
         res2, present2 = render_rays(fg, bg, inside, T(idx.astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
     assert not present2 and float(res2['bg_rgb_fine'].abs().max()) == 0.0 and np.isfinite(res2['rgb_fine'].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_fused_step_gradients_against_fp64_with_the_kernels_own_relu_masks(split):
+    """The tight gradient check of tests/test_gpu_parity.py on the fused step -- fp32 kernels and the opt-in split-precision
+    forward / data-gradient chain: mnr_train_step on the reference's captured random draws against an fp64 restatement of the
+    whole render that is handed the ReLU masks found on the step's own activation tapes; every parameter gradient within 2e-4 of
+    its tensor's scale (+ twice a plain fp32 CPU evaluation's error: the two background sigma-head tensors)."""
+    import fp64_ref
+    from mega_nerf import _native as N
+    from mega_nerf.training import FusedTrainStep
+    from oracle import torch_oracle as TO
+    from test_gpu_parity import _MaskedTorchNeRF
+    from test_oracle_golden import build_case
+    name = 'render_fgbg_train'
+    g = load(name)
+    hp, nerf, bg_nerf = native_models(name)
+    _, onerf, obg = build_case(name)
+    s = common.SCENE
+    hpn = Namespace(**vars(hp))
+    n = g['rays'].shape[0]
+    step = FusedTrainStep([(nerf, bg_nerf)], hpn, T(s['sphere_center']), T(s['sphere_radius']), n, split_precision=split)
+    loss, n_bg, err = step([(T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target']))], _randoms=[_randoms_of(g)], optimize=False)
+    torch.cuda.synchronize()
+    nb = int(n_bg[0])
+    lay, lib = step.layout, N.lib()
+    wsf = step.workspace.view(torch.float32)
+    Nc, Nf = hp.coarse_samples, hp.fine_samples
+    queues = {}
+    for tag, m, off, rows, units, Sc, Sf in (('bg', bg_nerf, lay.tape_bg_offset, lay.tape_bg_rows, nb, Nc // 2, Nf // 2),
+                                             ('fg', nerf, lay.tape_fg_offset, lay.tape_fg_rows, n, Nc, Nf)):
+        desc = m.model_desc()
+        tape = wsf[off // 4:off // 4 + rows * m.tape_floats_per_row()]
+        queues[tag] = [fp64_ref.tape_masks(lib, m, desc, tape, rows, 0, units * Sc), fp64_ref.tape_masks(lib, m, desc, tape, rows, n * Sc, units * Sf)]
+
+    def restate(dtype):
+        torch.set_default_dtype(dtype)
+        try:
+            w = {t: {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in om.params.items()} for t, om in (('fg', onerf), ('bg', obg))}
+            q = {t: [dict(act=list(m_['act']), dact=m_['dact']) for m_ in queues[t]] for t in queues}
+            fgm, bgm = _MaskedTorchNeRF(onerf.cfg, w['fg'], q['fg'], dtype), _MaskedTorchNeRF(obg.cfg, w['bg'], q['bg'], dtype)
+            rr = {k[4:]: torch.from_numpy(v).to(dtype) for k, v in g.items() if k.startswith('rnd_')}
+            out = TO.render_rays(fgm, bgm, torch.from_numpy(g['rays']).to(dtype), torch.from_numpy(g['idx']), hp,
+                                 torch.from_numpy(s['sphere_center']).to(dtype), torch.from_numpy(s['sphere_radius']).to(dtype), randoms=rr)
+            torch.nn.functional.mse_loss(out['rgb_fine'], torch.from_numpy(g['target']).to(dtype)).backward()
+            return out, w
+        finally:
+            torch.set_default_dtype(torch.float32)
+    r64, w64 = restate(torch.float64)
+    r32, w32 = restate(torch.float32)
+    np.testing.assert_allclose(step.rgb[0].cpu().numpy(), r64['rgb_fine'].detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(step.rgb[0].cpu().numpy(), g['res_rgb_fine'], rtol=1e-4, atol=2e-5)
+    worst = {}
+    for k, (tag, m) in enumerate((('fg', nerf), ('bg', bg_nerf))):
+        for pn, gv in step.grad_views[k].items():
+            ref = w64[tag][pn].grad.numpy()
+            worst['%s.%s' % (tag, pn)] = (fp64_ref.rel_to_scale(gv.cpu().numpy(), ref), fp64_ref.rel_to_scale(w32[tag][pn].grad.numpy(), ref))
+    print('split' if split else 'fp32', {k: 'hip %.1e cpu-fp32 %.1e' % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v[0] <= 2e-4 + 2 * v[1]}
+    assert not bad, bad
+    assert sum(v[0] > 2e-4 for v in worst.values()) <= 2, worst
+    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)))
+
+
+def test_split_precision_step_trains_like_the_fp32_step():
+    """Six optimisation steps (eval-mode models: deterministic render) of the split-precision step against the fp32 step: same
+    loss trajectory to 2e-5, and two cells in one split-precision plan behave like lone cells."""
+    from mega_nerf.training import FusedTrainStep
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    traj = []
+    for split in (False, True):
+        hp, nerf, bg_nerf = native_models('render_fgbg_train')
+        nerf.eval(), bg_nerf.eval()
+        step = FusedTrainStep([(nerf, bg_nerf)], Namespace(**vars(hp)), sc, sr, rays.shape[0], split_precision=split)
+        traj.append([float(step([(rays, idx, tgt)])[0][0]) for _ in range(6)])
+    np.testing.assert_allclose(traj[1], traj[0], rtol=2e-5)
+    assert traj[1][-1] < traj[1][0]
+    cells = [_cell(sd, 128) for sd in (41, 42)]
+    hpn = Namespace(**vars(cells[0][0]))
+    joint = FusedTrainStep([(c[1], c[2]) for c in cells], hpn, sc, sr, 128, seed=9, split_precision=True)
+    lj, nbj, _ = joint([c[3] for c in cells], optimize=False)
+    torch.cuda.synchronize()
+    for i, c in enumerate([_cell(sd, 128) for sd in (41, 42)]):
+        lone = FusedTrainStep([(c[1], c[2])], hpn, sc, sr, 128, seed=9 + i, split_precision=True)
+        l1, nb1, _ = lone([c[3]], optimize=False)
+        torch.cuda.synchronize()
+        assert int(nb1[0]) == int(nbj[i])
+        np.testing.assert_allclose(float(lj[i]), float(l1[0]), rtol=2e-6)
+        np.testing.assert_array_equal(joint.rgb[i].cpu().numpy(), lone.rgb[0].cpu().numpy())
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_fused_step_at_the_reference_default_sample_counts(split):
+    """256 + 512 samples per ray (opts.py:32-35; the other instantiation of the ray-stage kernels: 12 / 6 merged samples per lane):
+    one fused step on eval-mode models (deterministic render) against the stage-by-stage path -- loss, colours, gradients."""
+    from mega_nerf.rendering import render_rays
+    from mega_nerf.training import FusedTrainStep
+    name = 'render_default_samples_eval'
+    g = load(name)
+    s = common.SCENE
+    rays, idx = T(g['rays']), T(g['idx'].astype(np.int32))
+    tgt = T(np.random.default_rng(3).uniform(0, 1, (rays.shape[0], 3)).astype(f32))
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    hp, nerf, bg_nerf = native_models(name)
+    hpn = Namespace(**vars(hp))
+    assert (hp.coarse_samples, hp.fine_samples) == (256, 512)
+    res, _ = render_rays(nerf, bg_nerf, rays, idx, hpn, sc, sr, False, True, False)
+    loss = torch.nn.functional.mse_loss(res['rgb_fine'], tgt)
+    loss.backward()
+    ref = _grads((('fg', nerf), ('bg', bg_nerf)))
+    hp, n2, b2 = native_models(name)
+    step = FusedTrainStep([(n2, b2)], hpn, sc, sr, rays.shape[0], split_precision=split)
+    l2, n_bg, err = step([(rays, idx, tgt)], optimize=False)
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    np.testing.assert_allclose(float(l2[0]), float(loss.detach()), rtol=2e-5 if split else 2e-6)
+    a, b = step.rgb[0].cpu().numpy(), res['rgb_fine'].detach().cpu().numpy()
+    if split:
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5)
+    else:
+        np.testing.assert_array_equal(a, b)
+        got = _grads((('fg', n2), ('bg', b2)))
+        worst = {k: float(np.abs(got[k] - ref[k]).max()) / max(float(np.abs(ref[k]).max()), 1e-30) for k in ref}
+        assert max(worst.values()) < 2e-5, {k: v for k, v in worst.items() if v >= 2e-5}
