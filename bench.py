@@ -292,6 +292,8 @@ def main():
                     help='MLP width (256 = the headline Rubble config; 512 = configs/mega-nerf Building: layer-by-layer tiled GEMM path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the N = 1 side measurements and the PSNR check')
+    ap.add_argument('--only-split-extras', action='store_true',
+                    help='of the side measurements keep the split-precision ones only (profiling runs of the k_mlp_*_h2 kernels)')
     ap.add_argument('--container', type=int, default=0, metavar='N',
                     help='eval mode only: render through a merged N-cell container (MegaNeRF router, boundary_margin 1.15) '
                          'instead of one submodule -- the "8-submodule Rubble" evaluation shape on ONE GPU')
@@ -528,19 +530,20 @@ def main():
                 'step_spans_ms': {k: round(sum(d_[k] for d_ in sp) / len(sp), 4) for k in sp[0]}}
             del fs
             fgm.eval(), bgm.eval()
-        hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
-        extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
-        fgm.train(), bgm.train()
-        ts_ref = TrainStep(fgm, bgm, hp_ref, sc, sr)
-        extras['train_rays_per_sec_256+512_samples'] = args.rays / timed(lambda: ts_ref(*w['batch']), 5, 4)     # (warm-up: 16 GB of tapes to allocate)
-        del ts_ref
-        # north-star PSNR check, GPU half (the CPU half runs inside cpu_baseline)
-        prob = psnr_problem(hp, all_rays.cpu().numpy())
-        psnr_here, tgt_train, tgt_test = psnr_gpu(hp, prob, dev)
-        extras['_psnr_job'] = (prob, tgt_train, tgt_test)
-        extras['psnr'] = {'student_vs_teacher_db': round(psnr_here, 4),
-                          'protocol': '%d Adam steps of %d rays (training mode: jitter + sigma noise, identical random numbers on both sides), '
-                                      'PSNR of %d held-out rays against a fixed teacher field' % (PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS)}
+        if not args.only_split_extras:
+            hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
+            extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)
+            fgm.train(), bgm.train()
+            ts_ref = TrainStep(fgm, bgm, hp_ref, sc, sr)
+            extras['train_rays_per_sec_256+512_samples'] = args.rays / timed(lambda: ts_ref(*w['batch']), 5, 4)     # (warm-up: 16 GB of tapes to allocate)
+            del ts_ref
+            # north-star PSNR check, GPU half (the CPU half runs inside cpu_baseline)
+            prob = psnr_problem(hp, all_rays.cpu().numpy())
+            psnr_here, tgt_train, tgt_test = psnr_gpu(hp, prob, dev)
+            extras['_psnr_job'] = (prob, tgt_train, tgt_test)
+            extras['psnr'] = {'student_vs_teacher_db': round(psnr_here, 4),
+                              'protocol': '%d Adam steps of %d rays (training mode: jitter + sigma noise, identical random numbers on both sides), '
+                                          'PSNR of %d held-out rays against a fixed teacher field' % (PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS)}
 
     if rank == 0:
         total_rays = args.rays * args.steps * total_cells

@@ -350,6 +350,12 @@ typedef struct mnr_wgrad_region {
 size_t mnr_wgrad_workspace_bytes(void);
 int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev, size_t workspace_bytes,
                                    void *stream);
+/* The same weight gradients on the 16-bit matrix pipe (opt-in, csrc/wgrad.hip H2 path): both operands of every product split into
+ * f16 (hi, lo) halves on the fly, three v_mfma_f32_32x32x16_f16 products per block, fp32 accumulation; every dZ plane is scaled by a
+ * power of two first (found by one extra pass over the plane here; the fused split-precision step -- mnr_train_step -- gets the
+ * exponents from its data-gradient chain).  Same arguments, workspace and results (within fp32 rounding of the sums) as above. */
+int mnr_mlp_backward_weights_multi_h2(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev, size_t workspace_bytes,
+                                      void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Volume rendering stages -- mega_nerf/rendering.py

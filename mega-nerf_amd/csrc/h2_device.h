@@ -102,6 +102,13 @@ struct H2Stream {
     const uint4v *g;
     uint4v *lds;
     int cur;
+    float one;                       // 1.0f behind an opaque asm (h2_split8)
+    __device__ __forceinline__ void init(const uint4v *chunks, uint4v *ring) {
+        g = chunks; lds = ring; cur = 1;
+        one = 1.0f;
+        asm volatile("" : "+s"(one));
+        issue();
+    }
     __device__ __forceinline__ void issue() {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint4v *dst = lds + (cur ^ 1) * H2_CHUNK_U4 + wave * 64;
@@ -122,17 +129,18 @@ struct H2Stream {
     }
 };
 
-__device__ __forceinline__ void h2_split8(const float (&x)[8], uint4v &hi, uint4v &lo) {
-    float h[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = __uint_as_float(__float_as_uint(x[j]) & 0xffffe000u);
-        l[j] = x[j] - h[j];
-    }
+// x = hi + lo, both f16: hi = x rounded towards zero (v_cvt_pkrtz, two values per instruction), lo = x - hi (exact in fp32) by ONE
+// mixed-precision FMA that reads hi as f16 straight out of its packed half (v_fma_mix_f32  x * one - hi; `one` is 1.0f the compiler
+// cannot see, or it folds the product away and emits a conversion plus a subtraction): 2 VALU instructions per value (and + sub +
+// 2 x half a pack: 3), and the subtraction accounts for whatever the conversion dropped (f16 subnormals included).
+__device__ __forceinline__ void h2_split8(const float (&x)[8], uint4v &hi, uint4v &lo, float one) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        hi[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2 * q], h[2 * q + 1]));
-        lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2 * q], l[2 * q + 1]));
+        const auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+        const float l0 = __builtin_fmaf(x[2 * q], one, -(float)h[0]);
+        const float l1 = __builtin_fmaf(x[2 * q + 1], one, -(float)h[1]);
+        hi[q] = __builtin_bit_cast(unsigned, h);
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
     }
 }
 
@@ -142,6 +150,9 @@ __device__ __forceinline__ floatx4 h2_mfma(uint4v a, uint4v b, floatx4 c) {
 
 // One segment of a layer: NK K-steps whose B operands are src[0 .. NSRC) (zero beyond); K0 = index of the segment's first K-step
 // inside the layer (chunk boundaries are static: a new chunk every SPC K-steps, the first at K-step 0 of the layer).
+#ifndef H2_FRAG_GROUP
+#define H2_FRAG_GROUP 4
+#endif
 template <int NOB, int NK, int K0, int NSRC>
 __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane) {
     constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64);
@@ -152,19 +163,21 @@ __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&sr
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (8 * kl + j < NSRC) ? src[(8 * kl + j < NSRC) ? 8 * kl + j : 0] : 0.f;
         uint4v bh, bl;
-        h2_split8(x, bh, bl);
+        h2_split8(x, bh, bl, st.one);
         const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
+        constexpr int G = H2_FRAG_GROUP;
+        static_assert(NOB % G == 0, "output blocks per fragment group");
 #pragma unroll
-        for (int o0 = 0; o0 < NOB; o0 += 4) {
-            uint4v ah[4], al[4];
+        for (int o0 = 0; o0 < NOB; o0 += G) {
+            uint4v ah[G], al[G];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) { ah[o] = p[((o0 + o) * 2) * 64]; al[o] = p[((o0 + o) * 2 + 1) * 64]; }
+            for (int o = 0; o < G; ++o) { ah[o] = p[((o0 + o) * 2) * 64]; al[o] = p[((o0 + o) * 2 + 1) * 64]; }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(al[o], bh, acc[o0 + o]);
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(al[o], bh, acc[o0 + o]);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
         }
     });
 }

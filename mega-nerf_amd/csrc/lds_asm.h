@@ -22,6 +22,19 @@ __device__ __forceinline__ floatx4 lds_ld4(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+// eight words OFF0, OFF0 + STRIDE, ... and the wait for them in ONE statement: the results are valid when the compiler sees them, so it
+// may move or spill them freely (the split-precision weight-gradient path: its accumulators leave no register to spare, and a
+// compiler-inserted copy of a register whose ds_read is still in flight would copy the old content)
+template <int OFF0, int STRIDE>
+__device__ __forceinline__ void lds_ld8_wait(unsigned addr, float (&v)[8]) {
+    asm volatile("ds_read_b32 %0, %8 offset:%9\n\tds_read_b32 %1, %8 offset:%10\n\tds_read_b32 %2, %8 offset:%11\n\tds_read_b32 %3, %8 offset:%12\n\t"
+                 "ds_read_b32 %4, %8 offset:%13\n\tds_read_b32 %5, %8 offset:%14\n\tds_read_b32 %6, %8 offset:%15\n\tds_read_b32 %7, %8 offset:%16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(addr), "n"(OFF0), "n"(OFF0 + STRIDE), "n"(OFF0 + 2 * STRIDE), "n"(OFF0 + 3 * STRIDE), "n"(OFF0 + 4 * STRIDE),
+                   "n"(OFF0 + 5 * STRIDE), "n"(OFF0 + 6 * STRIDE), "n"(OFF0 + 7 * STRIDE)
+                 : "memory");
+}
 __device__ __forceinline__ int lds_ld_i(unsigned addr) {
     int v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");

@@ -26,8 +26,19 @@ __device__ __forceinline__ void gtape_store_scaled(const float (&g)[NH], float i
 // the split operands end at 2^-24 of the scaled row maximum -- so the scale follows the row (g *= 2^-e, e = exponent of the row's
 // largest |g|; E accumulates the exponents, scale_dn = 2^E).  Exact (powers of two); ~100 VALU operations per layer and lane
 // beside 384 matrix instructions.
+// publish a plane's row exponent (E + ZEXP_BIAS, 0 for rows without data): largest over the wavefront, one atomic max per wavefront
+// and plane, skipped when the published value is already as large (after the first workgroups: nearly always)
+__device__ __forceinline__ void zexp_publish(int32_t *zexp, int plane, int E, bool has_data) {
+    if (!zexp) return;
+    int v = has_data ? E + ZEXP_BIAS : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(zexp + plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(zexp + plane, v);
+}
+
 template <int NH>
-__device__ __forceinline__ void h2_renorm(float (&g)[NH], int &E, float &scale_dn) {
+__device__ __forceinline__ bool h2_renorm(float (&g)[NH], int &E, float &scale_dn) {
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < NH; ++i) mx = fmaxf(mx, fabsf(g[i]));
@@ -42,6 +53,7 @@ __device__ __forceinline__ void h2_renorm(float (&g)[NH], int &E, float &scale_d
 #pragma unroll
     for (int i = 0; i < NH; ++i) g[i] *= up;
     scale_dn = ldexpf(1.f, E);
+    return usable;
 }
 
 template <class C>
@@ -55,6 +67,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
     const uint4v *chunks = reinterpret_cast<const uint4v *>(a.chunks);
     const float *aux = a.aux;
     float *d_emb_a = a.d_emb_a;
+    int32_t *zexp = nullptr;
     if (a.dcells) {
         const MlpCellSeg cell = a.dcells[cidx];
         n_rows = cell.n_units ? (long)__builtin_amdgcn_readfirstlane(*cell.n_units) * a.rows_per_unit : a.cell_rows;
@@ -64,6 +77,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         d_emb_a = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(cell.d_emb_a))));
         row_base = (long)cidx * a.cell_rows;
         tape_row0 = uniform_long(cell.tape_row0);
+        zexp = reinterpret_cast<int32_t *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(cell.zexp))));
     } else {
         n_rows = a.n_units_dev ? (long)(*a.n_units_dev) * a.rows_per_unit : a.n_rows;
         if (blk * H2_ROWS >= n_rows) return;
@@ -78,10 +92,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
     const long trow = lrc + tape_row0;
 
     H2Stream st;
-    st.g = chunks;
-    st.lds = h2_ring;
-    st.cur = 1;
-    st.issue();
+    st.init(chunks, h2_ring);
 
     // ---- output activations backward (as mlp_bwd_body) ----
     float dr[3], ds;
@@ -133,10 +144,10 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         E = usable ? e : 0;
         scale_up = ldexpf(1.f, -E);
         scale_dn = ldexpf(1.f, E);
+        zexp_publish(zexp, C::NL + 1, E, usable && valid);
 #pragma unroll
         for (int i = 0; i < H2; ++i) dd[i] *= scale_up;
     }
-    const float ds_s = ds * scale_up;
     // ---- dir_a^T: d(final features) and d(appearance embedding) ----
     float g[H];
     {
@@ -171,6 +182,8 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         }
     }
     // ---- final^T (+ sigma head): dZ of trunk layer L-1 ----
+    { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, C::NL, E, live && valid); }
+    const float ds_s = ds * ldexpf(1.f, -E);          // fp32 accumulator initialiser: may exceed 1, never touches f16
     floatx4 acc[NOB];
     {
         const float *ws = aux + a.sigma_off + part * H;
@@ -184,7 +197,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         h2_segment<NOB, H / 8, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
-        h2_renorm(g, E, scale_dn);
+        { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, C::NL - 1, E, live && valid); }
     }
     // ---- trunk layers L-1 .. 1 transposed ----
     static_for<0, C::NL - 1>([&](auto jc) {
@@ -195,7 +208,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         h2_segment<NOB, H / 8, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
-        h2_renorm(g, E, scale_dn);
+        { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, l - 1, E, live && valid); }
     });
     gtape_store_scaled<P>(g, scale_dn, a.gtape + a.tl.act_off[0] * cap + trow * W, part, valid);
 }

@@ -49,7 +49,12 @@ struct MlpCellSeg {
     float *d_emb_a;            // ... and that table's gradient (data-gradient chain only)
     long tape_row0;            // tape row of the cell's first row of this pass
     const int32_t *n_units;    // device-side unit count of the cell (compacted background rays) or NULL
+    int32_t *zexp;             // split-precision step: per-plane exponents of the model's gradient tape (ZEXP_* below) or NULL
 };
+// Split-precision weight gradients scale every dZ plane by a power of two before its f16 split (gradients of 1e-6 .. 1e-12 are below
+// the f16 range).  The split-precision data-gradient chain publishes, per plane, the largest row exponent it saw (row max < 2^E)
+// as E + ZEXP_BIAS by atomic max; 0 = nothing seen.  Planes: trunk layer l -> l, final -> layers, dir_a -> layers + 1.
+constexpr int ZEXP_BIAS = 1024, ZEXP_PLANES = 16, ZEXP_TARGET = 14;
 
 // ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
 // `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at

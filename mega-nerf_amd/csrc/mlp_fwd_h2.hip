@@ -77,10 +77,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
     const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * H2_WAVES + wave) * 16 + tape_row0));
 
     H2Stream st;
-    st.g = chunks;
-    st.lds = h2_ring;
-    st.cur = 1;
-    st.issue();
+    st.init(chunks, h2_ring);
 
     float x[C::XYZ];
 #pragma unroll

@@ -957,6 +957,8 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
                 const long cap = k == 0 ? D.cap_f : D.cap_b, first = k == 0 ? D.N * D.Nc : D.N * D.Sb;
                 e.tape_row0 = (long)c * cap + (pass ? first : 0);
                 e.n_units = k == 0 ? nullptr : reinterpret_cast<const int32_t *>(ws + L.scal) + c;
+                // exponent words of the model's gradient-tape planes: ints 32.. (fg) / 48.. (bg) of the cell's zeroed control block
+                e.zexp = split ? reinterpret_cast<int32_t *>(ws + L.wcount + (size_t)c * 256) + 32 + 16 * k : nullptr;
             }
         }
     }
@@ -1198,8 +1200,10 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         rg[1].row0[0] = c * D.cap_b; rg[1].n_rows[0] = D.N * D.Sb; rg[1].n_units_dev[0] = scal + c; rg[1].rows_per_unit[0] = (int32_t)D.Sb;
         rg[1].row0[1] = c * D.cap_b + D.N * D.Sb; rg[1].n_rows[1] = D.N * D.Sfb; rg[1].n_units_dev[1] = scal + c; rg[1].rows_per_unit[1] = (int32_t)D.Sfb;
         rg[1].grad = Mb.grad;
-        rc = wgrad_regions_launch(rg, 2, reinterpret_cast<int32_t *>(ws + L.wcount + (size_t)c * 256),
-                                  reinterpret_cast<int32_t *>(ws + L.ep_job + (size_t)c * wgrad_ep_job_bytes()), F(L.slab), s);
+        int32_t *ctl = reinterpret_cast<int32_t *>(ws + L.wcount + (size_t)c * 256);
+        const int32_t *zexp[2] = {ctl + 32, ctl + 48};
+        rc = wgrad_regions_launch(rg, 2, ctl, reinterpret_cast<int32_t *>(ws + L.ep_job + (size_t)c * wgrad_ep_job_bytes()), F(L.slab), s,
+                                  split && !getenv("MNR_STEP_F32_WGRAD") ? zexp : nullptr);
         if (rc) return rc;
     }
     mark(7, 1);

@@ -40,7 +40,7 @@ int head_job_of(const mnr_model_desc *d, const mnr_mlp_grad_io *io, HeadJob &job
 // weight gradients with caller-placed control words (so that the step's single memset can clear them): as
 // mnr_mlp_backward_weights_multi, but counters_dev (256 bytes, ZEROED by the caller), ep_job_dev and slab_dev are separate
 int wgrad_regions_launch(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,
-                         hipStream_t s);
+                         hipStream_t s, const int32_t *const *zexp = nullptr);
 size_t wgrad_ep_job_bytes();
 size_t wgrad_slab_bytes();
 

@@ -128,6 +128,7 @@ struct WJob {
     int16_t shape, region;
     int32_t tiles_per_item;
     int32_t red_block0;             // first block of this job in the reduce launch
+    const int32_t *zexp;            // split-precision launches: exponent word of the dz plane (mlp_device.h ZEXP_*), else NULL
 };
 struct WArgs {
     WJob job[W2_MAX_JOBS];
@@ -156,7 +157,27 @@ struct WCtl {                        // LDS control area layout (word offsets)
 
 // ---- one (workgroup, job) episode ------------------------------------------------------------------------------------
 // Processes `item` and every further item of job j this workgroup manages to pull; flushes once.
-template <class S>
+typedef _Float16 half8w __attribute__((ext_vector_type(8)));
+typedef unsigned uint4w __attribute__((ext_vector_type(4)));
+// x * scale = hi + lo as packed f16 (csrc/h2_device.h h2_split8: round-towards-zero pack, remainder by one mixed-precision FMA)
+__device__ __forceinline__ void w2_split8(const float (&x)[8], float scale, uint4w &hi, uint4w &lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * q] * scale, x[2 * q + 1] * scale);
+        const float l0 = __builtin_fmaf(x[2 * q], scale, -(float)h[0]);
+        const float l1 = __builtin_fmaf(x[2 * q + 1], scale, -(float)h[1]);
+        hi[q] = __builtin_bit_cast(unsigned, h);
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+    }
+}
+__device__ __forceinline__ floatx16 w2_mfma(uint4w a, uint4w b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8w, a), __builtin_bit_cast(half8w, b), c, 0, 0, 0);
+}
+
+// H2 = split-precision form (opt-in): the same tiles, schedule and flush; a tile's 32 rows are two K-steps of
+// v_mfma_f32_32x32x16_f16, both operands split into f16 (hi, lo) halves on the fly -- three products per block, fp32 accumulate --,
+// dZ pre-scaled by the plane's power of two (WJob::zexp; undone at the flush).  The kernel is then bound by the tape stream (HBM).
+template <class S, bool H2 = false>
 __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, float *lds_all) {
     constexpr int M = S::M, MBW = S::MBW, NBW = S::NBW, KS = S::KS;
     const WJob &J = a.job[j];
@@ -172,6 +193,12 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
     const int tiles0 = lds_ld_u(ctl + 4 * (WCtl::TILES0 + j));
     const int tiles_all = lds_ld_u(ctl + 4 * (WCtl::TILES + j));
     const int tpi = J.tiles_per_item;
+    float zscale = 1.f, zdescale = 1.f, one = 1.f;
+    if constexpr (H2) {
+        const int zb = J.zexp ? __builtin_amdgcn_readfirstlane(*J.zexp) : 0;
+        if (zb > 0) { zscale = ldexpf(1.f, ZEXP_TARGET + ZEXP_BIAS - zb); zdescale = ldexpf(1.f, zb - ZEXP_BIAS - ZEXP_TARGET); }
+        asm volatile("" : "+s"(one));
+    }
 
     floatx16 acc[MBW][NBW];
 #pragma unroll
@@ -274,50 +301,92 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
         unsigned bb[S::NSEG];
 #pragma unroll
         for (int sg = 0; sg < S::NSEG; ++sg) bb[sg] = sb + b_off[sg];
-        float af[2][MBW], bf[2][NBW];
-        constexpr int KP = W2_KT / 2 / KS;      // k-pairs per wave per tile (the KS wave groups interleave k-pairs)
-        auto frag_read = [&](auto kpc, auto bufc) {
-            constexpr int kp = decltype(kpc)::value, buf = decltype(bufc)::value;
-            static_for<0, MBW>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                af[buf][m] = lds_ld<((2 * kp * KS) * M) * 4>(ab[m]);
+        if constexpr (H2) {
+            // lane (i32, kk) of a fragment: feature i32 of its block, tile rows 16 (q KS + ks) + 8 kk + j, j = 0..7 (consecutive k)
+            constexpr int NQ = W2_KT / 16 / KS;
+            unsigned ab2[MBW], bb2[S::NSEG];
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) ab2[m] = ab[m] + (unsigned)(((14 * ks + 7 * kk) * M) * 4);          // (2 ks + kk) -> (16 ks + 8 kk)
+#pragma unroll
+            for (int sg = 0; sg < S::NSEG; ++sg) bb2[sg] = bb[sg] + (unsigned)(((14 * ks + 7 * kk) * S::LD[sg]) * 4);
+            static_for<0, S::PIECES>([&](auto pc) { dma_piece(pc, q, s ^ 1); });
+            static_for<0, NQ>([&](auto qc) {
+                constexpr int kq = decltype(qc)::value;
+                // dZ fragments of the K-step: all MBW row blocks, split once (they meet every input block).  Every fragment is read
+                // and waited for in one statement (lds_asm.h lds_ld8_wait); the co-resident wavefront covers the LDS latency, and
+                // the kernel has HBM time to spare.
+                uint4w ah[MBW], al[MBW];
+                static_for<0, MBW>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    float ar[8];
+                    lds_ld8_wait<(16 * kq * KS * M) * 4, M * 4>(ab2[m], ar);
+                    if constexpr (m == 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) bsum += ar[jj];           // bias gradient: fp32, unscaled (fragment 0 only, see below)
+                    }
+                    w2_split8(ar, zscale, ah[m], al[m]);
+                });
+                static_for<0, NBW>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int sg = S::GN > 1 ? 0 : S::seg_of(n), nl = S::GN > 1 ? n : n - S::nb0_of(sg);
+                    float br[8];
+                    lds_ld8_wait<(16 * kq * KS * S::LD[sg] + nl * 32) * 4, S::LD[sg] * 4>(bb2[sg], br);
+                    uint4w bh, bl;
+                    w2_split8(br, one, bh, bl);
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) {
+                        acc[m][n] = w2_mfma(ah[m], bh, acc[m][n]);
+                        acc[m][n] = w2_mfma(al[m], bh, acc[m][n]);
+                        acc[m][n] = w2_mfma(ah[m], bl, acc[m][n]);
+                    }
+                });
             });
-            static_for<0, NBW>([&](auto nc) {
-                constexpr int n = decltype(nc)::value;
-                constexpr int sg = S::GN > 1 ? 0 : S::seg_of(n), nl = S::GN > 1 ? n : n - S::nb0_of(sg);
-                bf[buf][n] = lds_ld<((2 * kp * KS) * S::LD[sg] + nl * 32) * 4>(bb[sg]);
+        } else {
+            float af[2][MBW], bf[2][NBW];
+            constexpr int KP = W2_KT / 2 / KS;      // k-pairs per wave per tile (the KS wave groups interleave k-pairs)
+            auto frag_read = [&](auto kpc, auto bufc) {
+                constexpr int kp = decltype(kpc)::value, buf = decltype(bufc)::value;
+                static_for<0, MBW>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    af[buf][m] = lds_ld<((2 * kp * KS) * M) * 4>(ab[m]);
+                });
+                static_for<0, NBW>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int sg = S::GN > 1 ? 0 : S::seg_of(n), nl = S::GN > 1 ? n : n - S::nb0_of(sg);
+                    bf[buf][n] = lds_ld<((2 * kp * KS) * S::LD[sg] + nl * 32) * 4>(bb[sg]);
+                });
+            };
+            // the whole next tile is requested up front (measured on the structural microbenchmark tools/micro/mfma_probe.hip:
+            // 147 vs 137 TFLOP/s for one piece per k-pair), so it has the full tile time to land
+            static_for<0, S::PIECES>([&](auto pc) { dma_piece(pc, q, s ^ 1); });
+            frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, KP>([&](auto kpc) {
+                constexpr int kp = decltype(kpc)::value;
+                constexpr int cur = kp & 1;
+                if constexpr (kp + 1 < KP) {
+                    frag_read(std::integral_constant<int, kp + 1>{}, std::integral_constant<int, cur ^ 1>{});
+                    wait_lgkm<MBW + NBW>();
+                } else {
+                    wait_lgkm<0>();
+                }
+    #pragma unroll
+                for (int m = 0; m < MBW; ++m) pin(af[cur][m]);
+    #pragma unroll
+                for (int n = 0; n < NBW; ++n) pin(bf[cur][n]);
+                // bias gradient = column sums of dZ: VALU adds between MFMAs cost MFMA issue slots (measured: one add per A
+                // fragment = -10 % on the 256 x 256 shape), so every wave sums only ONE of its MBW row blocks -- its fragment 0,
+                // which is row block (wc % MBW) of the wave row thanks to the rotated block order (the GN >= MBW wave columns
+                // of a wave row cover all blocks between them)
+    #pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    if (m == 0) bsum += af[cur][0];
+    #pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m], bf[cur][n], acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the software pipeline as written (reads one k-pair ahead)
             });
-        };
-        // the whole next tile is requested up front (measured on the structural microbenchmark tools/micro/mfma_probe.hip:
-        // 147 vs 137 TFLOP/s for one piece per k-pair), so it has the full tile time to land
-        static_for<0, S::PIECES>([&](auto pc) { dma_piece(pc, q, s ^ 1); });
-        frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, KP>([&](auto kpc) {
-            constexpr int kp = decltype(kpc)::value;
-            constexpr int cur = kp & 1;
-            if constexpr (kp + 1 < KP) {
-                frag_read(std::integral_constant<int, kp + 1>{}, std::integral_constant<int, cur ^ 1>{});
-                wait_lgkm<MBW + NBW>();
-            } else {
-                wait_lgkm<0>();
-            }
-#pragma unroll
-            for (int m = 0; m < MBW; ++m) pin(af[cur][m]);
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) pin(bf[cur][n]);
-            // bias gradient = column sums of dZ: VALU adds between MFMAs cost MFMA issue slots (measured: one add per A
-            // fragment = -10 % on the 256 x 256 shape), so every wave sums only ONE of its MBW row blocks -- its fragment 0,
-            // which is row block (wc % MBW) of the wave row thanks to the rotated block order (the GN >= MBW wave columns
-            // of a wave row cover all blocks between them)
-#pragma unroll
-            for (int m = 0; m < MBW; ++m) {
-                if (m == 0) bsum += af[cur][0];
-#pragma unroll
-                for (int n = 0; n < NBW; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m], bf[cur][n], acc[m][n], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);     // keep the software pipeline as written (reads one k-pair ahead)
-        });
+        }
         if (a.prof) { const long long c3 = __builtin_amdgcn_s_memtime(); pc_vm += c1 - c0; pc_bar += c2 - c1; pc_cmp += c3 - c2; pc_tiles += 1; }
         if (!have_next) break;
         t = t_next;
@@ -347,7 +416,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = ks * M + (wr * MBW + (m + bm) % MBW) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kkf;
-                    base[row * S::NP + col] = acc[m][n][r];
+                    base[row * S::NP + col] = H2 ? acc[m][n][r] * zdescale : acc[m][n][r];
                 }
             }
         }
@@ -373,7 +442,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (wr * MBW + (m + bm) % MBW) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kkf;
-                        atomicAdd(J.dw + (long)row * J.ldw + J.col0[sg] + col, acc[m][n][r]);
+                        atomicAdd(J.dw + (long)row * J.ldw + J.col0[sg] + col, H2 ? acc[m][n][r] * zdescale : acc[m][n][r]);
                     }
                 }
             }
@@ -394,7 +463,7 @@ __device__ __forceinline__ int wg_broadcast(unsigned word_addr, int v) {
 // FAMILY 0: the shapes of the fused models' tapes (mnr_mlp_backward_weights_multi); FAMILY 1: the job form of the layer-by-layer
 // path (mnr_wgrad_jobs).  Two kernels rather than one: with all eleven episode instantiations in one kernel the 256 x 256
 // shape ran 4 % slower (2.02 vs 1.94 ms on the benchmark step, same instruction mix -- code placement).
-template <int FAMILY>
+template <int FAMILY, bool H2 = false>
 __global__ __launch_bounds__(W2_THREADS, 2) void k_wgrad2(WArgs a) {
     extern __shared__ float lds_all[];
     const unsigned ctl = lds_addr(lds_all);
@@ -428,14 +497,14 @@ __global__ __launch_bounds__(W2_THREADS, 2) void k_wgrad2(WArgs a) {
         if (item < lds_ld_u(ctl + 4 * (WCtl::ITEMS + cur))) {
             if constexpr (FAMILY == 0) {
                 switch (a.job[cur].shape) {
-                    case WSI_BIG: wgrad_episode<WS_BIG>(a, cur, item, lds_all); break;
-                    case WSI_L0F: wgrad_episode<WS_L0F>(a, cur, item, lds_all); break;
-                    case WSI_L0B: wgrad_episode<WS_L0B>(a, cur, item, lds_all); break;
-                    case WSI_SKF: wgrad_episode<WS_SKF>(a, cur, item, lds_all); break;
-                    case WSI_DIR: wgrad_episode<WS_DIR>(a, cur, item, lds_all); break;
+                    case WSI_BIG: wgrad_episode<WS_BIG, H2>(a, cur, item, lds_all); break;
+                    case WSI_L0F: wgrad_episode<WS_L0F, H2>(a, cur, item, lds_all); break;
+                    case WSI_L0B: wgrad_episode<WS_L0B, H2>(a, cur, item, lds_all); break;
+                    case WSI_SKF: wgrad_episode<WS_SKF, H2>(a, cur, item, lds_all); break;
+                    case WSI_DIR: wgrad_episode<WS_DIR, H2>(a, cur, item, lds_all); break;
 #ifdef MNR_ALL_VARIANTS
-                    case WSI_DIR_NOAPP: wgrad_episode<WS_DIR_NOAPP>(a, cur, item, lds_all); break;
-                    case WSI_DIR_NODIR: wgrad_episode<WS_DIR_NODIR>(a, cur, item, lds_all); break;
+                    case WSI_DIR_NOAPP: wgrad_episode<WS_DIR_NOAPP, H2>(a, cur, item, lds_all); break;
+                    case WSI_DIR_NODIR: wgrad_episode<WS_DIR_NODIR, H2>(a, cur, item, lds_all); break;
 #endif
                     default: break;
                 }
@@ -543,6 +612,33 @@ __global__ __launch_bounds__(256) void k_wgrad2_reduce(WArgs a) {
     }
 }
 
+// Split-precision launches without exponents from the data-gradient chain (stand-alone use, tests): the exponent of every job's dZ
+// plane by one pass over it (one more read of the gradient tape; the fused step gets the exponents from k_mlp_bwd_h2 for free).
+__global__ __launch_bounds__(256) void k_wgrad_zexp(WArgs a, int32_t *__restrict__ slots) {
+    const int j = blockIdx.y;
+    const WJob &J = a.job[j];
+    const WRegion &R = a.region[J.region];
+    const int M = wshape_info(J.shape).M, q = M / 4;
+    const long ldz = M == 256 ? (long)J.ldz : (long)M;
+    float mx = 0.f;
+    for (int i = 0; i < R.n_ranges; ++i) {
+        const long rows = (long)range_tiles(R, i) * W2_KT;
+        const float *base = J.dz + R.row0[i] * ldz;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * q; e += (long)gridDim.x * 256) {
+            const long row = e / q;
+            const float4 v = *reinterpret_cast<const float4 *>(base + row * ldz + (e - row * q) * 4);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f && mx < 3.0e38f) {
+        int e = 0;
+        (void)frexpf(mx, &e);
+        atomicMax(slots + j, (e < -100 ? -100 : e) + ZEXP_BIAS);
+    }
+}
+
 static ArchDims arch_of2(const mnr_model_desc *d) {
     return ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim, d->appearance_dim,
                     d->rgb_dim, d->mfma_tile};
@@ -571,16 +667,18 @@ static double env_d(const char *k, double d) { const char *v = getenv(k); return
 
 // per-tile cost model (cycles per SIMD): MFMA time of the two co-resident waves vs LDS-DMA fill time, + a fixed
 // boundary term -> tiles per item so that items of all jobs cost about the same (~4 tiles of the 256 x 256 shape)
-static double wgrad_tile_cost(int shape) {
+static double wgrad_tile_cost(int shape, bool h2 = false) {
     const double dma_bpc = env_d("MNR_WGRAD_DMA_BPC", 10.0), fixed = env_d("MNR_WGRAD_FIXED", 600.0);
     const WShapeInfo si = wshape_info(shape);
-    const double mfma = (double)si.blocks_per_wave * (W2_KT / 2 / si.KS) * 64.0 * 2.0;     // two co-resident waves per SIMD
+    const double mfma = h2 ? (double)si.blocks_per_wave * (W2_KT / 16 / si.KS) * 3 * 32.0 * 2.0        // three 32-cycle products per block and K-step
+                           : (double)si.blocks_per_wave * (W2_KT / 2 / si.KS) * 64.0 * 2.0;     // two co-resident waves per SIMD
     const double dma = si.tile_bytes / dma_bpc;
     return (mfma > dma ? mfma : dma) + fixed;
 }
 
 // shared tail of the two entry points: reduce-block table, workspace carving, the two launches
-static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev, bool zero_counters, hipStream_t s, int family) {
+static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev, bool zero_counters, hipStream_t s, int family,
+                         bool h2 = false, bool zexp_pass = false) {
     wa.njobs = nj;
     {
         const int cap = (int)env_d("MNR_WGRAD_MAX_EPISODES", (double)W2_MAX_EPISODES);
@@ -604,7 +702,8 @@ static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_j
     static bool lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (benign if raced)
     bool &lds_enabled = lds_enabled_dev[device_slot()];
     if (!lds_enabled) {
-        for (const void *f : {reinterpret_cast<const void *>(k_wgrad2<0>), reinterpret_cast<const void *>(k_wgrad2<1>)}) {
+        for (const void *f : {reinterpret_cast<const void *>(k_wgrad2<0>), reinterpret_cast<const void *>(k_wgrad2<1>),
+                              reinterpret_cast<const void *>(k_wgrad2<0, true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_wgrad2): %s", hipGetErrorString(e));
         }
@@ -612,7 +711,14 @@ static int launch_wgrad2(WArgs &wa, int nj, int32_t *counters_dev, int32_t *ep_j
     }
     if (zero_counters && hipMemsetAsync(wa.counters, 0, 256, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(wgrad counters)");
     const int grid = (int)env_d("MNR_WGRAD_WGS", 256.0);
-    if (family == 0) hipLaunchKernelGGL(k_wgrad2<0>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
+    if (zexp_pass) {                            // exponent words = counters[32 + job] (inside the 256 bytes zeroed above)
+        MNR_REQUIRE(zero_counters, "internal: the exponent pass needs the zeroed control words");
+        hipLaunchKernelGGL(k_wgrad_zexp, dim3(64, nj), dim3(256), 0, s, wa, counters_dev + 32);
+        int rc = check_launch("k_wgrad_zexp");
+        if (rc) return rc;
+    }
+    if (h2) hipLaunchKernelGGL((k_wgrad2<0, true>), dim3(grid), dim3(W2_THREADS), lds, s, wa);
+    else if (family == 0) hipLaunchKernelGGL(k_wgrad2<0>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
     else hipLaunchKernelGGL(k_wgrad2<1>, dim3(grid), dim3(W2_THREADS), lds, s, wa);
     int rc = check_launch("k_wgrad2");
     if (rc) return rc;
@@ -626,8 +732,10 @@ using namespace mnr;
 
 extern "C" size_t mnr_wgrad_workspace_bytes(void) { return W2Workspace::BYTES; }
 
+// h2: split-precision kernel; zexp[ri] = the region's exponent words (ZEXP_PLANES, written by k_mlp_bwd_h2) or, when zexp is NULL,
+// found by a pass over the planes (k_wgrad_zexp)
 static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,
-                              bool zero_counters, hipStream_t s) {
+                              bool zero_counters, hipStream_t s, bool h2 = false, const int32_t *const *zexp = nullptr) {
     MNR_REQUIRE(regions && n_regions >= 1 && n_regions <= W2_MAX_REGIONS, "1..%d weight-gradient regions per launch", W2_MAX_REGIONS);
     WArgs wa{};
     int nj = 0;
@@ -635,7 +743,7 @@ static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, in
     // per-tile cost model (cycles per SIMD): MFMA time of the two co-resident waves vs LDS-DMA fill time, + a fixed
     // boundary term -> tiles per item so that items of all jobs cost about the same (~4 tiles of the 256 x 256 shape)
     const double item_tiles = env_d("MNR_WGRAD_ITEM_TILES", 4.0);
-    auto cost_of = [&](int shape) { return wgrad_tile_cost(shape); };
+    auto cost_of = [&](int shape) { return wgrad_tile_cost(shape, h2); };
     const double cost_big = cost_of(WSI_BIG);
     const int only_shape = (int)env_d("MNR_WGRAD_ONLY_SHAPE", -1.0);
     for (int ri = 0; ri < n_regions; ++ri) {
@@ -663,7 +771,7 @@ static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, in
         const long cap = rg.tape_rows;
         int err = 0;
         struct SegIn { const float *in; int ld, N, col0; };
-        auto add = [&](const float *dz, int M, std::initializer_list<SegIn> segs, float *dw, int ldw, float *db) {
+        auto add = [&](int plane, const float *dz, int M, std::initializer_list<SegIn> segs, float *dw, int ldw, float *db) {
             int ld[3] = {0, 0, 0}, n = 0;
             for (const SegIn &sg : segs) ld[n++] = sg.ld;
             const int shape = shape_for(M, ld, n);
@@ -675,6 +783,7 @@ static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, in
             n = 0;
             for (const SegIn &sg : segs) { J.in[n] = sg.in; J.col0[n] = (int16_t)sg.col0; J.N[n] = (int16_t)sg.N; ++n; }
             J.shape = (int16_t)shape; J.region = (int16_t)ri;
+            J.zexp = !h2 ? nullptr : (zexp && zexp[ri] ? zexp[ri] + plane : counters_dev + 32 + (nj - 1));
             int tpi = (int)(item_tiles * cost_big / cost_of(shape) + 0.5);
             J.tiles_per_item = tpi < 1 ? 1 : tpi;
         };
@@ -684,29 +793,30 @@ static int wgrad_regions_impl(const mnr_wgrad_region *regions, int n_regions, in
             const float *dz = rg.gtape + (long)tl.act_off[l] * cap;
             const bool skip = (d->skip_mask >> l) & 1;
             const float *prev = l ? rg.tape + (long)tl.act_off[l - 1] * cap : nullptr;
-            if (l == 0) add(dz, W, {{embx, tl.embx_w, Ecols, 0}}, G.layer_w[l], Ecols, G.layer_b[l]);
-            else if (skip && d->xyz_dim == 3) add(dz, W, {{embx, tl.embx_w, Ecols, 0}, {prev, W, W, Ecols}}, G.layer_w[l], Ecols + W, G.layer_b[l]);
+            if (l == 0) add(l, dz, W, {{embx, tl.embx_w, Ecols, 0}}, G.layer_w[l], Ecols, G.layer_b[l]);
+            else if (skip && d->xyz_dim == 3) add(l, dz, W, {{embx, tl.embx_w, Ecols, 0}, {prev, W, W, Ecols}}, G.layer_w[l], Ecols + W, G.layer_b[l]);
             else if (skip) {
-                add(dz, W, {{prev, W, W, Ecols}}, G.layer_w[l], Ecols + W, G.layer_b[l]);
-                add(dz, W, {{embx, tl.embx_w, Ecols, 0}}, G.layer_w[l], Ecols + W, nullptr);
+                add(l, dz, W, {{prev, W, W, Ecols}}, G.layer_w[l], Ecols + W, G.layer_b[l]);
+                add(l, dz, W, {{embx, tl.embx_w, Ecols, 0}}, G.layer_w[l], Ecols + W, nullptr);
             }
-            else add(dz, W, {{prev, W, W, 0}}, G.layer_w[l], W, G.layer_b[l]);
+            else add(l, dz, W, {{prev, W, W, 0}}, G.layer_w[l], W, G.layer_b[l]);
         }
         MNR_REQUIRE(G.final_w && G.final_b && G.dir_a_w && G.dir_a_b, "missing final / dir_a gradient pointers");
-        add(rg.gtape + (long)tl.fin_off * cap, W, {{rg.tape + (long)tl.act_off[L - 1] * cap, W, W, 0}}, G.final_w, W, G.final_b);
+        add(L, rg.gtape + (long)tl.fin_off * cap, W, {{rg.tape + (long)tl.act_off[L - 1] * cap, W, W, 0}}, G.final_w, W, G.final_b);
         {
             const float *dz = rg.gtape + (long)tl.dact_off * cap;
             const int ldw = W + EDcols + d->appearance_dim;
             const SegIn fin{rg.tape + (long)tl.fin_off * cap, W, W, 0}, dir{rg.tape + (long)tl.embd_off * cap, tl.embd_w, EDcols, W},
                 app{rg.tape + (long)tl.app_off * cap, tl.app_w, d->appearance_dim, W + EDcols};
-            if (EDcols && d->appearance_dim) add(dz, W / 2, {fin, dir, app}, G.dir_a_w, ldw, G.dir_a_b);
-            else if (EDcols) add(dz, W / 2, {fin, dir}, G.dir_a_w, ldw, G.dir_a_b);
-            else add(dz, W / 2, {fin, app}, G.dir_a_w, ldw, G.dir_a_b);
+            if (EDcols && d->appearance_dim) add(L + 1, dz, W / 2, {fin, dir, app}, G.dir_a_w, ldw, G.dir_a_b);
+            else if (EDcols) add(L + 1, dz, W / 2, {fin, dir}, G.dir_a_w, ldw, G.dir_a_b);
+            else add(L + 1, dz, W / 2, {fin, app}, G.dir_a_w, ldw, G.dir_a_b);
         }
         MNR_REQUIRE(!err, "weight-gradient job table: unsupported layer shape or too many jobs (region %d)", ri);
     }
     if (rows_bound == 0) return MNR_OK;
-    return launch_wgrad2(wa, nj, counters_dev, ep_job_dev, slab_dev, zero_counters, s, 0);
+    MNR_REQUIRE(!h2 || nj <= 24, "split-precision weight gradients: too many jobs");
+    return launch_wgrad2(wa, nj, counters_dev, ep_job_dev, slab_dev, zero_counters, s, 0, h2, h2 && !zexp);
 }
 
 extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev,
@@ -718,10 +828,20 @@ extern "C" int mnr_mlp_backward_weights_multi(const mnr_wgrad_region *regions, i
                               as_stream(stream));
 }
 
-// the step's form (csrc/step.hip): control words placed by the caller and already zeroed by its one memset
+extern "C" int mnr_mlp_backward_weights_multi_h2(const mnr_wgrad_region *regions, int n_regions, void *workspace_dev,
+                                                 size_t workspace_bytes, void *stream) {
+    MNR_REQUIRE(workspace_dev && workspace_bytes >= W2Workspace::BYTES, "workspace missing or smaller than mnr_wgrad_workspace_bytes()");
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    return wgrad_regions_impl(regions, n_regions, reinterpret_cast<int32_t *>(ws + W2Workspace::COUNTERS),
+                              reinterpret_cast<int32_t *>(ws + W2Workspace::EP_JOB), reinterpret_cast<float *>(ws + W2Workspace::SLAB), true,
+                              as_stream(stream), true, nullptr);
+}
+
+// the step's form (csrc/step.hip): control words placed by the caller and already zeroed by its one memset; zexp != NULL selects the
+// split-precision kernel with the exponent words of every region (written by the split-precision data-gradient chain)
 int mnr::wgrad_regions_launch(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,
-                              hipStream_t s) {
-    return wgrad_regions_impl(regions, n_regions, counters_dev, ep_job_dev, slab_dev, false, s);
+                              hipStream_t s, const int32_t *const *zexp) {
+    return wgrad_regions_impl(regions, n_regions, counters_dev, ep_job_dev, slab_dev, false, s, zexp != nullptr, zexp);
 }
 size_t mnr::wgrad_ep_job_bytes() { return (size_t)W2_MAX_EPISODES * 4; }
 size_t mnr::wgrad_slab_bytes() { return (size_t)W2_MAX_EPISODES * W2_EP_FLOATS * 4; }

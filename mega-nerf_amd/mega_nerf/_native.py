@@ -188,6 +188,7 @@ EXPORTS = [
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
+    'mnr_mlp_backward_weights_multi_h2',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -258,6 +259,7 @@ def lib() -> C.CDLL:
         _lib.mnr_wgrad_workspace_bytes.restype = C.c_size_t
         _lib.mnr_wgrad_workspace_bytes.argtypes = []
         _lib.mnr_mlp_backward_weights_multi.argtypes = [C.POINTER(WgradRegion), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.mnr_mlp_backward_weights_multi_h2.argtypes = [C.POINTER(WgradRegion), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.mnr_tgemm_run.argtypes = [C.POINTER(TGemm), C.c_void_p]
         _lib.mnr_wgrad_jobs.argtypes = [C.POINTER(WgradJob), C.c_int, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.mnr_composite_backward.argtypes = [C.POINTER(CompositeGradIO), C.c_void_p]

@@ -2,9 +2,9 @@
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box from the repo root):
 #   kernel trace + stats of the default training bench and of the eval bench, then separate --pmc passes
 #   (HBM counters in their own passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).
-# Output: $OUT (default gpurun_out/r02_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r02
+# Output: $OUT (default gpurun_out/r03_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r03
 set -u
-OUT=${1:-$PWD/gpurun_out/r02_prof}
+OUT=${1:-$PWD/gpurun_out/r03_prof}
 B=$PWD/bench.py
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -31,4 +31,15 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE 
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
     --kernel-trace -d "$OUT/pmc_sq_w512" -o p --output-format csv -- \
     python "$B" $W5 --steps 3 --warmup 2 > /dev/null 2> "$OUT/pmc_sq_w512.err" < /dev/null
+# opt-in split-precision kernels (k_mlp_fwd_h2 / k_mlp_bwd_h2): they run in the side measurements of the default train bench
+SP="--mode train --steps 8 --warmup 2 --no-cpu-baseline --only-split-extras"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_split" -o t --output-format csv -- \
+    python "$B" $SP > "$OUT/bench_split_under_rocprof.json" 2> "$OUT/trace_split.err" < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_fetch_split" -o p --output-format csv -- \
+    python "$B" $SP > /dev/null 2> "$OUT/pmc_fetch_split.err" < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_write_split" -o p --output-format csv -- \
+    python "$B" $SP > /dev/null 2> "$OUT/pmc_write_split.err" < /dev/null
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
+    --kernel-trace -d "$OUT/pmc_sq_split" -o p --output-format csv -- \
+    python "$B" $SP > /dev/null 2> "$OUT/pmc_sq_split.err" < /dev/null
 ls "$OUT"

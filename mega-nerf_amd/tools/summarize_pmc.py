@@ -35,6 +35,10 @@ KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid si
     'k_tgemm_forward_w512': ('w512', lambda n, g: 'k_tgemm<false' in n),
     'k_tgemm_data_gradient_w512': ('w512', lambda n, g: 'k_tgemm<true' in n),
     'k_wgrad2_jobs_w512': ('w512', lambda n, g: 'k_wgrad2<1>' in n),
+    # opt-in split-precision kernels (16-bit matrix pipe, hi/lo operands)
+    'k_mlp_fwd_h2_train': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'true>' in n),
+    'k_mlp_fwd_h2_eval': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'false>' in n),
+    'k_mlp_bwd_h2': ('split', lambda n, g: 'k_mlp_bwd_h2' in n),
 }
 
 
@@ -61,13 +65,13 @@ def med(xs):
 def main():
     src, dst, rnd = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
     dst.mkdir(exist_ok=True)
-    for mode in ('train', 'eval', 'w512'):
+    for mode in ('train', 'eval', 'w512', 'split'):
         for f in glob.glob(str(src / ('trace_' + mode) / '**' / '*kernel_stats.csv'), recursive=True):
             shutil.copy(f, dst / ('%s_%s_kernel_stats.csv' % (rnd, mode)))
         j = src / ('bench_%s_under_rocprof.json' % mode)
         if j.exists() and j.stat().st_size:
             shutil.copy(j, dst / ('%s_bench_%s_under_rocprof.json' % (rnd, mode)))
-    passes = {(kind, mode): load_pass(src / ('pmc_%s_%s' % (kind, mode))) for kind in ('fetch', 'write', 'sq') for mode in ('train', 'eval', 'w512')}
+    passes = {(kind, mode): load_pass(src / ('pmc_%s_%s' % (kind, mode))) for kind in ('fetch', 'write', 'sq') for mode in ('train', 'eval', 'w512', 'split')}
     out = {}
     for key, (mode, pred) in KERNELS.items():
         e = {}

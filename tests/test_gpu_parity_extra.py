@@ -251,7 +251,7 @@ def test_batched_weight_gradients(mode, monkeypatch):
     assert not bad, bad
 
 
-def _flat_backward(name, S, n_ray, row0, pad, seed):
+def _flat_backward(name, S, n_ray, row0, pad, seed, d_scale=1.0):
     """One training-mode launch of model ``name`` over n_ray x S rows written at tape row ``row0`` + its data-gradient chain /
     head gradients; returns everything the weight-gradient launch and the fp64 checker need."""
     from mega_nerf import _native as N
@@ -265,7 +265,7 @@ def _flat_backward(name, S, n_ray, row0, pad, seed):
     dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
     idx = rng.integers(0, 100, n_ray).astype(f32)
     noise = rng.uniform(0, 1, B).astype(f32)
-    d_out = rng.standard_normal((B, 4)).astype(f32)
+    d_out = (rng.standard_normal((B, 4)) * d_scale).astype(f32)
     cap = row0 + B + pad
     fpr = m.tape_floats_per_row()
     tape, gtape = torch.zeros(cap * fpr, device=DEV), torch.zeros(cap * fpr, device=DEV)
@@ -291,21 +291,26 @@ def _flat_backward(name, S, n_ray, row0, pad, seed):
                 d_out=d_out, out=out, keep=(packed, pb, gtape, dheads, t, counter, g))
 
 
+@pytest.mark.parametrize('h2', [False, True], ids=['f32', 'split'])
 @pytest.mark.parametrize('size', ['r592', 'benchmark'])
-def test_wgrad2_against_fp64_autograd(size):
+def test_wgrad2_against_fp64_autograd(size, h2):
     """k_wgrad2 (mnr_mlp_backward_weights_multi: the weight-gradient launch of a training step) against torch fp64 autograd of
     the reference's NeRF.forward (nerf.py:115-160): EVERY parameter gradient within 2e-4 of its tensor's scale -- at the 592
     ragged rows of test_mlp_backward_against_fp64_autograd and at the benchmark's row counts (fg 1024 x 192 = 196 608 rows, bg
     138 x 96 = 13 248), fg + bg regions in ONE launch.  The fp64 side uses the ReLU masks found on the kernel's own tape, so
-    the comparison measures the kernels, not which way a pre-activation within an ulp of zero was rounded."""
+    the comparison measures the kernels, not which way a pre-activation within an ulp of zero was rounded.
+    ``split``: the opt-in split-precision form of the same launch (mnr_mlp_backward_weights_multi_h2: f16 hi/lo operands, plane-wise
+    power-of-two scaling of dZ) at the same tolerance, with output gradients of realistic size (1e-7: far below the f16 range)."""
     from mega_nerf import _native as N
     lib = N.lib()
+    d_scale = 1e-7 if h2 else 1.0
     shapes = dict(r592=(('fg', 16, 37, 24, 40), ('bg', 16, 37, 24, 40)),
                   benchmark=(('fg', 192, 1024, 0, 0), ('bg', 96, 138, 0, 0)))[size]
-    runs = [_flat_backward(name, S, n_ray, row0, pad, 40 + i) for i, (name, S, n_ray, row0, pad) in enumerate(shapes)]
+    runs = [_flat_backward(name, S, n_ray, row0, pad, 40 + i, d_scale) for i, (name, S, n_ray, row0, pad) in enumerate(shapes)]
     ws = torch.empty(lib.mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=DEV)
     arr = (N.WgradRegion * len(runs))(*[r['region'] for r in runs])
-    N.check(lib.mnr_mlp_backward_weights_multi(arr, len(runs), ws.data_ptr(), ws.numel(), None))
+    fn = lib.mnr_mlp_backward_weights_multi_h2 if h2 else lib.mnr_mlp_backward_weights_multi
+    N.check(fn(arr, len(runs), ws.data_ptr(), ws.numel(), None))
     torch.cuda.synchronize()
     worst, flips = {}, {}
     for (name, *_), r in zip(shapes, runs):
