@@ -20,7 +20,7 @@ file-based gather, runner.py:495-510).
     through its cells one after the other (``"scaling": "strong"``; --gpus 1 = one GPU trains all S).
 
 The line also carries: ``roofline`` (dominant kernel: live HIP-event duration of its launches, algorithmic FLOPs,
-MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r02_pmc_summary.json``), ``cpu_baseline`` (the
+MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r03_pmc_summary.json``), ``cpu_baseline`` (the
 torch-CPU restatement of the reference on this box's host cores, bounded sample), the north-star PSNR check
 (``psnr``: a student model trained for a few steps here and by the CPU restatement on identical batches and
 random numbers, both evaluated against a fixed teacher field), and (N = 1) short extra measurements: 65 536-ray
@@ -46,7 +46,7 @@ FG_FLOP_PER_SAMPLE = 1211392      # 2 x 605 696 MAC
 BG_FLOP_PER_SAMPLE = 1236992
 HEAD_FLOP_PER_SAMPLE = 2 * (256 + 3 * 128)          # sigma / rgb heads: VALU, not part of the MFMA kernels' work
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
-PMC_FILE = ROOT / 'profiles' / 'r02_pmc_summary.json'
+PMC_FILE = ROOT / 'profiles' / 'r03_pmc_summary.json'
 
 
 def build_models(hp, dev, seed, layer_dim=256):
@@ -523,9 +523,19 @@ def main():
                 fs([w['batch']])
             torch.cuda.synchronize()
             sp = [fs.kernel_times(i) for i in range(8)]
+            # the split-precision weight-gradient launch is bound by the tape stream: algorithmic bytes = every dZ plane and every input
+            # plane of every layer read once (floats per tape row: fg 4964, bg 5268 -- DESIGN.md section 3f)
+            nbg_s = int(fs.n_bg[0])
+            wg_bytes = 4.0 * (4964 * args.rays * (Nc + Nf) + 5268 * nbg_s * (Nc // 2 + Nf // 2))
+            wg_ms = sum(d_['wgrad'] for d_ in sp) / len(sp)
             extras['train_split_precision'] = {
-                'dtype': 'forward + data-gradient chain: f16 hi/lo split operands, 3 x v_mfma_f32_16x16x32_f16 per layer, f32 accumulate; '
-                         'weight gradients, heads, ray stages, Adam: f32 (opt-in; the f32 step is the default and `value`)',
+                'wgrad_roofline': {'bound': 'hbm', 'achieved': round(wg_bytes / wg_ms / 1e6, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                                   'frac': round(wg_bytes / wg_ms / 1e6 / 8000.0, 4), 'algorithmic_bytes_per_launch': int(wg_bytes),
+                                   'kernel': 'k_wgrad2<0, true> (split-precision weight gradients of both models; one launch per step)',
+                                   'avg_launch_ms': round(wg_ms, 4)},
+                'dtype': 'forward, data-gradient chain and weight gradients: f16 hi/lo split operands, 3 f16 MFMA products per block, f32 accumulate '
+                         '(gradients scaled by powers of two per row / per plane); tapes, heads, ray stages, Adam: f32 (opt-in; the f32 step is '
+                         'the default and `value`)',
                 'ms_per_step': t_ts * 1e3, 'rays_per_sec': args.rays / t_ts,
                 'step_spans_ms': {k: round(sum(d_[k] for d_ in sp) / len(sp), 4) for k in sp[0]}}
             del fs

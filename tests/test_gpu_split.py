@@ -104,5 +104,12 @@ def test_split_precision_render_goldens(name, split_precision):
 def test_split_precision_benchmark_shape_all_rays(split_precision):
     """The benchmark's 1024 rays x (64 + 128) samples on the split-precision kernel: ALL rays within the north-star bound of the
     numpy oracle (same assertion as the fp32 path's test)."""
-    from test_gpu_parity_extra import test_benchmark_shape_render_against_oracle
-    test_benchmark_shape_render_against_oracle()
+    from test_gpu_parity_extra import _benchmark_shape_check
+    _benchmark_shape_check()
+
+
+def test_split_precision_benchmark_shape_all_rays_after_training_steps(split_precision):
+    """... and on weights 25 training steps old (the state bench.py's `eval_split_precision.rgb_difference_to_f32_kernels` is taken in):
+    rays that miss the bound are rays with a fine sample that sits elsewhere than the oracle's, as for the fp32 kernels."""
+    from test_gpu_parity_extra import _benchmark_shape_check
+    _benchmark_shape_check(train_steps=25, max_offenders=80)
