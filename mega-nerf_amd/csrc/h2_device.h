@@ -103,6 +103,9 @@ struct H2Stream {
     uint4v *lds;
     int cur;
     float one;                       // 1.0f behind an opaque asm (h2_split8)
+#ifdef H2_EXPERIMENT_NO_DMA
+    int n_issued = 0;
+#endif
     __device__ __forceinline__ void init(const uint4v *chunks, uint4v *ring) {
         g = chunks; lds = ring; cur = 1;
         one = 1.0f;
@@ -110,6 +113,10 @@ struct H2Stream {
         issue();
     }
     __device__ __forceinline__ void issue() {
+#ifdef H2_EXPERIMENT_NO_DMA
+        if (n_issued >= 2) { g += H2_CHUNK_U4; return; }      // timing experiment only: the ring keeps its first two chunks
+        ++n_issued;
+#endif
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         uint4v *dst = lds + (cur ^ 1) * H2_CHUNK_U4 + wave * 64;
         const unsigned lane_off = threadIdx.x * 16u;
@@ -171,7 +178,11 @@ __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&sr
         for (int o0 = 0; o0 < NOB; o0 += G) {
             uint4v ah[G], al[G];
 #pragma unroll
+#ifdef H2_EXPERIMENT_HALF_LDS
+            for (int o = 0; o < G; ++o) { ah[o] = p[((o0 + o) * 2) * 64]; al[o] = ah[o]; }        // timing experiment only
+#else
             for (int o = 0; o < G; ++o) { ah[o] = p[((o0 + o) * 2) * 64]; al[o] = p[((o0 + o) * 2 + 1) * 64]; }
+#endif
 #pragma unroll
             for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
 #pragma unroll
