@@ -47,6 +47,22 @@ def _padded_weight(w: torch.Tensor, splits: List[Tuple[int, int, int]]) -> torch
     return torch.cat(parts, 1)
 
 
+def _cached_padded_weight(model, name: str, w: torch.Tensor, splits: List[Tuple[int, int, int]]) -> torch.Tensor:
+    """:func:`_padded_weight`, kept on the model until the parameter changes: every row chunk of an evaluation (and every call
+    between two optimiser steps) would otherwise rebuild the same copies with a torch.cat.  The key follows NeRF.packed(): storage,
+    version counter (absent under inference_mode: then the model's own ``weights_changed()`` epoch), splits."""
+    cache = model.__dict__.setdefault('_padded_weights', {})
+    ver = None if w.is_inference() else w._version
+    key = (w.data_ptr(), ver, getattr(model, '_weights_epoch', 0), tuple(splits))
+    hit = cache.get(name)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wp = _padded_weight(w, splits)
+    if wp.data_ptr() != w.data_ptr():
+        cache[name] = (key, wp)
+    return wp
+
+
 def _act_sigma(model) -> int:
     from mega_nerf.models.nerf import ShiftedSoftplus
     return 3 if isinstance(model.sigma_activation, ShiftedSoftplus) else 1
@@ -67,6 +83,9 @@ class LayerwiseTape:
         ED = self.ED = 3 * (1 + 2 * m.pos_dir_dim) if m.has_dir else 0
         A = self.A = m.appearance_dim if (m.embedding_a is not None and m.affine is None) else 0
         self.affine = m.affine is not None and not sigma_only     # nerf.py:156-158: 3x4 colour transform per appearance index
+        if self.affine and m.rgb_dim != 3:
+            # the reference fails here too: nerf.py:157-158 multiplies a [B, 3, 3] transform with the [B, rgb_dim] colour
+            raise N.NativeError('affine_appearance needs rgb_dim == 3 (got %d): the 3x4 colour transform of nerf.py:156-158 acts on RGB' % m.rgb_dim)
         self.B, self.out, self.out_stride, self.sigma_only = B, out, out_stride, sigma_only
         self.idx, self.idx_stride, self.rows_per_ray = idx, idx_stride, rows_per_ray
         self.sh = sh_deg >= 0 and m.rgb_dim > 3 and not sigma_only
@@ -85,7 +104,7 @@ class LayerwiseTape:
         def tlin(Y: torch.Tensor, phases, name: str, layer, splits, relu: int) -> bool:
             """Y = act([phases] . W^T + b) on the tiled GEMM; False when its alignment rules do not hold."""
             n = layer.weight.shape[0]
-            wp = _padded_weight(layer.weight, splits)
+            wp = _cached_padded_weight(m, name, layer.weight, splits)
             ldw = wp.shape[1]
             if n % 256 or not _al16(Y.data_ptr(), wp.data_ptr(), layer.bias.data_ptr(), *[x.data_ptr() for x, _, _ in phases]):
                 return False

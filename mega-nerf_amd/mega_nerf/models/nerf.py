@@ -193,6 +193,7 @@ class NeRF(nn.Module):
         """Tell the packed-weight caches that the parameters were updated by something that does not bump their version
         counters (``torch.optim.Adam(fused=True)`` does not)."""
         self._packed_key = self._packed_bwd_key = self._packed_h2_key = None
+        self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1          # models/layerwise.py: padded weight copies
 
     def packed(self):
         """(desc, packed device buffer); re-packs when any parameter changed (in-place updates bump ``_version``; storage

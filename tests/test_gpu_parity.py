@@ -255,6 +255,43 @@ def test_mlp_repacks_after_weight_update():
     assert not torch.allclose(a[:, 3], b[:, 3])
 
 
+def test_layerwise_padded_weights_cached_until_the_parameter_changes():
+    """models/layerwise.py: the zero-padded weight copies of the tiled-GEMM path (layer 0, skip layer, dir_a) are built once per
+    parameter version, not once per row chunk -- and rebuilt after an in-place update or ``weights_changed()``."""
+    hp, cfg, w = mlp_variant('w512')
+    g = load('mlp')
+    m = native_nerf(cfg, w)
+    m.fused_supported = lambda: False                    # small launches of this width take the fused kernel: force the layer-by-layer path
+    x = T(g['w512_x'])
+    with torch.no_grad():
+        close(m(x), g['w512_out'], 1e-4, 2e-6)
+        cache = dict(m.__dict__.get('_padded_weights', {}))
+        if not cache:
+            pytest.skip('this build evaluates w512 without padded copies')
+        m(x)
+        assert all(m._padded_weights[k][1] is v[1] for k, v in cache.items())           # second call: the same tensors
+        name = next(iter(cache))
+        layer = dict(m.named_modules())[name]
+        layer.weight.mul_(1.5)                                                           # in-place: version bump
+        m(x)
+        assert m._padded_weights[name][1] is not cache[name][1]
+        w2 = {k: (v * f32(1.5) if k == name + '.weight' else v) for k, v in w.items()}
+        close(m(x), O.nerf_forward(w2, cfg, g['w512_x']), 1e-4, 2e-6)
+        before = m._padded_weights[name][1]
+        m.weights_changed()
+        m(x)
+        assert m._padded_weights[name][1] is not before
+
+
+def test_affine_appearance_needs_rgb():
+    """nerf.py:156-158 multiplies a 3x3 colour transform with the colour: rgb_dim != 3 cannot work (the reference raises a shape error)."""
+    from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
+    m = NeRF(12, 4, 8, [4], 64, 48, True, 10, 27, 3, ShiftedSoftplus()).to(DEV).eval()
+    x = torch.zeros(8, 7, device=DEV)
+    with torch.no_grad(), pytest.raises(Exception, match='rgb_dim == 3'):
+        m(x)
+
+
 def test_mlp_large_batch_against_oracle():
     """Full benchmark shape (1024 rays x 192 samples) -- every workgroup / chunk boundary exercised."""
     hp, cfg, w = mlp_variant('fg')
