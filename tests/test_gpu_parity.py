@@ -286,8 +286,8 @@ def test_layerwise_padded_weights_cached_until_the_parameter_changes():
 def test_affine_appearance_needs_rgb():
     """nerf.py:156-158 multiplies a 3x3 colour transform with the colour: rgb_dim != 3 cannot work (the reference raises a shape error)."""
     from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
-    m = NeRF(12, 4, 8, [4], 64, 48, True, 10, 27, 3, ShiftedSoftplus()).to(DEV).eval()
-    x = torch.zeros(8, 7, device=DEV)
+    m = NeRF(12, 0, 8, [4], 64, 48, True, 10, 27, 3, ShiftedSoftplus()).to(DEV).eval()        # SH colour: no direction input (nerf.py:52-53)
+    x = torch.zeros(8, 4, device=DEV)
     with torch.no_grad(), pytest.raises(Exception, match='rgb_dim == 3'):
         m(x)
 

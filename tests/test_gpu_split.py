@@ -113,3 +113,4 @@ def test_split_precision_benchmark_shape_all_rays_after_training_steps(split_pre
     rays that miss the bound are rays with a fine sample that sits elsewhere than the oracle's, as for the fp32 kernels."""
     from test_gpu_parity_extra import _benchmark_shape_check
     _benchmark_shape_check(train_steps=25, max_offenders=80)
+    _benchmark_shape_check(train_steps=30, max_offenders=100, same_batch=True)
