@@ -160,19 +160,24 @@ __device__ __forceinline__ floatx4 h2_mfma(uint4v a, uint4v b, floatx4 c) {
 #ifndef H2_FRAG_GROUP
 #define H2_FRAG_GROUP 4
 #endif
-template <int NOB, int NK, int K0, int NSRC>
-__device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane) {
+struct H2NoHook {
+    template <class I> __device__ __forceinline__ void operator()(I) const {}
+};
+// `hook(chunk index inside the layer)` runs right behind every chunk boundary (behind the DMA issue of the following chunk): the
+// place for the training kernels' tape stores (a boundary drains vmcnt: stores issued just BEFORE one cost a write round trip)
+// G = output blocks whose (hi, lo) fragments are read ahead of their MFMAs (32 registers at 4; the training forward takes 2)
+template <int NOB, int NK, int K0, int G, int NSRC, class Hook = H2NoHook>
+__device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
     constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64);
     static_for<0, NK>([&](auto kc) {
         constexpr int kl = decltype(kc)::value, k = K0 + kl;
-        if constexpr (k % SPC == 0) st.next_chunk();
+        if constexpr (k % SPC == 0) { st.next_chunk(); hook(std::integral_constant<int, k / SPC>{}); }
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (8 * kl + j < NSRC) ? src[(8 * kl + j < NSRC) ? 8 * kl + j : 0] : 0.f;
         uint4v bh, bl;
         h2_split8(x, bh, bl, st.one);
         const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
-        constexpr int G = H2_FRAG_GROUP;
         static_assert(NOB % G == 0, "output blocks per fragment group");
 #pragma unroll
         for (int o0 = 0; o0 < NOB; o0 += G) {
@@ -191,6 +196,10 @@ __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&sr
             for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
         }
     });
+}
+template <int NOB, int NK, int K0, int NSRC, class Hook = H2NoHook>
+__device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
+    h2_segment_g<NOB, NK, K0, H2_FRAG_GROUP>(acc, src, st, lane, hook);
 }
 
 

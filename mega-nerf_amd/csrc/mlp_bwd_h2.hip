@@ -16,6 +16,9 @@ __global__ void k_pack_bwd_h2(BwdLayout b, uint4v *__restrict__ chunks) {
 // dZ of a layer to the gradient tape, scaled back by the row's power of two (exact)
 template <int P, int NH>
 __device__ __forceinline__ void gtape_store_scaled(const float (&g)[NH], float inv, float *g_row, int part, bool valid) {
+#ifdef H2_EXPERIMENT_NO_TAPE
+    if (NH == 64) return;             // timing experiment only
+#endif
     if (!valid) return;
 #pragma unroll
     for (int q = 0; q < NH / 4; ++q)
@@ -54,6 +57,21 @@ __device__ __forceinline__ bool h2_renorm(float (&g)[NH], int &E, float &scale_d
     for (int i = 0; i < NH; ++i) g[i] *= up;
     scale_dn = ldexpf(1.f, E);
     return usable;
+}
+
+// ... pieces Q0 .. Q0 + NQ - 1 only (a plane's stores are spread over the chunk periods of the product that consumes the registers);
+// uniform plane + 32-bit row offset in bytes (mlp_device.h gstore4)
+template <int P, int Q0, int NQ, int NH>
+__device__ __forceinline__ void gtape_store_scaled_part(const float (&g)[NH], float inv, const float *plane, unsigned row_byte_off, bool valid) {
+    static_assert(4 * (Q0 + NQ) <= NH, "piece range");
+#ifdef H2_EXPERIMENT_NO_TAPE
+    if (NH == 64) return;             // timing experiment only
+#endif
+    if (!valid) return;
+    static_for<Q0, Q0 + NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        gstore4<16 * P * q>(plane, row_byte_off, make_float4(g[4 * q] * inv, g[4 * q + 1] * inv, g[4 * q + 2] * inv, g[4 * q + 3] * inv));
+    });
 }
 
 template <class C>
@@ -184,6 +202,14 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
     // ---- final^T (+ sigma head): dZ of trunk layer L-1 ----
     { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, C::NL, E, live && valid); }
     const float ds_s = ds * ldexpf(1.f, -E);          // fp32 accumulator initialiser: may exceed 1, never touches f16
+    // dZ planes go to the gradient tape right behind the first chunk boundary of the product that consumes the registers (a boundary
+    // drains vmcnt: stores issued just before one cost a write round trip)
+    const unsigned grow_off = (unsigned)((trow * W + 4 * part) * 4);        // this lane's row in a W-wide plane, bytes (< 2^32: checked by the host)
+    auto store_g = [&](const float *plane) {
+        return [&, plane](auto cc) {
+            if constexpr (decltype(cc)::value == 0) gtape_store_scaled_part<P, 0, 16>(g, scale_dn, plane, grow_off, valid);
+        };
+    };
     floatx4 acc[NOB];
     {
         const float *ws = aux + a.sigma_off + part * H;
@@ -193,8 +219,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
             acc[ob][0] = ds_s * w4.x; acc[ob][1] = ds_s * w4.y; acc[ob][2] = ds_s * w4.z; acc[ob][3] = ds_s * w4.w;
         }
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[C::NL - 1] * cap, trow, a.tl.mask_w, part);
-        gtape_store_scaled<P>(g, scale_dn, a.gtape + a.tl.fin_off * cap + trow * W, part, valid);
-        h2_segment<NOB, H / 8, 0>(acc, g, st, lane);
+        h2_segment<NOB, H / 8, 0>(acc, g, st, lane, store_g(a.gtape + a.tl.fin_off * cap));
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
         { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, C::NL - 1, E, live && valid); }
@@ -204,8 +229,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         constexpr int l = C::NL - 1 - decltype(jc)::value;
         zero_acc(acc);
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);
-        gtape_store_scaled<P>(g, scale_dn, a.gtape + a.tl.act_off[l] * cap + trow * W, part, valid);
-        h2_segment<NOB, H / 8, 0>(acc, g, st, lane);
+        h2_segment<NOB, H / 8, 0>(acc, g, st, lane, store_g(a.gtape + a.tl.act_off[l] * cap));
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
         { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, l - 1, E, live && valid); }

@@ -56,6 +56,20 @@ struct MlpCellSeg {
 // as E + ZEXP_BIAS by atomic max; 0 = nothing seen.  Planes: trunk layer l -> l, final -> layers, dir_a -> layers + 1.
 constexpr int ZEXP_BIAS = 1024, ZEXP_PLANES = 16, ZEXP_TARGET = 14;
 
+// 16-byte store to  uniform base + 32-bit lane offset (bytes) + immediate: `global_store_dwordx4 v_off, v[data], s[base:base+1] offset:imm`.
+// One address VGPR per row instead of a 64-bit pointer pair per plane (which the training kernels spilled), and a GLOBAL store where
+// pointers that come out of a dynamically indexed kernel-argument struct would otherwise compile to FLAT stores (which count on
+// lgkmcnt as well and so sit in every LDS wait).
+typedef __attribute__((address_space(1))) char mnr_gchar;
+__device__ __forceinline__ const char *uniform_ptr(const char *p);
+template <int IMM>
+__device__ __forceinline__ void gstore4(const float *uniform_base, unsigned byte_off, float4 v) {
+    mnr_gchar *b = (mnr_gchar *)uniform_ptr(reinterpret_cast<const char *>(uniform_base));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) f4v gf4v;
+    *(gf4v *)(b + byte_off + IMM) = f4v{v.x, v.y, v.z, v.w};
+}
+
 // ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------
 // `global_load_lds_dwordx4`: every lane supplies its own global address, the data lands at
 // (wave-uniform LDS base) + lane*16 -- the packed image is lane-linear, so no staging registers and no

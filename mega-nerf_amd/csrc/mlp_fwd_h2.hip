@@ -49,6 +49,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
     static_assert(C::TILE == 16 && C::W == 256 && C::HAS_FINAL && C::RGB == 3, "split-precision kernel: default 8x256 architectures");
     constexpr int P = C::P, H = C::H, NOB = C::NOB, NOB2 = C::NOB2, H2 = C::H2, RPB = C::RPB;
     constexpr int KE = (C::EX + 7) / 8, KH = H / 8, KD = (C::ED + 7) / 8;
+    constexpr int FG = TRAIN ? 2 : H2_FRAG_GROUP;        // fragment read-ahead: the training instantiation has no registers to spare
     extern __shared__ uint4v h2_ring[];
     const mnr_mlp_io &io = a.io;
     const uint4v *chunks = a.chunks;
@@ -90,24 +91,35 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
 
     float h[H];
     floatx4 acc[NOB];
+    // Training: the output plane of a layer goes to the tape right behind the NEXT layer's first chunk boundary (a boundary drains
+    // vmcnt, so stores issued just before one would cost the wavefront a write round trip; the registers are the next layer's B
+    // operands and stay live).  16 x `global_store_dwordx4 v_off, v[data], s[plane]` per lane (mlp_device.h gstore4).
+    const unsigned trow_off = (unsigned)((tape_row<16>(trow0) * C::W + 4 * part) * 4);        // this lane's row in a W-wide plane, bytes (< 2^32: checked by the host)
+    auto store_prev = [&](auto planec) {            // hook: h -> activation plane `plane` + its sign bits
+        return [&](auto cc) {
+            constexpr int ci = decltype(cc)::value, pl = decltype(planec)::value;
+            if constexpr (TRAIN && ci == 0) {
+                if (valid) {
+#ifndef H2_EXPERIMENT_NO_TAPE
+                    tape_store_regs_part<P, 0, 16>(a.tape + a.tl.act_off[pl] * a.tape_rows, trow_off, h);
+#endif
+                    tape_store_mask<P>(a.tape + a.tl.mask_off[pl] * a.tape_rows, tape_row<16>(trow0), a.tl.mask_w, h, part);
+                }
+            }
+        };
+    };
     static_for<0, C::NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         init_acc<NOB, RPB>(acc, aux + a.bias_off[l] + part * H);
         if constexpr (l == 0) {
-            h2_segment<NOB, KE, 0>(acc, ex, st, lane);
+            h2_segment_g<NOB, KE, 0, FG>(acc, ex, st, lane);
         } else if constexpr ((C::SKIP >> l) & 1) {
-            h2_segment<NOB, KE, 0>(acc, ex, st, lane);
-            h2_segment<NOB, KH, KE>(acc, h, st, lane);
+            h2_segment_g<NOB, KE, 0, FG>(acc, ex, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
+            h2_segment_g<NOB, KH, KE, FG>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
         } else {
-            h2_segment<NOB, KH, 0>(acc, h, st, lane);
+            h2_segment_g<NOB, KH, 0, FG>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
-        if constexpr (TRAIN) {
-            if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.act_off[l] * a.tape_rows, tape_row<16>(trow0), C::W, h, part);
-                tape_store_mask<P>(a.tape + a.tl.mask_off[l] * a.tape_rows, tape_row<16>(trow0), a.tl.mask_w, h, part);
-            }
-        }
     });
 
     // sigma head (nerf.py:132-136): fp32 VALU
@@ -128,14 +140,16 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
 
     // xyz_encoding_final (no activation), then dir_a_encoding over [final | dir embedding | appearance]
     init_acc<NOB, RPB>(acc, aux + a.bias_off[C::NL] + part * H);
-    h2_segment<NOB, KH, 0>(acc, h, st, lane);
+    h2_segment_g<NOB, KH, 0, FG>(acc, h, st, lane, store_prev(std::integral_constant<int, C::NL - 1>{}));      // (the last trunk layer's plane)
     acc_to_regs<NOB, RPB, false>(h, acc);
-    if constexpr (TRAIN) {
-        if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, tape_row<16>(trow0), C::W, h, part);
-    }
     floatx4 acc2[NOB2];
     init_acc<NOB2, RPB>(acc2, aux + a.bias_off[C::NL + 1] + part * H2);
-    h2_segment<NOB2, KH, 0>(acc2, h, st, lane);
+    // ... and xyz_encoding_final's plane during dir_a's first segment (two chunks: half the plane behind each boundary)
+    h2_segment_g<NOB2, KH, 0, FG>(acc2, h, st, lane, [&](auto cc) {
+        if constexpr (TRAIN && decltype(cc)::value == 0) {
+            if (valid) tape_store_regs_part<P, 0, 16>(a.tape + a.tl.fin_off * a.tape_rows, trow_off, h);
+        }
+    });
     {
         float dv[3];
 #pragma unroll
@@ -145,7 +159,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
         if constexpr (TRAIN) {
             if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, tape_row<16>(trow0), a.tl.embd_w, ed, part);
         }
-        h2_segment<NOB2, KD, KH>(acc2, ed, st, lane);
+        h2_segment_g<NOB2, KD, KH, FG>(acc2, ed, st, lane);
         long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
                                    : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
         idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);
@@ -160,7 +174,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
                 for (int i = 0; i < C::APP / P; ++i) r[i] = ap[i];
             }
         }
-        h2_segment<NOB2, (C::AP + 7) / 8, KH + KD>(acc2, ap, st, lane);
+        h2_segment_g<NOB2, (C::AP + 7) / 8, KH + KD, FG>(acc2, ap, st, lane);
     }
     float dreg[H2];
     acc_to_regs<NOB2, RPB, true>(dreg, acc2);

@@ -48,6 +48,16 @@ __device__ __forceinline__ void tape_store_regs(float *plane, long row, int widt
     for (int q = 0; q < NH / 4; ++q)
         *reinterpret_cast<float4 *>(r + 4 * P * q) = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
 }
+// ... float4 pieces Q0 .. Q0 + NQ - 1 of a row only, addressed as uniform plane + 32-bit row offset in bytes (mlp_device.h gstore4): the
+// split-precision kernels spread a plane's stores over the chunk periods of the following layer
+template <int P, int Q0, int NQ, int NH>
+__device__ __forceinline__ void tape_store_regs_part(const float *plane, unsigned row_byte_off, const float (&h)[NH]) {
+    static_assert(4 * (Q0 + NQ) <= NH, "piece range");
+    static_for<Q0, Q0 + NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        gstore4<16 * P * q>(plane, row_byte_off, make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]));
+    });
+}
 // ReLU sign bits of a C-layout register array, packed per lane (TapeLayout mask planes)
 template <int P, int NH>
 __device__ __forceinline__ void tape_store_mask(float *plane, long row, int width, const float (&h)[NH], int part) {
