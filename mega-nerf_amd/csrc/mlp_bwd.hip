@@ -135,7 +135,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         AccT accd[NOBD];
         zero_acc(accd);
         st.next_chunk();
-        gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap + trow * (W / 2), part, valid);
+        gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap, (unsigned)((trow * (W / 2) + 4 * part) * 4), valid);
         run_segment<TILE, NOBD, H2 / 4, GPCD, 0>(accd, dd, st, lane);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
@@ -182,7 +182,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
             }
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[C::NL - 1] * cap, trow, a.tl.mask_w, part);
         st.next_chunk();
-        gtape_store<P>(g, a.gtape + a.tl.fin_off * cap + trow * W, part, valid);
+        gtape_store<P>(g, a.gtape + a.tl.fin_off * cap, (unsigned)((trow * W + 4 * part) * 4), valid);
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
@@ -194,12 +194,12 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         zero_acc(acc);
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);
         st.next_chunk();
-        gtape_store<P>(g, a.gtape + a.tl.act_off[l] * cap + trow * W, part, valid);       // dZ_l (deferred, see gtape_store)
+        gtape_store<P>(g, a.gtape + a.tl.act_off[l] * cap, (unsigned)((trow * W + 4 * part) * 4), valid);       // dZ_l (deferred, see gtape_store)
         run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
     });
-    gtape_store<P>(g, a.gtape + a.tl.act_off[0] * cap + trow * W, part, valid);
+    gtape_store<P>(g, a.gtape + a.tl.act_off[0] * cap, (unsigned)((trow * W + 4 * part) * 4), valid);
 }
 
 template <class C>
@@ -585,6 +585,7 @@ int mnr::fill_bwd_args(MlpBwdArgs &a, const ModelLayout &m, const void *packed_f
     a = MlpBwdArgs{};
     a.chunks = reinterpret_cast<const float4 *>(packed_bwd_dev);
     a.aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed_fwd_dev) + (size_t)m.total_chunks * CHUNK_BYTES);
+    MNR_REQUIRE((long)io->tape_rows * d->layer_dim * 4 < (1ll << 32), "tape capacity: a plane must stay below 4 GiB (32-bit row offsets in the store addressing)");
     a.tape = io->tape; a.gtape = io->gtape; a.tape_rows = io->tape_rows; a.tl = tape_layout(arch_of(d));
     a.d_out = io->d_out; a.d_out_stride = io->d_out_stride; a.out = io->out; a.out_stride = io->out_stride;
     a.dheads = io->dheads; a.d_emb_a = io->grad.embedding_a;

@@ -61,12 +61,15 @@ __device__ __forceinline__ void mask_apply(float (&g)[NH], const MaskBits<NH> &m
 // write dZ to the gradient tape (flat register i <-> feature 4P*(i/4) + 4*part + i%4).  Callers issue this right
 // AFTER a chunk barrier of the next layer: a barrier drains vmcnt, so a store issued just before one would stall the
 // wave for a full HBM write round trip; issued after it, the store has a whole chunk of MFMAs to complete.
+// Addressing: uniform plane base (SGPR pair) + this lane's 32-bit byte offset (row * width + 4 part floats; < 2^32, checked by the
+// host) + immediate: `global_store_dwordx4 v_off, v[data], s[plane] offset:imm` (mlp_device.h gstore4).
 template <int P, int NH>
-__device__ __forceinline__ void gtape_store(const float (&g)[NH], float *g_row, int part, bool valid) {
+__device__ __forceinline__ void gtape_store(const float (&g)[NH], const float *plane, unsigned row_byte_off, bool valid) {
     if (!valid) return;
-#pragma unroll
-    for (int q = 0; q < NH / 4; ++q)
-        *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+    static_for<0, NH / 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        gstore4<16 * P * q>(plane, row_byte_off, make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]));
+    });
 }
 
 template <int NOB, class AccT>

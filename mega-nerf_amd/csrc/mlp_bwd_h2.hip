@@ -13,22 +13,8 @@ __global__ void k_pack_bwd_h2(BwdLayout b, uint4v *__restrict__ chunks) {
     pack_bwd_h2_thread(b, chunks, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// dZ of a layer to the gradient tape, scaled back by the row's power of two (exact)
-template <int P, int NH>
-__device__ __forceinline__ void gtape_store_scaled(const float (&g)[NH], float inv, float *g_row, int part, bool valid) {
-#ifdef H2_EXPERIMENT_NO_TAPE
-    if (NH == 64) return;             // timing experiment only
-#endif
-    if (!valid) return;
-#pragma unroll
-    for (int q = 0; q < NH / 4; ++q)
-        *reinterpret_cast<float4 *>(g_row + 4 * P * q + 4 * part) = make_float4(g[4 * q] * inv, g[4 * q + 1] * inv, g[4 * q + 2] * inv, g[4 * q + 3] * inv);
-}
+// dZ of a layer to the gradient tape, scaled back by the row's power of two (exact): gtape_store_scaled_part below
 
-// Renormalise a row between two layers: the chain shrinks dZ by an order of magnitude every few layers, and the low halves of
-// the split operands end at 2^-24 of the scaled row maximum -- so the scale follows the row (g *= 2^-e, e = exponent of the row's
-// largest |g|; E accumulates the exponents, scale_dn = 2^E).  Exact (powers of two); ~100 VALU operations per layer and lane
-// beside 384 matrix instructions.
 // publish a plane's row exponent (E + ZEXP_BIAS, 0 for rows without data): largest over the wavefront, one atomic max per wavefront
 // and plane, skipped when the published value is already as large (after the first workgroups: nearly always)
 __device__ __forceinline__ void zexp_publish(int32_t *zexp, int plane, int E, bool has_data) {
@@ -141,7 +127,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         const MaskBits<H2> dm = mask_load<H2>(a.tape + a.tl.dmask_off * cap, trow, a.tl.dmask_w, part);
         mask_apply(dd, dm);
     }
-    gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap + trow * (W / 2), part, valid);
+    gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap, (unsigned)((trow * (W / 2) + 4 * part) * 4), valid);
     // ---- per-row power-of-two scale --------------------------------------------------------------------------------------------
     // Gradients are small (1e-6 .. 1e-12 is ordinary) and f16 ends at 6e-8: the chain is LINEAR per row once the masks are fixed,
     // so every row is scaled by 2^-e (e = exponent of its largest |dZ| entering the chain: max scaled value in [0.5, 1), 16 binades
@@ -234,7 +220,7 @@ __device__ __forceinline__ void mlp_bwd_h2_body(const MlpBwdArgs &a, long blk, i
         mask_apply(g, bits);
         { const bool live = h2_renorm(g, E, scale_dn); zexp_publish(zexp, l - 1, E, live && valid); }
     });
-    gtape_store_scaled<P>(g, scale_dn, a.gtape + a.tl.act_off[0] * cap + trow * W, part, valid);
+    gtape_store_scaled_part<P, 0, 16>(g, scale_dn, a.gtape + a.tl.act_off[0] * cap, grow_off, valid);
 }
 
 constexpr int H2B_MAX_SEGS = 4;

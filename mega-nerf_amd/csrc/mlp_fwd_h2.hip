@@ -275,6 +275,7 @@ int mnr::mlp_forward_multi_h2_impl(const mnr_mlp_launch *segs, int n_segs, const
         a.io = *L.io;
         for (int k = 0; k < MAX_MFMA_LAYERS; ++k) a.bias_off[k] = k < m.n_mfma_layers ? m.layer[k].bias_off : 0;
         a.sigma_off = m.sigma_off; a.rgb_off = m.rgb_off; a.sigma_act = L.desc->sigma_activation; a.app_count = L.desc->appearance_count;
+        MNR_REQUIRE(!L.tape_dev || (long)L.tape_rows * L.desc->layer_dim * 4 < (1ll << 32), "tape capacity: a plane must stay below 4 GiB");
         a.tape = L.tape_dev; a.tape_rows = L.tape_rows; a.tape_row0 = L.tape_row0;
         a.tl = tape_layout(ArchDims{L.desc->xyz_dim, L.desc->pos_xyz_dim, L.desc->pos_dir_dim, L.desc->layers, L.desc->skip_mask, L.desc->layer_dim,
                                     L.desc->appearance_dim, L.desc->rgb_dim, L.desc->mfma_tile});

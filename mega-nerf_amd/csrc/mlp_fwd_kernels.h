@@ -40,6 +40,13 @@ __device__ __forceinline__ long tape_row(unsigned wave_row0) {
     return (long)(wave_row0 + (l & (TILE - 1)));
 }
 
+// byte offset of this lane's 16-byte column group inside a `width`-float-wide plane (rows < 2^32 / (4 width): checked by the host);
+// re-derived at every use like tape_row, one 32-bit VGPR while it lives
+template <int TILE>
+__device__ __forceinline__ unsigned tape_row_off(unsigned wave_row0, int width, int part) {
+    return (unsigned)(((unsigned)tape_row<TILE>(wave_row0) * (unsigned)width + 4u * (unsigned)part) * 4u);
+}
+
 // tape stores (training): flat register i of a C-layout array <-> feature 4P*(i/4) + 4*part + i%4
 template <int P, int NH>
 __device__ __forceinline__ void tape_store_regs(float *plane, long row, int width, const float (&h)[NH], int part) {
@@ -191,7 +198,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
             // Tape stores of the previous layer's output are issued right AFTER the chunk barrier: a barrier drains
             // vmcnt, so stores issued just before one would stall the wave for a full HBM write round trip.
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
+                tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
                 tape_store_mask<P>(a.tape + a.tl.mask_off[l - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
@@ -235,7 +242,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         st.next_chunk();
         if constexpr (TRAIN) {                                   // deferred store of the last trunk layer (see above)
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
+                tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
                 tape_store_mask<P>(a.tape + a.tl.mask_off[C::NL - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
@@ -248,7 +255,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         init_acc<NOB2, RPB>(acc2, aux + a.bias_off[li] + part * H2);
         st.next_chunk();
         if constexpr (TRAIN) {
-            if (valid) tape_store_regs<P>(a.tape + a.tl.fin_off * a.tape_rows, tape_row<TILE>(trow0), C::W, h, part);
+            if (valid) tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.fin_off * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
         }
         run_segment<TILE, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane);
         if constexpr (C::ED > 0) {
@@ -283,7 +290,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         acc_to_regs<NOB2, RPB, true>(dreg, acc2);
         if constexpr (TRAIN) {
             if (valid) {
-                tape_store_regs<P>(a.tape + a.tl.dact_off * a.tape_rows, tape_row<TILE>(trow0), C::W / 2, dreg, part);
+                tape_store_regs_part<P, 0, H2 / 4>(a.tape + a.tl.dact_off * a.tape_rows, tape_row_off<TILE>(trow0, C::W / 2, part), dreg);
                 tape_store_mask<P>(a.tape + a.tl.dmask_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.dmask_w, dreg, part);
             }
         }
@@ -379,6 +386,7 @@ static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed
     a.sigma_act = d->sigma_activation;
     a.app_count = d->appearance_count;
     a.tape = tape;
+    if (tape && (long)tape_rows * d->layer_dim * 4 >= (1ll << 32)) return set_err(MNR_E_INVALID, "tape capacity: a plane must stay below 4 GiB (32-bit row offsets in the store addressing)");
     a.tape_rows = tape_rows;
     a.tape_row0 = tape_row0;
     a.tl = tape_layout(ArchDims{d->xyz_dim, d->pos_xyz_dim, d->pos_dir_dim, d->layers, d->skip_mask, d->layer_dim,
