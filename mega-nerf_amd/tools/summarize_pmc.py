@@ -24,7 +24,7 @@ from collections import defaultdict
 from pathlib import Path
 
 KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid size))
-    'k_wgrad2': ('train', lambda n, g: 'k_wgrad2<' in n or 'k_wgrad2(' in n),
+    'k_wgrad2': ('train', lambda n, g: ('k_wgrad2<' in n and 'true>' not in n) or 'k_wgrad2(' in n),
     'k_wgrad2_reduce': ('train', lambda n, g: 'k_wgrad2_reduce' in n),
     'k_mlp_fwd_multi_train': ('train', lambda n, g: 'k_mlp_fwd_multi' in n and 'true>' in n),
     'k_mlp_bwd_multi': ('train', lambda n, g: 'k_mlp_bwd_multi' in n),
@@ -39,6 +39,7 @@ KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid si
     'k_mlp_fwd_h2_train': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'true>' in n),
     'k_mlp_fwd_h2_eval': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'false>' in n),
     'k_mlp_bwd_h2': ('split', lambda n, g: 'k_mlp_bwd_h2' in n),
+    'k_wgrad2_h2': ('split', lambda n, g: 'k_wgrad2<0, true>' in n),
 }
 
 
