@@ -453,6 +453,22 @@ def main():
     metric_reduce_check = float(packed[0] / packed[1])
 
     extras = {}
+    if rank == 0 and world == 1 and args.container and args.mode == 'eval' and not args.no_extras and not wide:
+        # the routed container with every cell's rows on the opt-in split-precision kernel (mnr_mlp_forward_cells_h2): own dtype, not `value`
+        rendering.SPLIT_PRECISION = True
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            extras['eval_split_precision'] = {
+                'dtype': 'f16 hi/lo split operands, 3 x v_mfma_f32_16x16x32_f16 per layer, f32 accumulate (opt-in; fp32 kernels are the default)',
+                'rays_per_sec': args.rays * args.steps / (time.perf_counter() - t1)}
+        finally:
+            rendering.SPLIT_PRECISION = False
     if rank == 0 and world == 1 and not args.no_extras and not args.container and not args.submodules and (Nc, Nf) == (64, 128) and not wide:
         w = work[0]
         fgm, bgm = w['fg'], w['bg']

@@ -148,6 +148,10 @@ typedef struct mnr_mlp_cell {
 } mnr_mlp_cell;
 int mnr_mlp_forward_cells(const mnr_model_desc *desc, const mnr_mlp_cell *cells_dev, int n_cells, const mnr_mlp_io *io,
                           void *stream);
+/* The same routed launch on the 16-bit matrix pipe (opt-in split precision, csrc/mlp_fwd_h2.hip): mnr_mlp_cell::packed_dev are
+ * mnr_pack_model_h2 images; default 8x256 architectures, no sigma_only / SH (mega_nerf.py:28-49 under rendering.SPLIT_PRECISION). */
+int mnr_mlp_forward_cells_h2(const mnr_model_desc *desc, const mnr_mlp_cell *cells_dev, int n_cells, const mnr_mlp_io *io,
+                             void *stream);
 /* Host-side query (no GPU work): 1 if mnr_mlp_forward has a fused kernel for this architecture, else 0. */
 int mnr_fused_supported(const mnr_model_desc *desc);
 /* ... and 1 if the fused training kernels (mnr_mlp_forward_train / mnr_mlp_backward_*) cover it. */

@@ -42,6 +42,9 @@ struct H2Args {
     // several cells' rows side by side in the segment (csrc/step.hip): device table, blockIdx.y = cell
     const MlpCellSeg *dcells;
     long cell_rows, aux_byte_off;
+    // routed evaluation (mnr_mlp_forward_cells_h2): workgroups laid out cell after cell, device-side row lists / counts
+    const mnr_mlp_cell *cells;
+    int n_cells;
 };
 
 template <class C, bool TRAIN>
@@ -55,7 +58,25 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
     const uint4v *chunks = a.chunks;
     const float *aux = a.aux, *emb_a = a.emb_a;
     long n_rows, row_base = 0, tape_row0 = a.tape_row0;
-    if (a.dcells) {
+    const int32_t *row_index = nullptr;
+    float *outp = io.out;
+    if (a.cells) {
+        // as the fp32 kernel's routed mode (mlp_fwd_kernels.h): ceil(count_c / rows per workgroup) workgroups per cell, in cell order
+        int c = 0;
+        n_rows = 0;
+        for (; c < a.n_cells; ++c) {
+            const long n = *a.cells[c].count, t = (n + H2_ROWS - 1) / H2_ROWS;
+            if (blk < t) { n_rows = n; break; }
+            blk -= t;
+        }
+        if (c == a.n_cells) return;
+        const mnr_mlp_cell cell = a.cells[c];
+        chunks = reinterpret_cast<const uint4v *>(uniform_ptr(reinterpret_cast<const char *>(cell.packed_dev)));
+        aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(chunks) + a.aux_byte_off);
+        emb_a = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(cell.embedding_a)));
+        row_index = cell.row_index;
+        outp = cell.out;
+    } else if (a.dcells) {
         const MlpCellSeg cell = a.dcells[cidx];
         n_rows = cell.n_units ? (long)__builtin_amdgcn_readfirstlane(*cell.n_units) * io.rows_per_unit : a.cell_rows;
         if (blk * H2_ROWS >= n_rows) return;
@@ -74,7 +95,8 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
     const bool valid = lrow < n_rows;
     const long row = row_base + lrow;
     const long rc = row_base + (valid ? lrow : n_rows - 1);
-    const long ray = rc / io.rows_per_ray;
+    const long src = row_index ? (long)row_index[rc] : rc;            // gathered evaluation (MegaNeRF router)
+    const long ray = src / io.rows_per_ray;
     const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * H2_WAVES + wave) * 16 + tape_row0));
 
     H2Stream st;
@@ -82,7 +104,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
 
     float x[C::XYZ];
 #pragma unroll
-    for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[rc * io.xyz_stride + d];
+    for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
     float ex[C::EX];
     embed<C::XYZ, C::LX, P>(ex, x, part);
     if constexpr (TRAIN) {
@@ -134,7 +156,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
             s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
         }
         s = reduce_parts<P>(s) + ws[P * H];
-        if (io.sigma_noise) s += io.sigma_noise[rc];
+        if (io.sigma_noise) s += io.sigma_noise[src];
         sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
     }
 
@@ -198,7 +220,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
         rgbraw[c] = reduce_parts<P>(s) + wr[3 * P * H2 + c];
     }
     if (!(valid && part == 0)) return;
-    float *o = io.out + row * io.out_stride;
+    float *o = outp + row * io.out_stride;
     o[0] = sigmoidf_(rgbraw[0]); o[1] = sigmoidf_(rgbraw[1]); o[2] = sigmoidf_(rgbraw[2]); o[3] = sigma;
 }
 
@@ -252,6 +274,46 @@ extern "C" int mnr_pack_model_h2(void *packed_dev, size_t bytes, const mnr_model
     return check_launch("k_pack_model_h2");
 }
 
+static int h2_enable_lds() {
+    static bool lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (benign if raced)
+    bool &lds_enabled = lds_enabled_dev[device_slot()];
+    if (!lds_enabled) {
+        for (const void *f : {reinterpret_cast<const void *>(k_mlp_fwd_h2<H2FG, H2BG, false>), reinterpret_cast<const void *>(k_mlp_fwd_h2<H2FG, H2BG, true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2_CHUNK_BYTES);
+            if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_mlp_fwd_h2): %s", hipGetErrorString(e));
+        }
+        lds_enabled = true;
+    }
+    return MNR_OK;
+}
+
+// all cells of a routed evaluation in one launch (one architecture; inference)
+extern "C" int mnr_mlp_forward_cells_h2(const mnr_model_desc *d, const mnr_mlp_cell *cells_dev, int n_cells, const mnr_mlp_io *io, void *stream) {
+    MNR_REQUIRE(d && cells_dev && n_cells > 0 && n_cells <= 64 && io && io->xyz && io->dir && io->idx, "bad arguments to mnr_mlp_forward_cells_h2");
+    MNR_REQUIRE(!io->sigma_only && io->apply_sh_deg < 0 && io->rows_per_ray >= 1 && io->n_rows >= 0, "sigma_only / SH are not covered by the split-precision kernel");
+    ModelLayout m;
+    int rc = h2_layout(d, m);
+    if (rc != MNR_OK) return rc;
+    H2Multi mm{};
+    H2Args &a = mm.seg[0];
+    a.aux_byte_off = (long)h2_total_chunks(m) * H2_CHUNK_BYTES;
+    a.io = *io;
+    a.io.row_index = nullptr; a.io.n_units_dev = nullptr;
+    for (int k = 0; k < MAX_MFMA_LAYERS; ++k) a.bias_off[k] = k < m.n_mfma_layers ? m.layer[k].bias_off : 0;
+    a.sigma_off = m.sigma_off; a.rgb_off = m.rgb_off; a.sigma_act = d->sigma_activation; a.app_count = d->appearance_count;
+    a.cells = cells_dev; a.n_cells = n_cells;
+    mm.is_b[0] = d->xyz_dim == 4 ? 1 : 0;
+    // the worst case (every row routed to every cell); workgroups past the device-side counts exit at once
+    const long wg = (io->n_rows + H2_ROWS - 1) / H2_ROWS * n_cells;
+    MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one launch");
+    for (int i = 1; i <= H2_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
+    if (wg == 0) return MNR_OK;
+    rc = h2_enable_lds();
+    if (rc != MNR_OK) return rc;
+    hipLaunchKernelGGL((k_mlp_fwd_h2<H2FG, H2BG, false>), dim3((unsigned)wg), dim3(H2_THREADS), 2 * H2_CHUNK_BYTES, as_stream(stream), mm);
+    return check_launch("k_mlp_fwd_h2 (cells)");
+}
+
 int mnr::mlp_forward_multi_h2_impl(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
     MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= H2_MAX_SEGS, "1..%d segments per launch", H2_MAX_SEGS);
     H2Multi mm{};
@@ -294,14 +356,9 @@ int mnr::mlp_forward_multi_h2_impl(const mnr_mlp_launch *segs, int n_segs, const
     }
     for (int i = n_segs; i <= H2_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     if (wg == 0) return MNR_OK;
-    static bool lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (benign if raced)
-    bool &lds_enabled = lds_enabled_dev[device_slot()];
-    if (!lds_enabled) {
-        for (const void *f : {reinterpret_cast<const void *>(k_mlp_fwd_h2<H2FG, H2BG, false>), reinterpret_cast<const void *>(k_mlp_fwd_h2<H2FG, H2BG, true>)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2_CHUNK_BYTES);
-            if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_mlp_fwd_h2): %s", hipGetErrorString(e));
-        }
-        lds_enabled = true;
+    {
+        const int rc_lds = h2_enable_lds();
+        if (rc_lds != MNR_OK) return rc_lds;
     }
     const unsigned ny = cells ? (unsigned)(segs[0].io->n_rows / cells[0].cell_rows) : 1u;
     if (train) hipLaunchKernelGGL((k_mlp_fwd_h2<H2FG, H2BG, true>), dim3((unsigned)wg, ny), dim3(H2_THREADS), 2 * H2_CHUNK_BYTES, s, mm);

@@ -91,10 +91,15 @@ class MegaNeRF(nn.Module):
         same_arch = n_sub <= 64 and all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) for c in kids)
         if same_arch:
             # one launch for all cells: each cell alone (~1/n of the rows) cannot fill 256 CUs
+            from mega_nerf import rendering as R
+            # opt-in split precision (rendering.SPLIT_PRECISION; csrc/mlp_fwd_h2.hip): inference of the default 8x256 cells
+            split = (R.SPLIT_PRECISION and not torch.is_grad_enabled() and not sigma_only and sh_deg < 0 and dirs is not None and
+                     idx is not None and all(c.is_default_arch() for c in kids))
+            self._last_routed_split = split           # (tests: which kernel family served the last routed evaluation)
             sub_out = torch.empty(n_sub, B, ncol, device=dev, dtype=torch.float32)
             rows = []
             for i, child in enumerate(kids):
-                _, packed = child.packed()
+                _, packed = child.packed_h2() if split else child.packed()
                 rows.append([packed.data_ptr(), child.embedding_a.weight.data_ptr() if child.embedding_a is not None else 0,
                              lists[i].data_ptr(), counts[i:i + 1].data_ptr(), sub_out[i].data_ptr()])
             cells = torch.tensor(rows, dtype=torch.int64).to(dev)             # mnr_mlp_cell[n_sub]
@@ -102,7 +107,8 @@ class MegaNeRF(nn.Module):
             io = kids[0].mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, sub_out[0], noise, None, 0)
             io.sigma_only = 1 if sigma_only else 0
             io.apply_sh_deg = sh_deg
-            N.check(lib.mnr_mlp_forward_cells(C.byref(desc), cells.data_ptr(), n_sub, C.byref(io), N.stream_ptr()))
+            fwd = lib.mnr_mlp_forward_cells_h2 if split else lib.mnr_mlp_forward_cells
+            N.check(fwd(C.byref(desc), cells.data_ptr(), n_sub, C.byref(io), N.stream_ptr()))
             pos_scratch = torch.empty(n_sub, B, device=dev, dtype=torch.int32)
             N.check(lib.mnr_route_combine(out.data_ptr(), ncol, sub_out.data_ptr(), B * ncol, ncol, ncol, lists.data_ptr(),
                                           counts.data_ptr(), weights.data_ptr() if blend else None, n_sub, B, N.ptr(n_units),

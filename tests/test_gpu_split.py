@@ -114,3 +114,20 @@ def test_split_precision_benchmark_shape_all_rays_after_training_steps(split_pre
     from test_gpu_parity_extra import _benchmark_shape_check
     _benchmark_shape_check(train_steps=25, max_offenders=80)
     _benchmark_shape_check(train_steps=30, max_offenders=100, same_batch=True)
+
+
+def test_split_precision_routed_container(split_precision):
+    """An 8-cell merged container (MegaNeRF router, boundary margin 1.15) with every cell's rows on the split-precision kernel in ONE
+    launch per pass (mnr_mlp_forward_cells_h2): the reference's outputs at the fp32 path's tolerances."""
+    from test_gpu_parity_extra import test_new_render_goldens
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    test_new_render_goldens('render_container8_eval')
+    hp, nerf, bg_nerf = native_models('render_container8_eval')
+    assert isinstance(nerf, MegaNeRF)
+    from mega_nerf.rendering import render_rays
+    g = load('render_container8_eval')
+    s = common.SCENE
+    with torch.no_grad():
+        render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']),
+                    *[bool(v) for v in g['flags']])
+    assert nerf._last_routed_split is True                  # the split-precision launch really served it
