@@ -453,6 +453,23 @@ def main():
     metric_reduce_check = float(packed[0] / packed[1])
 
     extras = {}
+    if rank == 0 and world == 1 and args.submodules and fused is not None and not args.no_extras:
+        # the same cell set through the opt-in split-precision step (one mnr_train_step call for all cells): own dtype, not `value`
+        from mega_nerf.training import FusedTrainStep
+        fs = FusedTrainStep([(w['fg'], w['bg']) for w in work], hp, sc, sr, args.rays, split_precision=True)
+        bs = [w['batch'] for w in work]
+        for _ in range(3):
+            fs(bs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fs(bs)
+        torch.cuda.synchronize()
+        t_sp = (time.perf_counter() - t1) / args.steps
+        extras['train_split_precision'] = {
+            'dtype': 'forward, data-gradient chain and weight gradients: f16 hi/lo split operands, f32 accumulate (opt-in; the f32 step is `value`)',
+            'ms_per_step': t_sp * 1e3, 'rays_per_sec': args.rays * len(work) / t_sp}
+        del fs
     if rank == 0 and world == 1 and args.container and args.mode == 'eval' and not args.no_extras and not wide:
         # the routed container with every cell's rows on the opt-in split-precision kernel (mnr_mlp_forward_cells_h2): own dtype, not `value`
         rendering.SPLIT_PRECISION = True
