@@ -133,8 +133,9 @@ def _psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))      # metrics.py:8-10
 
 
-def psnr_gpu(hp, prob, dev):
-    """Teacher targets + student training on the MI355X path; returns (psnr_db, targets_train, target_test) as CPU tensors."""
+def psnr_gpu(hp, prob, dev, split_step=False):
+    """Teacher targets + student training on the MI355X path; returns (psnr_db, targets_train, target_test) as CPU tensors.
+    ``split_step``: the student trains through the opt-in split-precision fused step (same injected random numbers, Adam 5e-4)."""
     import synthetic_scene as S
     from mega_nerf.models.nerf import NeRF, ShiftedSoftplus
     from mega_nerf.rendering import render_rays_async
@@ -156,6 +157,19 @@ def psnr_gpu(hp, prob, dev):
                      for r, _ in prob['batches']]
         tgt_test = render_rays_async(tf, tb, torch.from_numpy(prob['test']).to(dev), idx_te, hp, sc, sr, False, False, False)[0]['rgb_fine']
     sf, sb = mk(prob['fcfg'], prob['student'][0]).train(), mk(prob['bcfg'], prob['student'][1]).train()
+    if split_step:
+        from mega_nerf.training import FusedTrainStep
+        n = prob['batches'][0][0].shape[0]
+        fs = FusedTrainStep([(sf, sb)], hp, sc, sr, n, lr=5e-4, lr_decay_factor=1.0, split_precision=True)
+        for (r, rnd), tgt in zip(prob['batches'], tgt_train):
+            fs([(torch.from_numpy(r).to(dev), idx_tr, tgt)],
+               _randoms=[{k: torch.from_numpy(v).to(dev).reshape(-1) if 'noise' in k else torch.from_numpy(v).to(dev) for k, v in rnd.items()}])
+        torch.cuda.synchronize()
+        del fs
+        sf.eval(), sb.eval()
+        with torch.no_grad():
+            out = render_rays_async(sf, sb, torch.from_numpy(prob['test']).to(dev), idx_te, hp, sc, sr, False, False, False)[0]['rgb_fine']
+        return _psnr(out, tgt_test), [t.cpu() for t in tgt_train], tgt_test.cpu()
     opts = [torch.optim.Adam(sf.parameters(), lr=5e-4), torch.optim.Adam(sb.parameters(), lr=5e-4)]
     for (r, rnd), tgt in zip(prob['batches'], tgt_train):
         for o in opts:
@@ -584,6 +598,8 @@ def main():
             prob = psnr_problem(hp, all_rays.cpu().numpy())
             psnr_here, tgt_train, tgt_test = psnr_gpu(hp, prob, dev)
             extras['_psnr_job'] = (prob, tgt_train, tgt_test)
+            if 'train_split_precision' in extras:
+                extras['train_split_precision']['psnr_student_vs_teacher_db'] = round(psnr_gpu(hp, prob, dev, split_step=True)[0], 4)
             extras['psnr'] = {'student_vs_teacher_db': round(psnr_here, 4),
                               'protocol': '%d Adam steps of %d rays (training mode: jitter + sigma noise, identical random numbers on both sides), '
                                           'PSNR of %d held-out rays against a fixed teacher field' % (PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS)}
@@ -678,6 +694,9 @@ def main():
             if 'psnr' in extras and 'psnr_db' in cpu:
                 extras['psnr']['cpu_restatement_db'] = round(cpu.pop('psnr_db'), 4)
                 extras['psnr']['abs_difference_db'] = round(abs(extras['psnr']['student_vs_teacher_db'] - extras['psnr']['cpu_restatement_db']), 4)
+                if 'psnr_student_vs_teacher_db' in extras.get('train_split_precision', {}):
+                    extras['train_split_precision']['psnr_abs_difference_to_cpu_restatement_db'] = round(
+                        abs(extras['train_split_precision']['psnr_student_vs_teacher_db'] - extras['psnr']['cpu_restatement_db']), 4)
                 extras['psnr']['cpu_seconds'] = cpu.pop('psnr_seconds')
         extras.pop('_psnr_job', None)
         if args.container:
