@@ -426,108 +426,93 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad(WgradArgs a) {
 }
 
 // sigma / rgb head weight gradients:  d w_sigma[W] = sum_r ds[r] * a_{L-1}[r][:],  d w_rgb[3][W/2] = sum_r dr[r][c] * d[r][:]
-// Pure streaming (1.5 KB per row): HBM-bound, so what matters is loads in flight.  A block is 16 waves = 4 groups of 256
-// threads; group g takes the 8-row chunks g, g + 4, g + 8, ... of the block's row range, every load of a chunk issued
-// before its first use.  In a group thread t owns sigma-head feature t (W == 256) and rgb-head feature t & 127 for the
-// rows of parity t >> 7 (W2 == 128); the bias sums ride on values the thread loads anyway (dheads is read by every
-// thread: a broadcast).  Groups are combined in LDS, one set of 644 atomics per block (few, long blocks: round 1
-// launched 1024 small blocks per segment and spent most of its time on those same-address atomics).
-constexpr int HG_GROUPS = 4;
+// Pure streaming (1.5 KB per row): HBM-bound, so what matters is bytes per load and loads in flight.  A block is 16 wavefronts; a
+// wavefront takes PAIRS of rows: a row of the 256-wide plane is one 16-byte load per lane (lane l <-> features 4l .. 4l + 3: the sigma
+// head needs no cross-lane sum at all), the two 128-wide rows of the pair are one 16-byte load per lane (lane half <-> row); four
+// pairs per iteration are requested before the first is used.  The per-row output gradients are wave-uniform (sigma: scalar loads) or
+// half-uniform (rgb: one broadcast 16-byte load).  Wavefronts are combined in LDS, one set of 644 atomics per block (few, long
+// blocks: round 1 launched 1024 small blocks per segment and spent most of its time on those same-address atomics).
+// (round 3: 0.124 -> 0.111 ms on the benchmark step; the first version read the planes with 4-byte loads, one feature per thread.
+// What is left is the launch, 16 short wavefronts per CU and the blocks' same-address atomics, not the stream: 0.33 GB in 0.11 ms.)
+constexpr int HG_GROUPS = 4;                 // block = 256 * HG_GROUPS threads = 16 wavefronts
 __device__ __forceinline__ void head_grads_body(const float *__restrict__ dheads, const float *__restrict__ a_last, int W,
                                                 const float *__restrict__ dact, int W2, long row0, long n_rows,
                                                 const int32_t *__restrict__ n_units_dev, int rows_per_unit,
                                                 float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b,
                                                 float *__restrict__ d_rgb_w, float *__restrict__ d_rgb_b, int with_rgb, int block, int n_blocks) {
-    __shared__ float red[HG_GROUPS][256 + 3 * 128 + 8];
+    constexpr int NWAVE = 4 * HG_GROUPS, SLOT = 256 + 3 * 128 + 4;
+    __shared__ float red[NWAVE][SLOT];
     const long n = n_units_dev ? (long)(*n_units_dev) * rows_per_unit : n_rows;
     const long per = ((n + n_blocks - 1) / n_blocks + 7) / 8 * 8;            // whole 8-row chunks per block
     const long rb = (long)block * per, re = min(n, rb + per);
     if (rb >= re) return;
     const long r0 = row0 + rb, r1 = row0 + re;
-    const int t = threadIdx.x & 255, grp = threadIdx.x >> 8;
-    const int f2 = t & (W2 - 1), par = t >> 7;
-    float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float sr[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = lane >> 5, l5 = lane & 31;
+    float4 as = make_float4(0.f, 0.f, 0.f, 0.f);                             // sigma head: features 4 lane .. 4 lane + 3
+    float4 ar[3] = {as, as, as};                                             // rgb head: features 4 l5 .. of channel c, rows of parity hh
     float bs = 0.f, br[3] = {0.f, 0.f, 0.f};
-    long r = r0 + 8 * grp;
-    for (; r + 7 < r1; r += 8 * HG_GROUPS) {
-        float al[8], hs[8], da[4];
-        float4 h4[4];
+    constexpr int U = 4;                                                     // row pairs in flight per wavefront
+    for (long p0 = r0 + 2 * wave; p0 < r1; p0 += 2 * NWAVE * U) {
+        float4 a0[U], a1[U], d4[U], h4[U];
+        float s0[U], s1[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { al[j] = a_last[(r + j) * W + t]; hs[j] = dheads[(r + j) * 4 + 3]; }
-        if (with_rgb) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long row = r + 2 * j + par;
-                da[j] = dact[row * W2 + f2];
-                h4[j] = *reinterpret_cast<const float4 *>(dheads + row * 4);
+        for (int u = 0; u < U; ++u) {
+            const long r = p0 + 2 * NWAVE * u;                               // wave-uniform
+            const bool ok0 = r < r1, ok1 = r + 1 < r1;
+            const long rr0 = ok0 ? r : r1 - 1, rr1 = ok1 ? r + 1 : r1 - 1;   // clamp: loads stay inside the row range, products are zeroed
+            a0[u] = *reinterpret_cast<const float4 *>(a_last + rr0 * W + 4 * lane);
+            a1[u] = *reinterpret_cast<const float4 *>(a_last + rr1 * W + 4 * lane);
+            s0[u] = ok0 ? dheads[rr0 * 4 + 3] : 0.f;
+            s1[u] = ok1 ? dheads[rr1 * 4 + 3] : 0.f;
+            if (with_rgb) {
+                const long rh = hh ? rr1 : rr0;
+                d4[u] = *reinterpret_cast<const float4 *>(dact + rh * W2 + 4 * l5);
+                h4[u] = *reinterpret_cast<const float4 *>(dheads + rh * 4);
+                if (!(hh ? ok1 : ok0)) h4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ss[j] = fmaf(hs[j], al[j], ss[j]); bs += hs[j]; }
-        if (with_rgb) {
+        for (int u = 0; u < U; ++u) {
+            as.x = fmaf(s0[u], a0[u].x, as.x); as.y = fmaf(s0[u], a0[u].y, as.y); as.z = fmaf(s0[u], a0[u].z, as.z); as.w = fmaf(s0[u], a0[u].w, as.w);
+            as.x = fmaf(s1[u], a1[u].x, as.x); as.y = fmaf(s1[u], a1[u].y, as.y); as.z = fmaf(s1[u], a1[u].z, as.z); as.w = fmaf(s1[u], a1[u].w, as.w);
+            bs += s0[u] + s1[u];
+            if (with_rgb) {
+                const float hc[3] = {h4[u].x, h4[u].y, h4[u].z};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sr[j][0] = fmaf(h4[j].x, da[j], sr[j][0]); sr[j][1] = fmaf(h4[j].y, da[j], sr[j][1]);
-                sr[j][2] = fmaf(h4[j].z, da[j], sr[j][2]);
-                br[0] += h4[j].x; br[1] += h4[j].y; br[2] += h4[j].z;
-            }
-        }
-    }
-    // ragged tail of the row range (< 8 rows): the group whose turn it would be takes it row by row
-    if (r < r1) {
-        for (; r < r1; ++r) {
-            const float h = dheads[r * 4 + 3];
-            ss[0] = fmaf(h, a_last[r * W + t], ss[0]);
-            bs += h;
-            if (with_rgb && ((r - r0) & 1) == par) {
-                const float d = dact[r * W2 + f2];
-                const float4 h4 = *reinterpret_cast<const float4 *>(dheads + r * 4);
-                sr[0][0] = fmaf(h4.x, d, sr[0][0]); sr[0][1] = fmaf(h4.y, d, sr[0][1]); sr[0][2] = fmaf(h4.z, d, sr[0][2]);
-                br[0] += h4.x; br[1] += h4.y; br[2] += h4.z;
+                for (int c = 0; c < 3; ++c) {
+                    ar[c].x = fmaf(hc[c], d4[u].x, ar[c].x); ar[c].y = fmaf(hc[c], d4[u].y, ar[c].y);
+                    ar[c].z = fmaf(hc[c], d4[u].z, ar[c].z); ar[c].w = fmaf(hc[c], d4[u].w, ar[c].w);
+                    br[c] += hc[c];
+                }
             }
         }
     }
-    float *mine = red[grp];
-    mine[t] = ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7]));
-    // rgb partials of the two row parities of feature f2 land in different slots and are added below
+    float *mine = red[wave];
+    *reinterpret_cast<float4 *>(mine + 4 * lane) = as;
     if (with_rgb) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (par == 0) mine[256 + c * 128 + f2] = (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]);
+        for (int c = 0; c < 3; ++c) {                                        // the two row parities of feature quad l5
+            float4 v = ar[c];
+            v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+            br[c] += __shfl_xor(br[c], 32);
+            if (hh == 0) *reinterpret_cast<float4 *>(mine + 256 + c * 128 + 4 * l5) = v;
         }
     }
-    __syncthreads();
-    if (with_rgb && par == 1) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) mine[256 + c * 128 + f2] += (sr[0][c] + sr[1][c]) + (sr[2][c] + sr[3][c]);
-    }
-    if (t == 0) mine[256 + 384] = bs;                                   // sigma bias: every thread saw every row of its group
-    if (with_rgb && f2 == 0) {                                          // rgb biases: threads 0 and 128 hold the two parities
-#pragma unroll
-        for (int c = 0; c < 3; ++c) mine[256 + 384 + 1 + 3 * par + c] = br[c];
+    if (lane == 0) {
+        mine[256 + 384] = bs;
+        mine[256 + 384 + 1] = with_rgb ? br[0] : 0.f; mine[256 + 384 + 2] = with_rgb ? br[1] : 0.f; mine[256 + 384 + 3] = with_rgb ? br[2] : 0.f;
     }
     __syncthreads();
-    if (grp == 0) {
+    for (int e = threadIdx.x; e < SLOT; e += 256 * HG_GROUPS) {
+        if (!with_rgb && e >= 256 && e != 256 + 384) continue;
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < HG_GROUPS; ++g) v += red[g][t];
-        atomicAdd(d_sigma_w + t, v);
-        if (with_rgb) {
-            for (int e = t; e < 384; e += 256) {
-                float u = 0.f;
-#pragma unroll
-                for (int g = 0; g < HG_GROUPS; ++g) u += red[g][256 + e];
-                atomicAdd(d_rgb_w + e, u);
-            }
-        }
-        if (t < 4 && (with_rgb || t == 3)) {
-            float u = 0.f;
-#pragma unroll
-            for (int g = 0; g < HG_GROUPS; ++g)
-                u += t == 3 ? red[g][256 + 384] : red[g][256 + 384 + 1 + t] + red[g][256 + 384 + 4 + t];
-            atomicAdd(t < 3 ? d_rgb_b + t : d_sigma_b, u);
-        }
+        for (int w = 0; w < NWAVE; ++w) v += red[w][e];
+        if (e < 256) atomicAdd(d_sigma_w + e, v);
+        else if (e < 256 + 384) atomicAdd(d_rgb_w + (e - 256), v);
+        else if (e == 256 + 384) atomicAdd(d_sigma_b, v);
+        else atomicAdd(d_rgb_b + (e - 256 - 384 - 1), v);
     }
 }
 
