@@ -488,15 +488,16 @@ struct MidArgs {
     const float *rays, *rays_bg, *last_delta, *z_c, *raw_c, *zb_asc, *zb_c, *braw_c, *u_f, *u_b, *t_f, *t_bf;
     const int32_t *scal;
     float *z_f, *xyz_f, *zb_f, *pts_f, *dr_f;
+    long unit0, unit1;               // units [unit0, unit1) of the 2 C N (foreground rays, then background slots)
 };
 
 template <int EC, int EB>
 __global__ __launch_bounds__(64 * WPB) void k_step_mid(MidArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long unit = (long)blockIdx.x * WPB + wave;
+    const long unit = a.unit0 + (long)blockIdx.x * WPB + wave;
     const long CN = a.C * a.N;
-    if (unit >= 2 * CN) return;
+    if (unit >= a.unit1) return;
     const int per_wave = 4 * a.Nc + 8;
     float *zl = smem + wave * per_wave;          // Nc      z of the ray as the compositing sees it
     float *bins = zl + a.Nc;                     // <= Nc - 1
@@ -818,7 +819,17 @@ struct mnr_step_plan {
     std::vector<hipEvent_t> events;   // profiling: n_slots x MNR_STEP_SPANS x (start, stop)
     int prof_slots = 0;
     long prof_step = 0;
-    ~mnr_step_plan() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+    // single-cell split-precision plans run the background branch of the forward (coarse pass -> fine samples -> fine pass) on a stream
+    // of their own, forked / joined by two events: the foreground passes are whole rounds of workgroups, the background's would be a
+    // partial round behind each of them (section 3e of DESIGN.md)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~mnr_step_plan() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 static size_t pack_table_bytes(int C) { return (size_t)4 * C * sizeof(PackJob); }
@@ -983,6 +994,19 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
     // the host vectors above die with this scope: the copies must have left them
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return fail(set_err(MNR_E_LAUNCH, "mnr_step_create: table upload failed: %s", hipGetErrorString(hipGetLastError())));
+    // Measured on the benchmark step: split-precision step 3.36 -> 3.21 ms; fp32 step 6.39 -> 6.35 ms (its foreground passes are longer,
+    // the partial rounds weigh less) -- within the box-to-box spread, and it would make every per-launch duration of the forward
+    // kernel an overlapped one, so the fp32 step keeps one stream unless MNR_STEP_TWO_STREAMS is set.
+    if (C == 1 && !getenv("MNR_STEP_ONE_STREAM") && (cfg->split_precision || getenv("MNR_STEP_TWO_STREAMS"))) {
+        // (failure to get the side stream is not an error: the step then runs its two branches in one launch each, as multi-cell plans do)
+        if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess) plan->side = nullptr;
+        if (plan->side && (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipStreamDestroy(plan->side);
+            plan->side = nullptr;
+        }
+        (void)hipGetLastError();
+    }
     rc = mnr_step_repack(plan, stream);
     if (rc != MNR_OK) return fail(rc);
     *out = plan;
@@ -1068,7 +1092,8 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     const bool split = p->cfg.split_precision != 0;
     const MlpCellSeg *tabs = reinterpret_cast<const MlpCellSeg *>(ws + L.tab_cells);
     const long capT_f = D.C * D.cap_f, capT_b = D.C * D.cap_b;
-    auto fwd_pass = [&](int pass) -> int {
+    // branch: 0 = both models in one launch, 1 = foreground only, 2 = background only
+    auto fwd_pass = [&](int pass, int branch, hipStream_t st) -> int {
         mnr_mlp_io io[2] = {};
         const long Sf = pass ? D.Nf : D.Nc, Sbb = pass ? D.Sfb : D.Sb;
         io[0].xyz = F(pass ? L.xyz_f : L.xyz_c); io[0].xyz_stride = 3;
@@ -1091,15 +1116,10 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         seg[1].packed_dev = split ? M0b.packed_h2_dev : M0b.packed_dev; seg[1].desc = &M0b.desc; seg[1].io = &io[1];
         seg[1].tape_dev = F(L.tape_b); seg[1].tape_rows = capT_b; seg[1].tape_row0 = 0;
         const CellTable ct[2] = {{tabs + (0 + pass) * C, D.N * Sf}, {tabs + (2 + pass) * C, D.N * Sbb}};
-        return split ? mlp_forward_multi_h2_impl(seg, 2, ct, s) : mlp_forward_multi_impl(seg, 2, ct, s);
+        const int first = branch == 2 ? 1 : 0, n = branch == 0 ? 2 : 1;
+        return split ? mlp_forward_multi_h2_impl(seg + first, n, ct + first, st) : mlp_forward_multi_impl(seg + first, n, ct + first, st);
     };
-    mark(1, 0);
-    int rc = fwd_pass(0);
-    if (rc) return rc;
-    mark(1, 1);
-    // ---- coarse weights -> fine samples ----
-    mark(2, 0);
-    {
+    auto mid = [&](long unit0, long unit1, hipStream_t st) -> int {
         MidArgs a{};
         a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb; a.det = rnd_u ? 0 : 1;
         a.sp = p->sp;
@@ -1107,19 +1127,47 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.braw_c = F(L.braw_c); a.u_f = F(L.u_f); a.u_b = F(L.u_b); a.t_f = F(L.t_f); a.t_bf = F(L.t_bf);
         a.scal = scal;
         a.z_f = F(L.z_f); a.xyz_f = F(L.xyz_f); a.zb_f = F(L.zb_f); a.pts_f = F(L.pts_f); a.dr_f = F(L.dr_f);
-        const long units = 2 * D.C * D.N;
+        a.unit0 = unit0; a.unit1 = unit1;
         const size_t sh = (size_t)WPB * (4 * D.Nc + 8) * sizeof(float);
-        const dim3 grid((unsigned)((units + WPB - 1) / WPB)), block(64 * WPB);
-        if (D.Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, s, a);
-        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, s, a);
-        rc = check_launch("k_step_mid");
-        if (rc) return rc;
+        const dim3 grid((unsigned)((unit1 - unit0 + WPB - 1) / WPB)), block(64 * WPB);
+        if (D.Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, st, a);
+        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, st, a);
+        return check_launch("k_step_mid");
+    };
+    int rc = MNR_OK;
+    const long CN = D.C * D.N;
+    if (p->side) {
+        // two branches side by side: the background's coarse pass -> fine samples -> fine pass on the plan's own stream, forked behind the
+        // sample kernel and joined in front of the ray tail; the spans below then time the FOREGROUND launches (the background runs inside them)
+        hipStream_t s2 = p->side;
+        if (hipEventRecord(p->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, p->ev_fork, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        if ((rc = fwd_pass(0, 2, s2)) || (rc = mid(CN, 2 * CN, s2)) || (rc = fwd_pass(1, 2, s2))) return rc;
+        if (hipEventRecord(p->ev_join, s2) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+        mark(1, 0);
+        if ((rc = fwd_pass(0, 1, s))) return rc;
+        mark(1, 1);
+        mark(2, 0);
+        if ((rc = mid(0, CN, s))) return rc;
+        mark(2, 1);
+        mark(3, 0);
+        if ((rc = fwd_pass(1, 1, s))) return rc;
+        mark(3, 1);
+        if (hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+        mark(1, 0);
+        if ((rc = fwd_pass(0, 0, s))) return rc;
+        mark(1, 1);
+        // ---- coarse weights -> fine samples ----
+        mark(2, 0);
+        if ((rc = mid(0, 2 * CN, s))) return rc;
+        mark(2, 1);
+        mark(3, 0);
+        if ((rc = fwd_pass(1, 0, s))) return rc;
+        mark(3, 1);
     }
-    mark(2, 1);
-    mark(3, 0);
-    rc = fwd_pass(1);
-    if (rc) return rc;
-    mark(3, 1);
     // ---- merge, compositing, blend, loss and their adjoints ----
     mark(4, 0);
     {
@@ -1311,6 +1359,7 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         a.rays = F(L.rays); a.rays_bg = F(L.rays_bg); a.last_delta = F(L.last_delta); a.z_c = F(L.z_c); a.raw_c = F(L.raw_c);
         a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.braw_c = F(L.braw_c); a.t_f = r->t_fine_dev; a.t_bf = r->t_bg_fine_dev; a.scal = r->n_bg;
         a.z_f = F(L.z_f); a.xyz_f = F(L.xyz_f); a.zb_f = F(L.zb_f); a.pts_f = F(L.pts_f); a.dr_f = F(L.dr_f);
+        a.unit0 = 0; a.unit1 = 2 * N;
         const size_t sh = (size_t)WPB * (4 * Nc + 8) * sizeof(float);
         const dim3 grid((unsigned)((2 * N + WPB - 1) / WPB)), block(64 * WPB);
         if (Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, s, a);

@@ -368,3 +368,38 @@ def test_fused_step_at_the_reference_default_sample_counts(split):
         got = _grads((('fg', n2), ('bg', b2)))
         worst = {k: float(np.abs(got[k] - ref[k]).max()) / max(float(np.abs(ref[k]).max()), 1e-30) for k in ref}
         assert max(worst.values()) < 2e-5, {k: v for k, v in worst.items() if v >= 2e-5}
+
+
+@pytest.mark.parametrize('split', [False, True], ids=['f32', 'split'])
+def test_background_branch_on_the_side_stream_changes_nothing(split, monkeypatch):
+    """Single-cell plans may run the background branch of the forward on a plan-owned side stream (default for the split-precision step,
+    MNR_STEP_TWO_STREAMS for the fp32 step; MNR_STEP_ONE_STREAM turns it off): same kernels, same inputs -- colours bit-identical,
+    loss and gradients equal up to the order of the atomically accumulated sums, over several steps (fork / join every step)."""
+    from mega_nerf.training import FusedTrainStep
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    batch = (T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target']))
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    out = {}
+    for mode in ('one', 'two'):
+        monkeypatch.delenv('MNR_STEP_ONE_STREAM', raising=False)
+        monkeypatch.delenv('MNR_STEP_TWO_STREAMS', raising=False)
+        monkeypatch.setenv('MNR_STEP_ONE_STREAM' if mode == 'one' else 'MNR_STEP_TWO_STREAMS', '1')
+        hp, nerf, bg_nerf = native_models('render_fgbg_train')
+        step = FusedTrainStep([(nerf, bg_nerf)], Namespace(**vars(hp)), sc, sr, batch[0].shape[0], seed=5, split_precision=split)
+        loss, n_bg, err = step([batch], optimize=False)           # first: gradients on identical weights
+        torch.cuda.synchronize()
+        assert int(err.max()) == 0 and int(n_bg.min()) > 0
+        first = (float(loss[0]), step.rgb[0].cpu().numpy().copy(),
+                 {'%d.%s' % (k, n): v.cpu().numpy().copy() for k in range(2) for n, v in step.grad_views[k].items()})
+        losses = [float(step([batch])[0][0]) for _ in range(4)]   # then four optimisation steps: fork / join every step
+        torch.cuda.synchronize()
+        out[mode] = (first, losses)
+        del step
+    (l1, rgb1, g1), (l2, rgb2, g2) = out['one'][0], out['two'][0]
+    np.testing.assert_allclose(l1, l2, rtol=2e-6)
+    np.testing.assert_array_equal(rgb1, rgb2)
+    for k in g1:
+        sc_ = max(float(np.abs(g1[k]).max()), 1e-30)
+        assert float(np.abs(g1[k] - g2[k]).max()) / sc_ < 2e-5, k
+    np.testing.assert_allclose(out['one'][1], out['two'][1], rtol=1e-3)
