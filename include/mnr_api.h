@@ -632,7 +632,12 @@ typedef struct mnr_render_io {
     float *rgb, *depth, *fg_rgb, *bg_rgb, *fg_depth, *bg_depth, *bg_lambda;
     int32_t *n_bg, *err;
     void *workspace;  size_t workspace_bytes;
+    void *side;                        /* optional side handle of mnr_side_create: the background branch runs on its stream beside the foreground's passes; NULL = one stream */
 } mnr_render_io;
+/* A side stream + fork / join events a caller may lend to mnr_render_fwd (host objects; create once per device / thread, destroy at exit). */
+typedef struct mnr_side mnr_side;
+int mnr_side_create(mnr_side **out);
+void mnr_side_destroy(mnr_side *side);
 size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples);
 int mnr_render_fwd(const mnr_render_io *io, void *stream);
 

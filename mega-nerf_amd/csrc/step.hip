@@ -1304,6 +1304,34 @@ extern "C" size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples,
 
 extern "C" int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, void *stream);
 
+// a side stream + fork / join events a caller may lend to mnr_render_fwd (mnr_render_io::side): the background branch then runs beside
+// the foreground's passes (the step plans own theirs)
+struct mnr_side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+extern "C" int mnr_side_create(mnr_side **out) {
+    MNR_REQUIRE(out, "NULL argument");
+    mnr_side *sd = new mnr_side();
+    if (hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+        if (sd->fork) (void)hipEventDestroy(sd->fork);
+        if (sd->stream) (void)hipStreamDestroy(sd->stream);
+        delete sd;
+        return set_err(MNR_E_LAUNCH, "mnr_side_create: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *out = sd;
+    return MNR_OK;
+}
+extern "C" void mnr_side_destroy(mnr_side *sd) {
+    if (!sd) return;
+    (void)hipEventDestroy(sd->fork);
+    (void)hipEventDestroy(sd->join);
+    (void)hipStreamDestroy(sd->stream);
+    delete sd;
+}
+
 extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
     MNR_REQUIRE(r && r->fg && r->bg && r->fg_packed && r->bg_packed && r->rays && r->idx && r->rgb && r->bg_lambda && r->n_bg && r->err &&
                 r->workspace && r->t_coarse_dev && r->t_bg_coarse_dev && r->t_fine_dev && r->t_bg_fine_dev, "NULL argument to mnr_render_fwd");
@@ -1337,7 +1365,7 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         hipLaunchKernelGGL(k_step_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         if ((rc = check_launch("k_step_samples"))) return rc;
     }
-    auto fwd_pass = [&](int pass) -> int {
+    auto fwd_pass = [&](int pass, int branch, hipStream_t st) -> int {
         mnr_mlp_io io[2] = {};
         const long Sf = pass ? Nf : Nc, Sbb = pass ? Sfb : Sb;
         io[0].xyz = F(pass ? L.xyz_f : L.xyz_c); io[0].xyz_stride = 3; io[0].dir = F(L.rays) + 3; io[0].dir_stride = 8;
@@ -1350,23 +1378,36 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         mnr_mlp_launch seg[2] = {};
         seg[0].packed_dev = r->fg_packed; seg[0].desc = r->fg; seg[0].io = &io[0];
         seg[1].packed_dev = r->bg_packed; seg[1].desc = r->bg; seg[1].io = &io[1];
-        return r->split_precision ? mnr_mlp_forward_multi_h2(seg, 2, stream) : mlp_forward_multi_impl(seg, 2, nullptr, s);
+        const int first = branch == 2 ? 1 : 0, n = branch == 0 ? 2 : 1;
+        return r->split_precision ? mnr_mlp_forward_multi_h2(seg + first, n, st) : mlp_forward_multi_impl(seg + first, n, nullptr, st);
     };
-    if ((rc = fwd_pass(0))) return rc;
-    {
+    auto mid = [&](long unit0, long unit1, hipStream_t st) -> int {
         MidArgs a{};
         a.C = 1; a.N = N; a.Nc = (int)Nc; a.Nf = (int)Nf; a.Sb = (int)Sb; a.Sfb = (int)Sfb; a.det = 1; a.sp = sp;
         a.rays = F(L.rays); a.rays_bg = F(L.rays_bg); a.last_delta = F(L.last_delta); a.z_c = F(L.z_c); a.raw_c = F(L.raw_c);
         a.zb_asc = F(L.zb_asc); a.zb_c = F(L.zb_c); a.braw_c = F(L.braw_c); a.t_f = r->t_fine_dev; a.t_bf = r->t_bg_fine_dev; a.scal = r->n_bg;
         a.z_f = F(L.z_f); a.xyz_f = F(L.xyz_f); a.zb_f = F(L.zb_f); a.pts_f = F(L.pts_f); a.dr_f = F(L.dr_f);
-        a.unit0 = 0; a.unit1 = 2 * N;
+        a.unit0 = unit0; a.unit1 = unit1;
         const size_t sh = (size_t)WPB * (4 * Nc + 8) * sizeof(float);
-        const dim3 grid((unsigned)((2 * N + WPB - 1) / WPB)), block(64 * WPB);
-        if (Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, s, a);
-        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, s, a);
-        if ((rc = check_launch("k_step_mid"))) return rc;
+        const dim3 grid((unsigned)((unit1 - unit0 + WPB - 1) / WPB)), block(64 * WPB);
+        if (Nc == 64) hipLaunchKernelGGL((k_step_mid<1, 1>), grid, block, sh, st, a);
+        else hipLaunchKernelGGL((k_step_mid<4, 2>), grid, block, sh, st, a);
+        return check_launch("k_step_mid");
+    };
+    if (r->side) {
+        // the background branch (coarse pass -> fine samples -> fine pass) beside the foreground's, on the lent stream
+        const mnr_side *sd = reinterpret_cast<const mnr_side *>(r->side);
+        if (hipEventRecord(sd->fork, s) != hipSuccess || hipStreamWaitEvent(sd->stream, sd->fork, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_render_fwd: stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        if ((rc = fwd_pass(0, 2, sd->stream)) || (rc = mid(N, 2 * N, sd->stream)) || (rc = fwd_pass(1, 2, sd->stream))) return rc;
+        if (hipEventRecord(sd->join, sd->stream) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_render_fwd: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+        if ((rc = fwd_pass(0, 1, s)) || (rc = mid(0, N, s)) || (rc = fwd_pass(1, 1, s))) return rc;
+        if (hipStreamWaitEvent(s, sd->join, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_render_fwd: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+        if ((rc = fwd_pass(0, 0, s)) || (rc = mid(0, 2 * N, s)) || (rc = fwd_pass(1, 0, s))) return rc;
     }
-    if ((rc = fwd_pass(1))) return rc;
     {
         RTailArgs a{};
         a.N = N; a.Nc = (int)Nc; a.Nf = (int)Nf; a.Sb = (int)Sb; a.Sfb = (int)Sfb;

@@ -171,7 +171,7 @@ class RenderIO(C.Structure):
                 ('t_coarse_dev', C.c_void_p), ('t_bg_coarse_dev', C.c_void_p), ('t_fine_dev', C.c_void_p), ('t_bg_fine_dev', C.c_void_p),
                 ('rgb', C.c_void_p), ('depth', C.c_void_p), ('fg_rgb', C.c_void_p), ('bg_rgb', C.c_void_p), ('fg_depth', C.c_void_p),
                 ('bg_depth', C.c_void_p), ('bg_lambda', C.c_void_p), ('n_bg', C.c_void_p), ('err', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('side', C.c_void_p)]
 
 
 EXPORTS = [
@@ -188,7 +188,7 @@ EXPORTS = [
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
-    'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2',
+    'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -301,6 +301,9 @@ def lib() -> C.CDLL:
         _lib.mnr_step_query.argtypes = [C.POINTER(StepCfg), C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.POINTER(StepLayout)]
         _lib.mnr_step_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(StepCfg), C.POINTER(StepModel), C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.mnr_step_destroy.argtypes = [C.c_void_p]
+        _lib.mnr_side_create.argtypes = [C.POINTER(C.c_void_p)]
+        _lib.mnr_side_destroy.argtypes = [C.c_void_p]
+        _lib.mnr_side_destroy.restype = None
         _lib.mnr_step_destroy.restype = None
         _lib.mnr_step_repack.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mnr_packed_model_h2_bytes.restype = C.c_size_t

@@ -13,6 +13,7 @@ injected (``_randoms``) so that train-mode parity is testable.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from argparse import Namespace
 from typing import Dict, Optional, Tuple
@@ -374,6 +375,7 @@ def _empty_results(hparams: Namespace, has_bg: bool, get_depth: bool, get_depth_
 
 FUSED_RENDER = True          # inference renders of the default configuration go through mnr_render_fwd (six launches)
 _render_ws: Dict[str, torch.Tensor] = {}
+_render_side: Dict[str, C.c_void_p] = {}       # device -> mnr_side handle (host object: stream + two events), created on first use
 
 
 def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_depth_variance, rnd) -> bool:
@@ -427,6 +429,18 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
             io.fg_depth, io.bg_depth = v['fg_depth'].data_ptr(), v['bg_depth'].data_ptr()
     io.n_bg, io.err = scal[0:1].data_ptr(), scal[1:2].data_ptr()
     io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+    if os.environ.get('MNR_RENDER_TWO_STREAMS'):
+        # opt-in: the background branch beside the foreground's passes on a side stream (the foreground's passes are whole rounds of
+        # workgroups, the background's partial rounds run inside them).  Measured at 1024 rays: fp32 render 488 K -> 508 K rays/s, the
+        # split-precision render unchanged (1.27 M).  Off by default: with it every per-launch duration of the MLP kernel is an
+        # overlapped one (the evidence under profiles/ is per launch).
+        side = _render_side.get(key)
+        if side is None:
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                N.check(lib.mnr_side_create(C.byref(h)))
+            side = _render_side[key] = h
+        io.side = side
     N.check(lib.mnr_render_fwd(C.byref(io), N.stream_ptr()))
     results = {'rgb_fine': v['rgb'], 'bg_lambda_fine': v['bg_lambda']}
     if get_depth:

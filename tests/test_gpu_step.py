@@ -403,3 +403,24 @@ def test_background_branch_on_the_side_stream_changes_nothing(split, monkeypatch
         sc_ = max(float(np.abs(g1[k]).max()), 1e-30)
         assert float(np.abs(g1[k] - g2[k]).max()) / sc_ < 2e-5, k
     np.testing.assert_allclose(out['one'][1], out['two'][1], rtol=1e-3)
+
+
+def test_fused_render_on_two_streams_changes_nothing(monkeypatch):
+    """mnr_render_fwd with a lent side stream (mnr_render_io::side; MNR_RENDER_TWO_STREAMS in the Python mirror): bit-identical outputs."""
+    from mega_nerf import rendering as R
+    g = load('render_fgbg_eval')
+    hp, nerf, bg_nerf = native_models('render_fgbg_eval')
+    s = common.SCENE
+    args = (nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    outs = []
+    for two in (False, True, True):
+        if two:
+            monkeypatch.setenv('MNR_RENDER_TWO_STREAMS', '1')
+        else:
+            monkeypatch.delenv('MNR_RENDER_TWO_STREAMS', raising=False)
+        with torch.no_grad():
+            res = R.render_rays(*args)[0]
+        outs.append({k: v.cpu().numpy().copy() for k, v in res.items()})
+    for k in outs[0]:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+        np.testing.assert_array_equal(outs[0][k], outs[2][k], err_msg=k)
