@@ -78,12 +78,15 @@ def _cell(seed, n_rays):
     return hp, fg, bg, (T(rays), T(idx.astype(np.int32)), T(tgt))
 
 
-def test_cells_sharing_a_step_are_independent():
+@pytest.mark.parametrize('split', [False, True], ids=['f32', 'split'])
+def test_cells_sharing_a_step_are_independent(split):
     """Three cells (own weights, own batches, own optimiser moments) stepped by ONE plan -- their rows side by side in every MLP
     launch -- against the same cells stepped one plan each (cell c of a plan draws its random numbers with key seed + c, so a
     lone plan seeded seed + c sees the same numbers): per-cell loss, rendered colours and gradients of the first step agree --
     colours exactly, gradients to the summation order of the atomics and of the weight-gradient partials -- and so do the weights
-    after three Adam steps (parscripts/run_8.txt: independent trainers)."""
+    after three Adam steps (parscripts/run_8.txt: independent trainers).  ``split``: the same through the split-precision kernels
+    (per-cell exponent words of the weight-gradient scaling, device tables of the h2 images; the lone plans run their background
+    branch on a side stream, the shared plan does not)."""
     from mega_nerf.training import FusedTrainStep
     s = common.SCENE
     sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
@@ -94,7 +97,7 @@ def test_cells_sharing_a_step_are_independent():
         hpn = Namespace(**vars(cells[0][0]))
         first = {}
         for grp in groups:
-            step = FusedTrainStep([(cells[i][1], cells[i][2]) for i in grp], hpn, sc, sr, n_rays, seed=77 + grp[0])
+            step = FusedTrainStep([(cells[i][1], cells[i][2]) for i in grp], hpn, sc, sr, n_rays, seed=77 + grp[0], split_precision=split)
             for it in range(3):
                 loss, n_bg, err = step([cells[i][3] for i in grp])
                 if it == 0:
