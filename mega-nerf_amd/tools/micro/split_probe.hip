@@ -78,41 +78,48 @@ __device__ __forceinline__ void split8(const float *x, uint4v &hi, uint4v &lo) {
     }
 }
 
-template <int DT, int PROD>
-__global__ __launch_bounds__(THREADS, 1) void k_split(const uint4v *__restrict__ wstream, const float *__restrict__ bias,
+// TILES: 16-row tiles a wavefront owns (1: 8 wavefronts per workgroup, 2 per SIMD; 2: 4 wavefronts, one per SIMD with the whole
+// 512-register file -- every fragment read from LDS then feeds two tiles' MFMAs)
+template <int DT, int PROD, int TILES>
+__global__ __launch_bounds__(THREADS / TILES, 1) void k_split(const uint4v *__restrict__ wstream, const float *__restrict__ bias,
                                                       const float *__restrict__ in, float *__restrict__ out, int nl) {
+    constexpr int WAVES_T = WAVES / TILES, THREADS_T = THREADS / TILES;
     extern __shared__ uint4v ring[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int part = lane >> 4;
-    const long row = ((long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
+    const long row0 = ((long)blockIdx.x * WAVES_T + wave) * 16 * TILES + (lane & 15);
 
     const uint4v *g = wstream + threadIdx.x;
     int cur = 1;
     auto issue = [&]() {
         uint4v *dst = ring + (cur ^ 1) * CHUNK_U4 + wave * 64;
 #pragma unroll
-        for (int i = 0; i < CHUNK_U4 / THREADS; ++i)
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * THREADS), (lds_void_t *)(dst + i * THREADS), 16, 0, 0);
+        for (int i = 0; i < CHUNK_U4 / THREADS_T; ++i)
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(g + i * THREADS_T), (lds_void_t *)(dst + i * THREADS_T), 16, 0, 0);
         g += CHUNK_U4;
     };
     issue();
 
-    float x[H];
+    uint4v bh[TILES][NS], bl[TILES][NS];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        const float4 v = *reinterpret_cast<const float4 *>(in + row * W + 16 * ob + 4 * part);
-        x[4 * ob] = v.x; x[4 * ob + 1] = v.y; x[4 * ob + 2] = v.z; x[4 * ob + 3] = v.w;
+    for (int t = 0; t < TILES; ++t) {
+        float x[H];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const float4 v = *reinterpret_cast<const float4 *>(in + (row0 + 16 * t) * W + 16 * ob + 4 * part);
+            x[4 * ob] = v.x; x[4 * ob + 1] = v.y; x[4 * ob + 2] = v.z; x[4 * ob + 3] = v.w;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) split8<DT>(x + 8 * s, bh[t][s], bl[t][s]);
     }
-    uint4v bh[NS], bl[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) split8<DT>(x + 8 * s, bh[s], bl[s]);
 
-    floatx4 acc[NOB];
+    floatx4 acc[TILES][NOB];
     for (int l = 0; l < nl; ++l) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const float4 v = *reinterpret_cast<const float4 *>(bias + l * W + 16 * ob + 4 * part);
-            acc[ob] = floatx4{v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[t][ob] = floatx4{v.x, v.y, v.z, v.w};
         }
         static_for<0, NS / SPC>([&](auto cc) {
             __syncthreads();                       // chunk landed (hipcc drains vmcnt in front of the barrier) and the other buffer is free
@@ -127,12 +134,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_split(const uint4v *__restrict__
 #pragma unroll
                     for (int o = 0; o < 4; ++o) { ah[o] = p[((o0 + o) * 2) * FRAG_U4]; if constexpr (PROD == 3) al[o] = p[((o0 + o) * 2 + 1) * FRAG_U4]; }
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) acc[o0 + o] = mfma16<DT>(ah[o], bh[s], acc[o0 + o]);
-                    if constexpr (PROD == 3) {
+                    for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o0 + o] = mfma16<DT>(al[o], bh[s], acc[o0 + o]);
+                        for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(ah[o], bh[t][s], acc[t][o0 + o]);
+                        if constexpr (PROD == 3) {
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o0 + o] = mfma16<DT>(ah[o], bl[s], acc[o0 + o]);
+                            for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(al[o], bh[t][s], acc[t][o0 + o]);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(ah[o], bl[t][s], acc[t][o0 + o]);
+                        }
                     }
                 }
             });
@@ -140,17 +150,21 @@ __global__ __launch_bounds__(THREADS, 1) void k_split(const uint4v *__restrict__
         if (l + 1 < nl) {
             // ReLU + re-split: the accumulators of blocks 2s, 2s+1 are the B operands of K-step s of the next layer
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float y[8];
+            for (int t = 0; t < TILES; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) y[j] = __int_as_float(max(__float_as_int(acc[2 * s + (j >> 2)][j & 3]), 0));
-                split8<DT>(y, bh[s], bl[s]);
-            }
+                for (int s = 0; s < NS; ++s) {
+                    float y[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) y[j] = __int_as_float(max(__float_as_int(acc[t][2 * s + (j >> 2)][j & 3]), 0));
+                    split8<DT>(y, bh[t][s], bl[t][s]);
+                }
         }
     }
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-        *reinterpret_cast<float4 *>(out + row * W + 16 * ob + 4 * part) = make_float4(acc[ob][0], acc[ob][1], acc[ob][2], acc[ob][3]);
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+            *reinterpret_cast<float4 *>(out + (row0 + 16 * t) * W + 16 * ob + 4 * part) = make_float4(acc[t][ob][0], acc[t][ob][1], acc[t][ob][2], acc[t][ob][3]);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
@@ -201,7 +215,7 @@ static void split_weight(int dt, float w, uint16_t &hi, uint16_t &lo) {
 }
 static int fin(int s, int p, int j) { return 32 * s + 16 * (j >> 2) + 4 * p + (j & 3); }
 
-template <int DT, int PROD>
+template <int DT, int PROD, int TILES = 1>
 static void run(const char *name, const std::vector<float> &Wt, const std::vector<float> &bias, const std::vector<float> &in, long rows,
                 int nl, int reps) {
     // pack: stream[l][s][ob][hi|lo][lane] = 8 x 16 bit
@@ -224,13 +238,13 @@ static void run(const char *name, const std::vector<float> &Wt, const std::vecto
     hipMalloc(&d_b, bias.size() * 4); hipMemcpy(d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&d_in, (size_t)rows * W * 4); hipMemcpy(d_in, in.data(), (size_t)rows * W * 4, hipMemcpyHostToDevice);
     hipMalloc(&d_out, (size_t)rows * W * 4);
-    auto kern = k_split<DT, PROD>;
+    auto kern = k_split<DT, PROD, TILES>;
     hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_U4 * 16);
     const dim3 grid((unsigned)(rows / (WAVES * 16)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(THREADS), 2 * CHUNK_U4 * 16, 0, d_w, d_b, d_in, d_out, nl);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(THREADS / TILES), 2 * CHUNK_U4 * 16, 0, d_w, d_b, d_in, d_out, nl);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(THREADS), 2 * CHUNK_U4 * 16, 0, d_w, d_b, d_in, d_out, nl);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(THREADS / TILES), 2 * CHUNK_U4 * 16, 0, d_w, d_b, d_in, d_out, nl);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     const hipError_t err = hipGetLastError();
@@ -276,6 +290,8 @@ int main(int argc, char **argv) {
     for (int nl : {1, 8}) {
         run<0, 3>("f16 hi/lo, 3 products", Wt, bias, in, rows, nl, reps);
         run<1, 3>("bf16 hi/lo, 3 products", Wt, bias, in, rows, nl, reps);
+        run<0, 3, 2>("f16 hi/lo, 3 products, 2 tiles per wavefront (4 wavefronts)", Wt, bias, in, rows, nl, reps);
+        run<0, 1, 2>("plain f16 (1 product), 2 tiles per wavefront", Wt, bias, in, rows, nl, reps);
         run<0, 1>("plain f16 (1 product)", Wt, bias, in, rows, nl, reps);
         run<1, 1>("plain bf16 (1 product)", Wt, bias, in, rows, nl, reps);
     }
