@@ -80,7 +80,7 @@ __device__ __forceinline__ void split8(const float *x, uint4v &hi, uint4v &lo) {
 
 // TILES: 16-row tiles a wavefront owns (1: 8 wavefronts per workgroup, 2 per SIMD; 2: 4 wavefronts, one per SIMD with the whole
 // 512-register file -- every fragment read from LDS then feeds two tiles' MFMAs)
-template <int DT, int PROD, int TILES>
+template <int DT, int PROD, int TILES, bool PIPE = false>
 __global__ __launch_bounds__(THREADS / TILES, 1) void k_split(const uint4v *__restrict__ wstream, const float *__restrict__ bias,
                                                       const float *__restrict__ in, float *__restrict__ out, int nl) {
     constexpr int WAVES_T = WAVES / TILES, THREADS_T = THREADS / TILES;
@@ -91,7 +91,12 @@ __global__ __launch_bounds__(THREADS / TILES, 1) void k_split(const uint4v *__re
 
     const uint4v *g = wstream + threadIdx.x;
     int cur = 1;
+    int n_issued = 0;
     auto issue = [&]() {
+#ifdef PROBE_NO_DMA
+        if (n_issued >= 2) { g += CHUNK_U4; return; }        // timing experiment: the ring keeps its first two chunks (results invalid)
+#endif
+        ++n_issued;
         uint4v *dst = ring + (cur ^ 1) * CHUNK_U4 + wave * 64;
 #pragma unroll
         for (int i = 0; i < CHUNK_U4 / THREADS_T; ++i)
@@ -125,6 +130,36 @@ __global__ __launch_bounds__(THREADS / TILES, 1) void k_split(const uint4v *__re
             __syncthreads();                       // chunk landed (hipcc drains vmcnt in front of the barrier) and the other buffer is free
             cur ^= 1;
             issue();
+            if constexpr (PIPE) {
+                // explicit software pipeline over the 2 x 4 fragment groups of the chunk: group g + 1 is read before group g's MFMAs issue
+                constexpr int NG = SPC * (NOB / 4);
+                uint4v fh[2][4], fl[2][4];
+                auto rd = [&](auto gc, auto bc) {
+                    constexpr int gidx = decltype(gc)::value, buf = decltype(bc)::value;
+                    const uint4v *p = ring + cur * CHUNK_U4 + (gidx / (NOB / 4)) * STEP_U4 + lane;
+                    constexpr int o0 = (gidx % (NOB / 4)) * 4;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) { fh[buf][o] = p[((o0 + o) * 2) * FRAG_U4]; if constexpr (PROD == 3) fl[buf][o] = p[((o0 + o) * 2 + 1) * FRAG_U4]; }
+                };
+                rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                static_for<0, NG>([&](auto gc) {
+                    constexpr int gidx = decltype(gc)::value, buf = gidx & 1;
+                    constexpr int s = decltype(cc)::value * SPC + gidx / (NOB / 4), o0 = (gidx % (NOB / 4)) * 4;
+                    if constexpr (gidx + 1 < NG) rd(std::integral_constant<int, gidx + 1>{}, std::integral_constant<int, buf ^ 1>{});
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(fh[buf][o], bh[t][s], acc[t][o0 + o]);
+                        if constexpr (PROD == 3) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(fl[buf][o], bh[t][s], acc[t][o0 + o]);
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[t][o0 + o] = mfma16<DT>(fh[buf][o], bl[t][s], acc[t][o0 + o]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else
             static_for<0, SPC>([&](auto sc) {
                 constexpr int s = decltype(cc)::value * SPC + decltype(sc)::value;
                 const uint4v *p = ring + cur * CHUNK_U4 + decltype(sc)::value * STEP_U4 + lane;
@@ -215,7 +250,7 @@ static void split_weight(int dt, float w, uint16_t &hi, uint16_t &lo) {
 }
 static int fin(int s, int p, int j) { return 32 * s + 16 * (j >> 2) + 4 * p + (j & 3); }
 
-template <int DT, int PROD, int TILES = 1>
+template <int DT, int PROD, int TILES = 1, bool PIPE = false>
 static void run(const char *name, const std::vector<float> &Wt, const std::vector<float> &bias, const std::vector<float> &in, long rows,
                 int nl, int reps) {
     // pack: stream[l][s][ob][hi|lo][lane] = 8 x 16 bit
@@ -238,7 +273,7 @@ static void run(const char *name, const std::vector<float> &Wt, const std::vecto
     hipMalloc(&d_b, bias.size() * 4); hipMemcpy(d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&d_in, (size_t)rows * W * 4); hipMemcpy(d_in, in.data(), (size_t)rows * W * 4, hipMemcpyHostToDevice);
     hipMalloc(&d_out, (size_t)rows * W * 4);
-    auto kern = k_split<DT, PROD, TILES>;
+    auto kern = k_split<DT, PROD, TILES, PIPE>;
     hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_U4 * 16);
     const dim3 grid((unsigned)(rows / (WAVES * 16)));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -291,6 +326,8 @@ int main(int argc, char **argv) {
         run<0, 3>("f16 hi/lo, 3 products", Wt, bias, in, rows, nl, reps);
         run<1, 3>("bf16 hi/lo, 3 products", Wt, bias, in, rows, nl, reps);
         run<0, 3, 2>("f16 hi/lo, 3 products, 2 tiles per wavefront (4 wavefronts)", Wt, bias, in, rows, nl, reps);
+        run<0, 3, 1, true>("f16 hi/lo, 3 products, fragment reads one group ahead", Wt, bias, in, rows, nl, reps);
+        run<0, 3, 2, true>("f16 hi/lo, 3 products, 2 tiles per wavefront, fragment reads one group ahead", Wt, bias, in, rows, nl, reps);
         run<0, 1, 2>("plain f16 (1 product), 2 tiles per wavefront", Wt, bias, in, rows, nl, reps);
         run<0, 1>("plain f16 (1 product)", Wt, bias, in, rows, nl, reps);
         run<1, 1>("plain bf16 (1 product)", Wt, bias, in, rows, nl, reps);
