@@ -166,8 +166,14 @@ __global__ __launch_bounds__(THREADS / TILES, 1) void k_split(const uint4v *__re
 #pragma unroll
                 for (int o0 = 0; o0 < NOB; o0 += 4) {
                     uint4v ah[4], al[4];
+#ifdef PROBE_NO_LDS
+                    // timing experiment (results invalid): one fragment group per K-step is read, every output block reuses it
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) { ah[o] = p[(o * 2) * FRAG_U4]; if constexpr (PROD == 3) al[o] = p[(o * 2 + 1) * FRAG_U4]; }
+#else
 #pragma unroll
                     for (int o = 0; o < 4; ++o) { ah[o] = p[((o0 + o) * 2) * FRAG_U4]; if constexpr (PROD == 3) al[o] = p[((o0 + o) * 2 + 1) * FRAG_U4]; }
+#endif
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
 #pragma unroll
