@@ -318,13 +318,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if os.environ.get('MNR_BENCH_SHARE_GPU'):          # diagnostics: several ranks on ONE GPU (exercises the N > 1 code path on a 1-GPU box)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)            # RCCL on ROCm, communicator bound to this rank's GPU
+        if os.environ.get('MNR_BENCH_SHARE_GPU'):
+            dist.init_process_group('gloo')                       # (RCCL refuses two ranks on one device)
+        else:
+            dist.init_process_group('nccl', device_id=dev)        # RCCL on ROCm, communicator bound to this rank's GPU
     assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
 
     import synthetic_scene as S                    # seeded scene / weight generator (pure numpy; no oracle code)
