@@ -131,3 +131,44 @@ def test_split_precision_routed_container(split_precision):
         render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']),
                     *[bool(v) for v in g['flags']])
     assert nerf._last_routed_split is True                  # the split-precision launch really served it
+
+
+@pytest.mark.parametrize('name', ['fg', 'bg'])
+def test_split_precision_routed_launch_ragged_cells(name):
+    """mnr_mlp_forward_cells_h2 against mnr_mlp_forward_cells (the fp32 routed launch) on hand-made row lists: an empty cell, a
+    one-row cell, counts that are not multiples of the 128-row workgroup tile, rows listed by two cells -- same rows, same cell
+    weights, outputs within the split kernel's rounding of the fp32 kernel's."""
+    from mega_nerf import _native as N
+    lib = N.lib()
+    hp, cfg, w = mlp_variant(name)
+    rng = np.random.default_rng(17)
+    B, S = 1536, 8
+    n_ray = B // S
+    xyz = rng.uniform(-1, 1, (B, cfg.xyz_dim)).astype(f32)
+    dirs = rng.standard_normal((n_ray, 3)).astype(f32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    idx = rng.integers(0, 100, n_ray).astype(f32)
+    counts = [0, 1, 130, 517, 1536]
+    kids = [native_nerf(cfg, {k: (v * f32(1 + 0.03 * i)).astype(f32) for k, v in w.items()}) for i in range(len(counts))]
+    lists = torch.zeros(len(counts), B, dtype=torch.int32, device=DEV)
+    for i, c in enumerate(counts):
+        lists[i, :c] = torch.from_numpy(np.sort(rng.permutation(B)[:c]).astype(np.int32)).to(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    t = [T(a) for a in (xyz, dirs, idx)]
+    outs = {}
+    for split in (False, True):
+        sub_out = torch.full((len(counts), B, 4), -7.0, device=DEV)
+        rows = []
+        for i, child in enumerate(kids):
+            _, packed = child.packed_h2() if split else child.packed()
+            rows.append([packed.data_ptr(), child.embedding_a.weight.data_ptr(), lists[i].data_ptr(), cnt[i:i + 1].data_ptr(), sub_out[i].data_ptr()])
+        cells = torch.tensor(rows, dtype=torch.int64).to(DEV)
+        desc, _ = kids[0].packed()
+        io = kids[0].mlp_io(t[0], cfg.xyz_dim, t[1], 3, t[2], 1, S, B, sub_out[0], None, None, 0)
+        fn = lib.mnr_mlp_forward_cells_h2 if split else lib.mnr_mlp_forward_cells
+        N.check(fn(C.byref(desc), cells.data_ptr(), len(counts), C.byref(io), None))
+        torch.cuda.synchronize()
+        outs[split] = sub_out.cpu().numpy()
+    for i, c in enumerate(counts):
+        np.testing.assert_allclose(outs[True][i, :c], outs[False][i, :c], rtol=2e-5, atol=2e-6, err_msg='cell %d' % i)
+        assert (outs[True][i, c:] == -7.0).all(), 'rows past the count of cell %d were written' % i
