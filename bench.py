@@ -59,7 +59,7 @@ def build_models(hp, dev, seed, layer_dim=256):
         cfg = S.model_cfg(hp, xyz_dim, layer_dim if xyz_dim == 3 else hp.bg_layer_dim)     # opts.py:48-49: --layer_dim is the foreground's
         w = S.make_weights(cfg, A, s)
         m = NeRF(cfg.pos_xyz_dim, cfg.pos_dir_dim, cfg.layers, cfg.skip_layers, cfg.layer_dim, cfg.appearance_dim,
-                 False, A, 3, xyz_dim, ShiftedSoftplus())
+                 False, A, cfg.rgb_dim, xyz_dim, ShiftedSoftplus())
         m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
         out.append((m.to(dev), cfg, w))
     return out
@@ -291,7 +291,7 @@ def cpu_baseline_container(hp, rays_np, idx_np, cells):
 
 # ---- main ------------------------------------------------------------------------------------------------------------
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -304,15 +304,22 @@ def main():
                     help='strong scaling: a fixed set of S submodules dealt round-robin to the ranks (0 = one private submodule per rank)')
     ap.add_argument('--layer-dim', type=int, default=256,
                     help='MLP width (256 = the headline Rubble config; 512 = configs/mega-nerf Building: layer-by-layer tiled GEMM path)')
+    ap.add_argument('--sh-deg', type=int, default=None,
+                    help='spherical-harmonics colour head (BASELINE configs[4], configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the N = 1 side measurements and the PSNR check')
+    ap.add_argument('--no-config-sweep', action='store_true',
+                    help='skip the compact lines of the other BASELINE configs (8-cell set, container, W=512, SH) in the default run')
     ap.add_argument('--only-split-extras', action='store_true',
                     help='of the side measurements keep the split-precision ones only (profiling runs of the k_mlp_*_h2 kernels)')
     ap.add_argument('--container', type=int, default=0, metavar='N',
                     help='eval mode only: render through a merged N-cell container (MegaNeRF router, boundary_margin 1.15) '
                          'instead of one submodule -- the "8-submodule Rubble" evaluation shape on ONE GPU')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -331,7 +338,105 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)        # RCCL on ROCm, communicator bound to this rank's GPU
     assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
+    line = run_config(args, rank, world, dev, dist)
+    headline = (world == 1 and args.mode == 'train' and not args.submodules and not args.container and args.layer_dim == 256 and
+                args.sh_deg is None and args.samples == '64,128' and args.rays == 1024)
+    if rank == 0 and headline and not args.no_extras and not args.no_config_sweep:
+        t0 = time.perf_counter()
+        line['baseline_configs'] = config_sweep(args, dev)
+        line['runner_loop'] = runner_loop(args, dev, line['value'])
+        line['baseline_configs']['_seconds'] = round(time.perf_counter() - t0, 1)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
+
+# BASELINE.json `configs` beyond the headline one (configs[1]), each as a compact line of the default run: same code path as the
+# flag combination named in `flags`, short timed region, no CPU baseline, no side measurements
+SWEEP = [
+    ('configs[2] Rubble 8 submodules, ONE GPU trains the whole set (one mnr_train_step call per iteration)', ['--submodules', '8', '--mode', 'train']),
+    ('configs[2] Rubble merged 8-cell container, routed eval', ['--container', '8', '--mode', 'eval']),
+    ('configs[3] Building-shaped cell (fg 8x512), train', ['--layer-dim', '512', '--mode', 'train']),
+    ('configs[3] Building-shaped cell (fg 8x512), eval', ['--layer-dim', '512', '--mode', 'eval']),
+    ('configs[3] Building merged 25-cell container of 512-wide cells, routed eval', ['--layer-dim', '512', '--container', '25', '--mode', 'eval']),
+    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), train', ['--sh-deg', '2', '--mode', 'train']),
+    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), eval', ['--sh-deg', '2', '--mode', 'eval']),
+]
+
+
+def config_sweep(args, dev):
+    import gc
+    out = {}
+    for name, flags in SWEEP:
+        a = parse_args(flags + ['--steps', '10', '--warmup', '3', '--no-cpu-baseline', '--no-extras', '--rays', str(args.rays), '--samples', args.samples])
+        t0 = time.perf_counter()
+        try:
+            ln = run_config(a, 0, 1, dev, None)
+            r = ln.get('roofline') or {}
+            out[name] = {'flags': ' '.join(flags), 'ms_per_step': round(ln['ms_per_step'], 4), 'rays_per_sec': round(ln['value'], 1),
+                         'steps': a.steps, 'frac': r.get('frac'), 'frac_of': (r.get('kernel') or '').split(' (')[0], 'peak_tflops': r.get('peak'),
+                         'achieved_tflops': r.get('achieved'), 'workload': ln['config']['workload'],
+                         'seconds': round(time.perf_counter() - t0, 1)}
+            for k in ('step_spans_ms',):
+                if k in ln:
+                    out[name][k] = ln[k]
+            if 'routed_rows_per_step' in r:
+                out[name]['routed_rows_per_step'] = r['routed_rows_per_step']
+        except Exception as e:                      # a side line must never take the headline down
+            out[name] = {'flags': ' '.join(flags), 'error': '%s: %s' % (type(e).__name__, e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def runner_loop(args, dev, value):
+    """Rays/s of the DROP-IN trainer: mega_nerf.runner.Runner.train() (the loop train.py runs, reference runner.py:244-277) over a
+    device-resident synthetic dataset at the headline shape, timed from iteration 20 to the last one (a hook the Runner calls after
+    every iteration synchronises at the two ends): dataset.batches() gathers + the one-call step + scheduler + periodic health check."""
+    import shutil
+    import subprocess
+    import tempfile
+    from mega_nerf.runner import Runner
+    from mega_nerf.opts import get_opts_base
+    tmp = Path(tempfile.mkdtemp(prefix='mnr_bench_'))
+    try:
+        data = tmp / 'data'
+        subprocess.run([sys.executable, str(ROOT / 'mega-nerf_amd' / 'tools' / 'make_synthetic_dataset.py'), '--out', str(data), '--images', '8',
+                        '--val_every', '8', '--size', '96', '--samples', '64', '128'], check=True, stdout=subprocess.DEVNULL)
+        p = get_opts_base()
+        p.add_argument('--exp_name', type=str, required=True)
+        p.add_argument('--dataset_path', type=str, required=True)
+        iters, first = 20 + args.steps, 20
+        hp = p.parse_args(['--dataset_path', str(data), '--exp_name', str(tmp / 'exp'), '--coarse_samples', '64', '--fine_samples', '128',
+                           '--near', '0.01', '--ray_altitude_range', '-0.5', '0.2', '--val_scale_factor', '4', '--batch_size', str(args.rays),
+                           '--train_iterations', str(iters)])
+        r = Runner(hp)
+        marks = {}
+
+        def hook(it):
+            if it in (first, iters):
+                torch.cuda.synchronize()
+                marks[it] = time.perf_counter()
+        r.iteration_hook = hook
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            r.train()
+        dt = (marks[iters] - marks[first]) / (iters - first)
+        fused = r.trainer is not None and r.trainer.fused is not None
+        return {'rays_per_sec': round(args.rays / dt, 1), 'ms_per_iteration': round(dt * 1e3, 4), 'iterations_timed': iters - first,
+                'fraction_of_value': round(args.rays / dt / value, 4), 'one_call_step': bool(fused),
+                'what': 'Runner.train() on a %d-pixel device-resident MemoryDataset, batch %d: batch gathers + mnr_train_step + ExponentialLR + '
+                        'health check every 100 iterations' % (8 * 96 * 96 - 96 * 48, args.rays)}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_config(args, rank, world, dev, dist):
+    """One measured configuration -> the JSON line (rank 0; None elsewhere)."""
     import synthetic_scene as S                    # seeded scene / weight generator (pure numpy; no oracle code)
     from mega_nerf import ray_utils, rendering
     from mega_nerf.distributed import assign_submodules
@@ -341,8 +446,9 @@ def main():
 
     Nc, Nf = [int(v) for v in args.samples.split(',')]
     # opts.py defaults = configs/mega-nerf (8x256, 12/4 frequency bands, 48-d appearance) at the benchmark's samples per ray
-    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf), '--layer_dim', str(args.layer_dim)])
-    wide = args.layer_dim != 256                   # side measurement of the wide configs: headline numbers only
+    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf), '--layer_dim', str(args.layer_dim)] +
+                                    (['--sh_deg', str(args.sh_deg), '--pos_dir_dim', '0'] if args.sh_deg is not None else []))
+    wide = args.layer_dim != 256 or args.sh_deg is not None          # side measurement of the other architectures: whole-step figures only
     s = S.SCENE
     sc, sr = torch.from_numpy(s['sphere_center']).to(dev), torch.from_numpy(s['sphere_radius']).to(dev)
     d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
@@ -435,6 +541,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     rendering.KERNEL_EVENTS = None
+    if args.container:      # the router's device-side tally of the TIMED steps only (every later render of this function adds to it)
+        routed_timed = (int(work[0]['fg'].routed_rows), int(work[0]['bg'].routed_rows))
     if args.mode == 'eval' and not ev and not args.container:
         # the timed steps went through mnr_render_fwd (six launches, no Python between them): take the kernel-level timings of
         # the MLP launches -- the same kernel over the same rows -- from the stage-by-stage sequencing of the same render
@@ -638,7 +746,7 @@ def main():
         roof, extra_roof = None, {}
         if args.container:
             # whole-step figure from the device-side routed row counts (a row inside the boundary margin is evaluated by two cells)
-            r_fg, r_bg = int(work[0]['fg'].routed_rows), int(work[0]['bg'].routed_rows)
+            r_fg, r_bg = routed_timed
             fl = (r_fg * FG_FLOP_PER_SAMPLE + r_bg * BG_FLOP_PER_SAMPLE) / args.steps
             ach = fl / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -731,9 +839,8 @@ def main():
             line['step_spans_ms']['non_mlp_share_of_step'] = round(1.0 - mlp_ms / (dt / args.steps * 1e3), 4)
             line['host']['launches_per_step'] = 11 + 2 * len(work)      # memset + 10 kernels + (k_wgrad2 + reduce) per cell
         line.update(extras)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 if __name__ == '__main__':

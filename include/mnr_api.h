@@ -549,6 +549,10 @@ typedef struct mnr_step_model {
     mnr_model_desc desc;             /* the nn.Module parameters (updated in place by the optimiser) */
     mnr_model_grads grad;            /* param.grad: views INTO the workspace's gradient area (zeroed at the start of every step) */
     mnr_model_grads adam_m, adam_v;  /* torch.optim.Adam's exp_avg / exp_avg_sq, same shapes (caller-owned, zero before step 1) */
+    int32_t *adam_steps_dev;         /* DEVICE int32: optimiser steps this model has taken (torch.optim.Adam's per-parameter `step`; caller-owned,
+                                        0 before step 1, set from a checkpoint on resume).  The step reads it for the bias corrections and
+                                        advances it -- for a background model only on batches with background rays, which are the only
+                                        ones the reference steps that optimiser on (runner.py:268-272) */
     void *packed_dev;                /* mnr_packed_model_bytes(desc) bytes: re-packed at the end of every step */
     void *packed_bwd_dev;            /* mnr_packed_bwd_bytes(desc) bytes */
     void *packed_h2_dev;             /* cfg.split_precision: mnr_packed_model_h2_bytes / mnr_packed_bwd_h2_bytes bytes INSTEAD of the */
@@ -583,7 +587,12 @@ typedef struct mnr_step_layout {
     size_t tape_fg_offset, tape_bg_offset;   /* the activation tapes (mlp_layout.h TapeLayout planes, tape_*_rows rows each): cell c's coarse */
     int64_t tape_fg_rows, tape_bg_rows;      /*   rows start at row c * (tape_*_rows / n_cells), its fine rows follow (tests read the ReLU masks here) */
     size_t gtape_fg_offset, gtape_bg_offset; /* the gradient tapes (same planes: dL/d(pre-activation) of every layer) */
+    size_t sticky_offset;            /* int32  [n_cells]          MNR_STEP_STICKY_* bits OR-ed over all optimising steps since mnr_step_create
+                                        (never cleared by a step): lets a trainer check "Train metrics not finite" (runner.py:260-261) and
+                                        the camera-outside-sphere error (rendering.py:412-414) every k steps instead of synchronising every step */
 } mnr_step_layout;
+#define MNR_STEP_STICKY_NONFINITE 1  /* a step's loss was NaN / inf */
+#define MNR_STEP_STICKY_OUTSIDE   2  /* a step's batch had a camera outside the unit ellipsoid */
 int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg_arch, const mnr_model_desc *bg_arch, mnr_step_layout *out);
 
 typedef struct mnr_step_plan mnr_step_plan;
@@ -609,8 +618,9 @@ typedef struct mnr_step_randoms {    /* optional injected uniforms of one cell (
 } mnr_step_randoms;
 #define MNR_STEP_NO_OPTIMIZER 1      /* flags: stop after the gradients (no Adam, no re-pack) */
 /* batches [n_cells]; randoms NULL or [n_cells]; lr = this step's learning rate (the caller applies ExponentialLR,
- * runner.py:173-176); adam_step = 1, 2, ... (bias correction); seed + adam_step key the counter-based generator. */
-int mnr_train_step(mnr_step_plan *plan, const mnr_step_batch *batches, const mnr_step_randoms *randoms, float lr, int64_t adam_step,
+ * runner.py:173-176; a double, as torch.optim.Adam computes lr / bias_correction1 before it rounds to fp32); iteration = 1, 2, ...:
+ * seed + iteration key the counter-based generator (the bias corrections come from each model's adam_steps_dev). */
+int mnr_train_step(mnr_step_plan *plan, const mnr_step_batch *batches, const mnr_step_randoms *randoms, double lr, int64_t iteration,
                    uint64_t seed, int flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@
 // gradients equal the stage-by-stage path's: tests/test_gpu_step.py) with the intermediate arrays of a ray kept in LDS /
 // registers.  Compiled with -ffp-contract=off like render.hip (bit-exact sample positions).
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -105,6 +107,7 @@ struct StepWs {
     size_t tape_f, gtape_f, dheads_f, tape_b, gtape_b, dheads_b;
     size_t ep_job, slab;
     size_t tab_cells, tab_pack, tab_adam, t_c, t_bc, t_f, t_bf;
+    size_t sticky;                            // int32 [MAXC]: health bits that survive the per-step memset (cleared by mnr_step_create)
     size_t grad_stride, total;
 };
 struct StepDims {
@@ -164,6 +167,7 @@ static void step_layout(const mnr_step_cfg *cfg, const StepDims &D, StepWs &L) {
     L.tab_pack = take(0);       // sized below (depends on the plan's tables); placeholder keeps the order explicit
     L.tab_adam = take(0);
     L.t_c = take(D.Nc * 4); L.t_bc = take(D.Sb * 4); L.t_f = take(D.Nf * 4); L.t_bf = take(D.Sfb * 4);
+    L.sticky = take(MAXC * 4);
     L.total = off;
 }
 
@@ -753,10 +757,13 @@ __global__ __launch_bounds__(64 * WPB) void k_render_tail(RTailArgs a) {
 }
 
 // ---- optimiser + re-pack -----------------------------------------------------------------------------------------------------
-struct AdamTensor { float *p; const float *g; float *m, *v; long n, block0; };
+// gate: NULL, or the device-side count of rays with a background segment of the tensor's cell -- the reference steps the background
+// optimiser only when the batch had such rays (runner.py:268-272); steps: how many updates the tensor's optimiser has applied so far
+// (torch.optim.Adam's per-parameter `step`, the exponent of the bias corrections), advanced by k_step_pack behind this kernel.
+struct AdamTensor { float *p; const float *g; float *m, *v; long n, block0; const int32_t *gate; const int32_t *steps; };
 
-__global__ __launch_bounds__(256) void k_step_adam(const AdamTensor *__restrict__ tab, int n_tensors, float beta1, float beta2, float eps,
-                                                   float step_size, float bc2_sqrt) {
+__global__ __launch_bounds__(256) void k_step_adam(const AdamTensor *__restrict__ tab, int n_tensors, double beta1, double beta2, double eps,
+                                                   double lr) {
     // binary search: the tensor whose block range holds this block
     int lo = 0, hi = n_tensors - 1;
     const long b = blockIdx.x;
@@ -765,16 +772,28 @@ __global__ __launch_bounds__(256) void k_step_adam(const AdamTensor *__restrict_
         if (tab[mid].block0 <= b) lo = mid; else hi = mid - 1;
     }
     const AdamTensor t = tab[lo];
+    if (t.gate && *t.gate <= 0) return;                                     // (uniform per block)
+    // torch/optim/adam.py _single_tensor_adam: the scalars are Python doubles, rounded to fp32 where they meet a tensor
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)(*t.steps + 1);
+        const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+        sh[0] = (float)(lr / bc1);                                           // step_size
+        sh[1] = (float)sqrt(bc2);                                            // bias_correction2_sqrt
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2_sqrt = sh[1];
+    const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2), epsf = (float)eps;
     const long i0 = ((b - t.block0) * 256 + threadIdx.x) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long i = i0 + j;
         if (i < t.n) {
-            // torch/optim/adam.py (_single_tensor_adam / the fused kernel), no weight decay, no amsgrad
+            // no weight decay, no amsgrad
             const float g = t.g[i];
-            const float m = t.m[i] + (g - t.m[i]) * (1.f - beta1);          // exp_avg.lerp_(grad, 1 - beta1)
-            const float v = beta2 * t.v[i] + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            const float m = t.m[i] + (g - t.m[i]) * w1;                     // exp_avg.lerp_(grad, 1 - beta1)
+            const float v = b2f * t.v[i] + w2 * g * g;                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+            const float denom = sqrtf(v) / bc2_sqrt + epsf;
             t.p[i] = t.p[i] - step_size * (m / denom);
             t.m[i] = m; t.v[i] = v;
         }
@@ -786,15 +805,33 @@ struct PackJob {
     long block0, nblocks, n_u4;
     float4 *chunks;
     float *aux;
+    // end-of-step bookkeeping, done by thread 0 of a model's forward-image job when the kernel runs behind k_step_adam (after_adam):
+    const int32_t *gate;       // as AdamTensor::gate: the model was not updated this step -> its images are current, its step count stands
+    int32_t *steps;            // the model's optimiser step counter (forward-image jobs only)
+    const float *loss;         // foreground forward-image jobs only: the cell's loss / error flag of this step -> sticky health bits
+    const int32_t *err;
+    int32_t *sticky;
     ModelLayout m;
     BwdLayout b;
 };
-__global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ jobs, int n_jobs) {
+__global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ jobs, int n_jobs, int after_adam) {
     int j = 0;
     const long blk = blockIdx.x;
     for (int i = 1; i < n_jobs; ++i) j += blk >= jobs[i].block0;
     const PackJob &job = jobs[j];
     const long tid = (blk - job.block0) * 256 + threadIdx.x;
+    if (after_adam) {
+        const bool skipped = job.gate && *job.gate <= 0;
+        if (tid == 0) {
+            if (job.steps && !skipped) job.steps[0] += 1;
+            if (job.sticky) {
+                const float l = job.loss[0];
+                const int bits = ((l - l) != 0.f ? MNR_STEP_STICKY_NONFINITE : 0) | (job.err[0] ? MNR_STEP_STICKY_OUTSIDE : 0);
+                if (bits) job.sticky[0] |= bits;
+            }
+        }
+        if (skipped) return;
+    }
     if (job.kind == 0) pack_model_thread(job.m, job.chunks, job.aux, tid);
     else if (job.kind == 1) pack_bwd_thread(job.b, job.chunks, tid);
     else if (job.kind == 2) pack_model_h2_thread(job.m, reinterpret_cast<uint4v *>(job.chunks), job.aux, job.n_u4, tid);
@@ -832,6 +869,13 @@ struct mnr_step_plan {
     }
 };
 
+// the shortest decimal that round-trips the float, read back as a double: 0.9f -> 0.9, the value torch.optim.Adam computes with
+static double as_typed(float f) {
+    char buf[32];
+    snprintf(buf, sizeof buf, "%.7g", (double)f);
+    return strtod(buf, nullptr);
+}
+
 static size_t pack_table_bytes(int C) { return (size_t)4 * C * sizeof(PackJob); }
 static size_t adam_table_bytes(int C) { return (size_t)2 * C * 32 * sizeof(AdamTensor); }
 
@@ -858,17 +902,18 @@ extern "C" int mnr_step_query(const mnr_step_cfg *cfg, const mnr_model_desc *fg,
     out->n_bg_offset = L.scal; out->err_offset = L.scal + MAXC * 4;
     out->tape_fg_offset = L.tape_f; out->tape_bg_offset = L.tape_b; out->tape_fg_rows = D.C * D.cap_f; out->tape_bg_rows = D.C * D.cap_b;
     out->gtape_fg_offset = L.gtape_f; out->gtape_bg_offset = L.gtape_b;
+    out->sticky_offset = L.sticky;
     return MNR_OK;
 }
 
 // tensors of one model in (param, grad, m, v) form
-static int adam_tensors_of(const mnr_step_model &M, std::vector<AdamTensor> &out) {
+static int adam_tensors_of(const mnr_step_model &M, const int32_t *gate, std::vector<AdamTensor> &out) {
     const mnr_model_desc &d = M.desc;
     const int W = d.layer_dim, E = emb_cols(d.xyz_dim, d.pos_xyz_dim), ED = emb_cols(3, d.pos_dir_dim);
     int err = 0;
     auto add = [&](const float *p, float *g, float *m, float *v, long n) {
         if (!p || !g || !m || !v) { err = 1; return; }
-        out.push_back(AdamTensor{const_cast<float *>(p), g, m, v, n, 0});
+        out.push_back(AdamTensor{const_cast<float *>(p), g, m, v, n, 0, gate, M.adam_steps_dev});
     };
     for (int l = 0; l < d.layers; ++l) {
         const long in = l == 0 ? E : (((d.skip_mask >> l) & 1) ? E + W : W);
@@ -884,14 +929,14 @@ static int adam_tensors_of(const mnr_step_model &M, std::vector<AdamTensor> &out
     add(d.sigma_b, M.grad.sigma_b, M.adam_m.sigma_b, M.adam_v.sigma_b, 1);
     add(d.rgb_w, M.grad.rgb_w, M.adam_m.rgb_w, M.adam_v.rgb_w, (long)d.rgb_dim * (W / 2));
     add(d.rgb_b, M.grad.rgb_b, M.adam_m.rgb_b, M.adam_v.rgb_b, d.rgb_dim);
-    MNR_REQUIRE(!err, "mnr_step_create: a parameter / gradient / Adam-moment pointer is missing");
+    MNR_REQUIRE(!err && M.adam_steps_dev, "mnr_step_create: a parameter / gradient / Adam-moment / step-counter pointer is missing");
     return MNR_OK;
 }
 
 extern "C" int mnr_step_repack(mnr_step_plan *p, void *stream) {
     MNR_REQUIRE(p, "NULL plan");
     hipLaunchKernelGGL(k_step_pack, dim3((unsigned)p->pack_blocks), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const PackJob *>(p->ws + p->L.tab_pack), p->n_pack_jobs);
+                       reinterpret_cast<const PackJob *>(p->ws + p->L.tab_pack), p->n_pack_jobs, 0);
     return check_launch("k_step_pack");
 }
 
@@ -960,7 +1005,17 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
             jb.nblocks = split ? ((long)h2b_total_chunks(bl) * H2_CHUNK_U4 + 255) / 256 : ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
             pack_blocks += jb.nblocks;
             jobs.push_back(jb);
-            if ((rc = adam_tensors_of(M, adam)) != MNR_OK) return fail(rc);
+            // background models are stepped only on batches with background rays (runner.py:268-272): gated on the cell's device-side count
+            const int32_t *gate = k == 1 ? reinterpret_cast<const int32_t *>(ws + L.scal) + c : nullptr;
+            jobs[jobs.size() - 2].gate = jobs[jobs.size() - 1].gate = gate;
+            jobs[jobs.size() - 2].steps = M.adam_steps_dev;
+            if (k == 0) {
+                PackJob &jf0 = jobs[jobs.size() - 2];
+                jf0.loss = reinterpret_cast<const float *>(ws + L.loss) + c;
+                jf0.err = reinterpret_cast<const int32_t *>(ws + L.scal) + MAXC + c;
+                jf0.sticky = reinterpret_cast<int32_t *>(ws + L.sticky) + c;
+            }
+            if ((rc = adam_tensors_of(M, gate, adam)) != MNR_OK) return fail(rc);
             // the four (branch, pass) cell tables: fg coarse, fg fine, bg coarse, bg fine
             for (int pass = 0; pass < 2; ++pass) {
                 MlpCellSeg &e = cells[(2 * k + pass) * C + c];
@@ -991,6 +1046,7 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
     up(L.t_bc, plan->tables.data() + D.Nc, D.Sb * 4);
     up(L.t_f, plan->tables.data() + D.Nc + D.Sb, D.Nf * 4);
     up(L.t_bf, plan->tables.data() + D.Nc + D.Sb + D.Nf, D.Sfb * 4);
+    ok = ok && hipMemsetAsync(ws + L.sticky, 0, MAXC * 4, s) == hipSuccess;
     // the host vectors above die with this scope: the copies must have left them
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return fail(set_err(MNR_E_LAUNCH, "mnr_step_create: table upload failed: %s", hipGetErrorString(hipGetLastError())));
@@ -1039,7 +1095,7 @@ extern "C" int mnr_step_kernel_times(mnr_step_plan *p, int slot, float *ms_out) 
     return MNR_OK;
 }
 
-extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, const mnr_step_randoms *randoms, float lr, int64_t adam_step,
+extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, const mnr_step_randoms *randoms, double lr, int64_t adam_step,
                               uint64_t seed, int flags, void *stream) {
     MNR_REQUIRE(p && batches && adam_step >= 1, "bad arguments to mnr_train_step");
     const StepDims &D = p->D;
@@ -1259,14 +1315,15 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     // ---- Adam (torch.optim.Adam defaults of runner.py:169-171) + re-pack ----
     mark(8, 0);
     {
-        const double b1 = p->cfg.adam_beta1, b2 = p->cfg.adam_beta2;
-        const double bc1 = 1.0 - pow(b1, (double)adam_step), bc2 = 1.0 - pow(b2, (double)adam_step);
+        // the hyper-parameters as the Python doubles the caller typed (0.9, 0.999, 1e-8), not as the widened floats of the cfg struct
         hipLaunchKernelGGL(k_step_adam, dim3((unsigned)p->adam_blocks), dim3(256), 0, s, reinterpret_cast<const AdamTensor *>(ws + L.tab_adam),
-                           p->n_adam_tensors, (float)b1, (float)b2, p->cfg.adam_eps, (float)((double)lr / bc1), (float)sqrt(bc2));
+                           p->n_adam_tensors, as_typed(p->cfg.adam_beta1), as_typed(p->cfg.adam_beta2), as_typed(p->cfg.adam_eps), lr);
         rc = check_launch("k_step_adam");
         if (rc) return rc;
     }
-    rc = mnr_step_repack(p, stream);
+    hipLaunchKernelGGL(k_step_pack, dim3((unsigned)p->pack_blocks), dim3(256), 0, s, reinterpret_cast<const PackJob *>(ws + L.tab_pack),
+                       p->n_pack_jobs, 1);
+    rc = check_launch("k_step_pack");
     mark(8, 1);
     return rc;
 }

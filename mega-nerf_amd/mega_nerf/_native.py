@@ -125,6 +125,7 @@ class CompositeGradIO(C.Structure):
 
 MNR_STEP_MAX_CELLS = 16
 MNR_STEP_NO_OPTIMIZER = 1
+MNR_STEP_STICKY_NONFINITE, MNR_STEP_STICKY_OUTSIDE = 1, 2
 MNR_STEP_SPANS = 9
 STEP_SPAN_NAMES = ('samples', 'fwd_c', 'mid', 'fwd_f', 'tail', 'bwd', 'head_grads', 'wgrad', 'adam_pack')
 
@@ -132,6 +133,7 @@ STEP_SPAN_NAMES = ('samples', 'fwd_c', 'mid', 'fwd_f', 'tail', 'bwd', 'head_grad
 class StepModel(C.Structure):
     """struct mnr_step_model"""
     _fields_ = [('desc', ModelDesc), ('grad', ModelGrads), ('adam_m', ModelGrads), ('adam_v', ModelGrads),
+                ('adam_steps_dev', C.c_void_p),
                 ('packed_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p), ('packed_h2_dev', C.c_void_p), ('packed_bwd_h2_dev', C.c_void_p)]
 
 
@@ -148,7 +150,8 @@ class StepLayout(C.Structure):
     _fields_ = [('workspace_bytes', C.c_size_t), ('grad_offset', C.c_size_t), ('grad_stride', C.c_size_t), ('loss_offset', C.c_size_t),
                 ('rgb_offset', C.c_size_t), ('depth_var_offset', C.c_size_t), ('bg_lambda_offset', C.c_size_t),
                 ('n_bg_offset', C.c_size_t), ('err_offset', C.c_size_t), ('tape_fg_offset', C.c_size_t), ('tape_bg_offset', C.c_size_t),
-                ('tape_fg_rows', C.c_int64), ('tape_bg_rows', C.c_int64), ('gtape_fg_offset', C.c_size_t), ('gtape_bg_offset', C.c_size_t)]
+                ('tape_fg_rows', C.c_int64), ('tape_bg_rows', C.c_int64), ('gtape_fg_offset', C.c_size_t), ('gtape_bg_offset', C.c_size_t),
+                ('sticky_offset', C.c_size_t)]
 
 
 class StepBatch(C.Structure):
@@ -318,7 +321,7 @@ def lib() -> C.CDLL:
         _lib.mnr_render_fwd.argtypes = [C.POINTER(RenderIO), C.c_void_p]
         _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
-        _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_float, C.c_int64, C.c_uint64, C.c_int,
+        _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_double, C.c_int64, C.c_uint64, C.c_int,
                                         C.c_void_p]
     return _lib
 

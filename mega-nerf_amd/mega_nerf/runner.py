@@ -9,8 +9,11 @@ right-half validation PSNR, image-parallel validation (image i on rank i % world
 What changes (MI355X-first): the training set is device resident and batches are drawn on the device; compute is
 fp32 (``--no_amp`` is implied); validation metrics are combined with ONE all_reduce instead of temp files
 (mega_nerf.distributed); SSIM/LPIPS/TensorBoard/JPEG dumps are out of scope (optional if the packages exist).
-Data-parallel training of one submodule over several ranks (DDP, runner.py:120-129) is not provided: the
-multi-GPU layout is one submodule per GPU (parscripts/run_8.txt), i.e. independent single-rank Runners.
+Training of the default architecture runs the whole iteration (render, loss, backward, Adam on both models, re-pack) as ONE
+native call per step (``mnr_train_step`` through ``training.CellTrainer``) with no host synchronisation between the log /
+checkpoint intervals; the optimiser objects and the checkpoint's ``optimizers`` entry stay torch.optim.Adam's.
+The multi-GPU layout is one submodule per GPU (parscripts/run_8.txt), i.e. independent single-rank Runners; the reference's
+DDP mode (several ranks on one submodule, runner.py:120-129) is kept on the stage-by-stage autograd path.
 """
 from __future__ import annotations
 
@@ -120,8 +123,8 @@ class Runner:
     # ------------------------------------------------------------------------------------------------
     def train(self):
         # Several ranks on ONE submodule (the reference's DDP + DistributedSampler mode, runner.py:120-129,228-238): every rank
-        # walks the same shuffled epoch and trains on the batches  index % world == rank; gradients are averaged with one
-        # all_reduce per parameter before the optimiser steps, so all ranks hold identical weights.  (The Mega-NeRF layout
+        # walks the same shuffled epoch and trains on the batches  index % world == rank; gradients are averaged with ONE
+        # all_reduce over a flat buffer before the optimiser steps, so all ranks hold identical weights.  (The Mega-NeRF layout
         # proper -- one submodule per GPU, parscripts/run_8.txt -- is N independent single-rank runs and needs none of this.)
         world = dist.get_world_size() if self.distributed else 1
         rank = dist.get_rank() if self.distributed else 0
@@ -146,6 +149,18 @@ class Runner:
                 opt.load_state_dict(sd)
         schedulers = {k: ExponentialLR(o, gamma=hp.lr_decay_factor ** (1 / hp.train_iterations),
                                        last_epoch=train_iterations - 1) for k, o in optimizers.items()}
+        # One rank per submodule (the Mega-NeRF layout): the iteration is ONE native call (training.CellTrainer -> mnr_train_step)
+        # whenever the configuration has a fused step, on the SAME optimiser / scheduler objects (their moment tensors become views
+        # of the step's buffers, so checkpoints keep the reference's `optimizers` entry); anything else, and ragged last batches,
+        # take the stage-by-stage autograd path inside the same trainer.  MNR_RUNNER_AUTOGRAD=1 keeps the reference-shaped loop below.
+        from mega_nerf.training import CellTrainer, fused_step_supported
+        trainer = None
+        if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD') and \
+                fused_step_supported(self.nerf, self.bg_nerf, hp, hp.batch_size):
+            trainer = CellTrainer(self.nerf, self.bg_nerf, hp, self.sphere_center, self.sphere_radius, optimizers, schedulers,
+                                  seed=int(hp.random_seed), iteration=train_iterations)
+        self.trainer = trainer
+        check_every = max(1, min(hp.ckpt_interval, 100))      # fused path: loss finiteness / sphere errors are checked at this interval
         filesystem = hp.dataset_type == 'filesystem'
         chunk_ready = False
         if filesystem:
@@ -174,10 +189,33 @@ class Runner:
             # data-parallel ranks walk the epoch in groups of `world` consecutive batches (one each) and drop the ragged last group:
             # every rank then takes the same number of steps per epoch and their collectives pair up
             usable = (-(-len(dataset) // hp.batch_size) // world) * world
+            if usable == 0:
+                raise Exception('{} training pixels give fewer batches of {} than there are ranks ({}): nothing to train on'.format(
+                    len(dataset), hp.batch_size, world))
             for dataset_index, item in enumerate(dataset.batches(hp.batch_size, gen)):
                 if dataset_index < discard or dataset_index >= usable or dataset_index % world != rank:
                     continue
                 image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
+                if trainer is not None:
+                    loss_dev, _, _ = trainer.step(item['rays'], image_indices, item['rgbs'])
+                    train_iterations += 1
+                    last = train_iterations >= hp.train_iterations
+                    if train_iterations % check_every == 0 or last or train_iterations % hp.ckpt_interval == 0:
+                        trainer.health()                      # raises what the reference raises per iteration (runner.py:260-261)
+                        loss = float(loss_dev)
+                        if not math.isfinite(loss):
+                            raise Exception('Train metrics not finite: {}'.format({'loss': loss}))
+                        if self.is_master:
+                            main_print('iter {}: psnr {:.3f} loss {:.5f}'.format(train_iterations, -10 * math.log10(max(loss, 1e-30)), loss))
+                    if self.is_master and train_iterations % hp.ckpt_interval == 0:
+                        trainer.sync()
+                        self._save_checkpoint(optimizers, None, train_iterations, dataset_index,
+                                              dataset.get_state() if filesystem else None, epoch)
+                    if train_iterations % hp.val_interval == 0:
+                        self._run_validation(train_iterations)
+                    if last:
+                        break
+                    continue
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)
                 for key, val in metrics.items():
                     val = float(val.detach()) if isinstance(val, torch.Tensor) else float(val)
@@ -213,6 +251,8 @@ class Runner:
                 epoch, discard = epoch + 1, 0           # the epoch ran to its end
                 continue
             break
+        if trainer is not None:
+            trainer.sync()
         if self.is_master:
             self._save_checkpoint(optimizers, None, train_iterations, dataset_index, dataset.get_state() if filesystem else None, epoch)
         if hp.cluster_mask_path is None:
@@ -273,10 +313,10 @@ class Runner:
         sums = defaultdict(float)
         with torch.inference_mode():
             was_training = self.nerf.training
-            self.nerf.eval()          # NB the reference leaves bg_nerf in training mode here;
-            bg_was = self.bg_nerf.training if self.bg_nerf is not None else False
-            if self.bg_nerf is not None:
-                self.bg_nerf.eval()   # we evaluate both deterministically (what scripts/render_images.py:73-75 does)
+            self.nerf.eval()          # NB the reference leaves bg_nerf in training mode here (random, unsorted
+            bg_was = self.bg_nerf.training if self.bg_nerf is not None else False     # bg fine samples + sigma noise at validation);
+            if self.bg_nerf is not None and not os.environ.get('MNR_REFERENCE_BG_EVAL_MODE'):
+                self.bg_nerf.eval()   # default: both deterministic (scripts/render_images.py:73-75); MNR_REFERENCE_BG_EVAL_MODE=1 = the quirk
             count = 0
             for i in main_tqdm(mdist.images_for_rank(len(self.val_items), rank, world)):
                 item = self.val_items[i]

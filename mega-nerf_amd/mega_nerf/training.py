@@ -736,17 +736,26 @@ class FusedTrainStep:
     foreground and the background model, ExponentialLR) for ONE OR SEVERAL independent cells a rank owns, as one call of
     ``mnr_train_step``: 12 kernel launches + one memset (+ 2 per further cell), no torch kernels, no host synchronisation.  Every cell keeps its own models,
     optimiser moments and batch (parscripts/run_8.txt: one trainer per cell).  After a call ``param.grad`` of every model
-    parameter is that step's gradient (a view into the step's workspace)."""
+    parameter is that step's gradient (a view into the step's workspace).
+
+    Optimiser state (all device resident, per cell): ``adam_m`` / ``adam_v`` = torch.optim.Adam's exp_avg / exp_avg_sq of every
+    parameter in ``named_parameters()`` order (fg, then bg; each tensor padded to 16 bytes), ``adam_t[cell, 0 | 1]`` = the number
+    of updates the cell's fg | bg optimiser has applied (torch's per-parameter ``step``).  A background model is updated only by
+    batches that had rays with a background segment -- the rule of runner.py:268-272 -- decided on the device.
+    ``state_dict()`` / ``load_state_dict()`` speak the reference's checkpoint layout (runner.py:519-538 ``optimizers``)."""
 
     def __init__(self, cells, hparams: Namespace, sphere_center, sphere_radius, n_rays: int, lr: float = 5e-4,
-                 lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None, split_precision: bool = False):
+                 lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None, split_precision: bool = False,
+                 state=None):
         lib = N.lib()
         self.cells = [(f, b) for f, b in cells]
         assert 1 <= len(self.cells) <= N.MNR_STEP_MAX_CELLS
         f0, b0 = self.cells[0]
         dev = next(f0.parameters()).device
         self.dev, self.hparams, self.n_rays = dev, hparams, n_rays
+        # ExponentialLR in its chained form (torch/optim/lr_scheduler.py: lr <- lr * gamma after every step), in Python doubles
         self.lr0, self.gamma = lr, lr_decay_factor ** (1 / train_iterations)
+        self.lr = float(lr)
         self.step_count = 0
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xffffffffffffffff
         c, r = R._host_vec(sphere_center), R._host_vec(sphere_radius)
@@ -773,11 +782,16 @@ class FusedTrainStep:
         self.workspace = torch.empty(lay.workspace_bytes, dtype=torch.uint8, device=dev)
         self.layout = lay
         wsf = self.workspace.view(torch.float32)
-        self.adam_m = torch.zeros(len(self.cells), per_cell, device=dev)
-        self.adam_v = torch.zeros(len(self.cells), per_cell, device=dev)
+        if state is None:
+            self.adam_m = torch.zeros(len(self.cells), per_cell, device=dev)
+            self.adam_v = torch.zeros(len(self.cells), per_cell, device=dev)
+            self.adam_t = torch.zeros(len(self.cells), 2, device=dev, dtype=torch.int32)
+        else:       # a second plan (another batch size) of the same cells shares the first one's optimiser state
+            self.adam_m, self.adam_v, self.adam_t = state
+            assert self.adam_m.shape == (len(self.cells), per_cell) and self.adam_t.shape == (len(self.cells), 2)
         self._packed = []
         models = (N.StepModel * (2 * len(self.cells)))()
-        self.grad_views = []
+        self.grad_views, self.m_views, self.v_views = [], [], []
         for ci, (f, b) in enumerate(self.cells):
             g0 = (lay.grad_offset + ci * lay.grad_stride) // 4
             o = 0
@@ -794,6 +808,7 @@ class FusedTrainStep:
                     views[2][name] = self.adam_v[ci, o:o + p.numel()].view(p.shape)
                     o += n
                 sm.grad, sm.adam_m, sm.adam_v = m.grad_struct(views[0]), m.grad_struct(views[1]), m.grad_struct(views[2])
+                sm.adam_steps_dev = self.adam_t[ci, k:k + 1].data_ptr()
                 if split_precision:
                     pk = torch.empty(lib.mnr_packed_model_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
                     pb = torch.empty(lib.mnr_packed_bwd_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
@@ -804,6 +819,8 @@ class FusedTrainStep:
                     sm.packed_dev, sm.packed_bwd_dev = pk.data_ptr(), pb.data_ptr()
                 self._packed.append((pk, pb))
                 self.grad_views.append(views[0])
+                self.m_views.append(views[1])
+                self.v_views.append(views[2])
         self._models = models
         plan = C.c_void_p()
         N.check(lib.mnr_step_create(C.byref(plan), C.byref(cfg), models, self.workspace.data_ptr(), self.workspace.numel(), N.stream_ptr()))
@@ -816,6 +833,8 @@ class FusedTrainStep:
         wsi = self.workspace.view(torch.int32)
         self.n_bg = wsi[lay.n_bg_offset // 4:lay.n_bg_offset // 4 + nc]
         self.err = wsi[lay.err_offset // 4:lay.err_offset // 4 + nc]
+        # MNR_STEP_STICKY_* bits OR-ed over every optimising step since the plan was made (or since health() last cleared them)
+        self.sticky = wsi[lay.sticky_offset // 4:lay.sticky_offset // 4 + nc]
 
     def __del__(self):
         plan = getattr(self, '_plan', None)
@@ -840,9 +859,72 @@ class FusedTrainStep:
         """After the parameters were changed from outside (checkpoint load): refresh the step's weight images."""
         N.check(N.lib().mnr_step_repack(self._plan, N.stream_ptr()))
 
-    def __call__(self, batches, _randoms=None, optimize: bool = True):
+    def health(self, clear: bool = True) -> None:
+        """The checks the reference makes on every iteration (runner.py:260-261 'Train metrics not finite', rendering.py:412-414
+        cameras outside the sphere), made for all optimising steps since the last call: ONE host synchronisation per call."""
+        bits = self.sticky.cpu()
+        if clear:
+            self.sticky.zero_()
+        if int((bits & N.MNR_STEP_STICKY_OUTSIDE).max()) != 0:
+            raise Exception(R._ERR_TEXT)
+        if int((bits & N.MNR_STEP_STICKY_NONFINITE).max()) != 0:
+            raise Exception('Train metrics not finite: {}'.format({'loss': self.loss.tolist()}))
+
+    # ---- optimiser state in torch.optim.Adam's terms ---------------------------------------------------------------------------
+    def _torch_adam(self, ci: int, k: int, clone: bool) -> torch.optim.Adam:
+        """A torch.optim.Adam over the parameters of model k (0 = fg, 1 = bg) of cell ci whose state IS this plan's state
+        (views of the moment buffers, or copies when ``clone``)."""
+        m = self.cells[ci][k]
+        opt = torch.optim.Adam(m.parameters(), lr=self.lr0)
+        group = opt.param_groups[0]
+        group['initial_lr'], group['lr'] = self.lr0, self.lr
+        t = float(self.adam_t[ci, k].item())
+        mv, vv = self.m_views[2 * ci + k], self.v_views[2 * ci + k]
+        for name, p in m.named_parameters():
+            a, b = mv[name], vv[name]
+            opt.state[p] = {'step': torch.tensor(t, dtype=torch.float32), 'exp_avg': a.clone() if clone else a,
+                            'exp_avg_sq': b.clone() if clone else b}
+        return opt
+
+    def state_dict(self, cell: int = 0) -> Dict[str, dict]:
+        """{'nerf': ..., 'bg_nerf': ...}: what ``{k: v.state_dict() for k, v in optimizers.items()}`` of the reference's trainer
+        holds for this cell (runner.py:523) -- loadable by ``torch.optim.Adam.load_state_dict`` there and here."""
+        return {key: self._torch_adam(cell, k, True).state_dict() for k, key in enumerate(('nerf', 'bg_nerf'))}
+
+    def load_state_dict(self, sd: Dict[str, dict], cell: int = 0) -> None:
+        """Inverse of :meth:`state_dict` (also accepts the ``optimizers`` entry of a checkpoint written by the reference)."""
+        for k, key in enumerate(('nerf', 'bg_nerf')):
+            opt = self._torch_adam(cell, k, True)
+            merged = opt.state_dict()
+            merged.update(sd[key])                            # the reference's update-then-load (runner.py:181-184)
+            opt.load_state_dict(merged)
+            self.adopt(opt, cell, k)
+
+    def adopt(self, opt: torch.optim.Optimizer, cell: int, k: int) -> None:
+        """Copy a torch.optim.Adam's state (moments, step count, current lr) into the plan's buffers."""
+        m = self.cells[cell][k]
+        mv, vv = self.m_views[2 * cell + k], self.v_views[2 * cell + k]
+        steps = set()
+        for name, p in m.named_parameters():
+            st = opt.state.get(p)
+            if not st:                                        # never stepped
+                mv[name].zero_(), vv[name].zero_()
+                steps.add(0)
+                continue
+            if st['exp_avg'].data_ptr() != mv[name].data_ptr():
+                mv[name].copy_(st['exp_avg'])
+                vv[name].copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) != 1:
+            raise N.NativeError('torch.optim.Adam state with different step counts per parameter: {}'.format(sorted(steps)))
+        self.adam_t[cell, k] = steps.pop()
+        if k == 0:
+            self.lr = float(opt.param_groups[0]['lr'])
+
+    def __call__(self, batches, _randoms=None, optimize: bool = True, lr: Optional[float] = None):
         """batches: one (rays [n_rays, 8], image_indices [n_rays], rgbs [n_rays, 3]) per cell.  Returns (loss [cells], n_bg
-        [cells], err [cells]) as device tensors (views of the workspace: valid until the next call)."""
+        [cells], err [cells]) as device tensors (views of the workspace: valid until the next call).  ``lr``: this step's learning
+        rate when the caller runs the schedule (Runner: torch's ExponentialLR object); default: the plan's own chained decay."""
         nc = len(self.cells)
         assert len(batches) == nc
         arr = (N.StepBatch * nc)()
@@ -868,9 +950,11 @@ class FusedTrainStep:
                         keep.append(t)
                         setattr(inj[i], k, t.data_ptr())
         self.step_count += 1
-        lr = self.lr0 * self.gamma ** (self.step_count - 1)
-        N.check(N.lib().mnr_train_step(self._plan, arr, inj, lr, self.step_count, self.seed, 0 if optimize else N.MNR_STEP_NO_OPTIMIZER,
+        step_lr = self.lr if lr is None else float(lr)
+        N.check(N.lib().mnr_train_step(self._plan, arr, inj, step_lr, self.step_count, self.seed, 0 if optimize else N.MNR_STEP_NO_OPTIMIZER,
                                        N.stream_ptr()))
+        if optimize and lr is None:
+            self.lr *= self.gamma                # ExponentialLR.step()
         self._keep = keep                    # inputs stay alive until the enqueued step has read them (next call at the latest)
         for ci, (f, b) in enumerate(self.cells):
             for k, m in enumerate((f, b)):
@@ -882,47 +966,138 @@ class FusedTrainStep:
         return self.loss, self.n_bg, self.err
 
 
-class TrainStep:
-    """One optimisation step of the reference trainer (runner.py:244-277, fp32): render -> MSE -> backward ->
-    Adam on fg and bg -> LR decay.  No host synchronisation inside the step."""
+class CellTrainer:
+    """Optimiser side of the reference trainer for one cell (runner.py:169-194 Adam + ExponentialLR per model, :244-277 the
+    iteration) with ONE source of truth for its state: the torch.optim.Adam objects in ``optimizers`` (the reference's dict:
+    'nerf', 'bg_nerf') -- whose exp_avg / exp_avg_sq tensors are VIEWS of the fused plan's moment buffers once a plan exists.
+
+    ``step(rays, image_indices, rgbs)`` runs ``mnr_train_step`` (csrc/step.hip: the whole iteration as one call, no host
+    synchronisation) when the configuration and the batch size allow it, and otherwise the stage-by-stage autograd path with
+    the same optimisers (a ragged last batch of an epoch, an architecture outside the fused step): both paths read and write
+    the same moments, step counts and learning rate, and the fused plan's weight images are refreshed after a torch step.
+    ``optimizers[k].state_dict()`` after :meth:`sync` is the checkpoint entry of runner.py:523."""
 
     def __init__(self, nerf: nn.Module, bg_nerf: Optional[nn.Module], hparams: Namespace, sphere_center, sphere_radius,
-                 lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000):
+                 optimizers: Optional[Dict[str, torch.optim.Optimizer]] = None, schedulers: Optional[dict] = None,
+                 lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None,
+                 split_precision: bool = False, iteration: int = 0):
         self.nerf, self.bg_nerf, self.hparams = nerf, bg_nerf, hparams
         self.sc, self.sr = sphere_center, sphere_radius
-        self._fused, self._lr, self._decay, self._iters = None, lr, lr_decay_factor, train_iterations
-        # same update rule as runner.py:169-171 (Adam, default betas / eps); ``fused`` = torch's single-launch multi-tensor
-        # implementation (the default "foreach" form is ~6 launches of ~20 us per optimiser on this GPU)
-        import os
-        fused = not os.environ.get('MNR_ADAM_FOREACH')
-        self.opts = [torch.optim.Adam(nerf.parameters(), lr=lr, fused=fused)]
-        if bg_nerf is not None:
-            self.opts.append(torch.optim.Adam(bg_nerf.parameters(), lr=lr, fused=fused))
-        gamma = lr_decay_factor ** (1 / train_iterations)
-        self.scheds = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=gamma) for o in self.opts]
+        self._seed, self._split = seed, split_precision
+        if optimizers is None:
+            optimizers = {'nerf': torch.optim.Adam(nerf.parameters(), lr=lr)}
+            if bg_nerf is not None:
+                optimizers['bg_nerf'] = torch.optim.Adam(bg_nerf.parameters(), lr=lr)
+        if schedulers is None:
+            gamma = lr_decay_factor ** (1 / train_iterations)
+            schedulers = {k: torch.optim.lr_scheduler.ExponentialLR(o, gamma=gamma) for k, o in optimizers.items()}
+        self.optimizers, self.schedulers = optimizers, schedulers
+        for o in optimizers.values():
+            o._opt_called = True             # (ExponentialLR warns when its first step() precedes optimizer.step(): the fused step IS that step)
+        self.fused: Optional[FusedTrainStep] = None
+        self.iteration = iteration           # keys the fused step's random streams: continues across a resume
+        self._steps_stale = False            # torch's per-parameter `step` tensors lag behind the device counters
 
-    def __call__(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
-        if self._fused is None and image_indices is not None and fused_step_supported(self.nerf, self.bg_nerf, self.hparams, rays.shape[0]):
-            self._fused = FusedTrainStep([(self.nerf, self.bg_nerf)], self.hparams, self.sc, self.sr, rays.shape[0], self._lr,
-                                         self._decay, self._iters)
-        if self._fused is not None and rays.shape[0] == self._fused.n_rays and image_indices is not None:
-            loss, n_bg, err = self._fused([(rays, image_indices, rgbs)])
+    # ---- state plumbing --------------------------------------------------------------------------------------------------------
+    def _models(self):
+        return [('nerf', self.nerf, 0)] + ([('bg_nerf', self.bg_nerf, 1)] if self.bg_nerf is not None else [])
+
+    def _make_plan(self, n_rays: int) -> None:
+        lr = float(self.optimizers['nerf'].param_groups[0]['lr'])
+        self.fused = FusedTrainStep([(self.nerf, self.bg_nerf)], self.hparams, self.sc, self.sr, n_rays, lr, seed=self._seed,
+                                    split_precision=self._split)
+        self.fused.step_count = self.iteration
+        for key, m, k in self._models():
+            opt = self.optimizers[key]
+            self.fused.adopt(opt, 0, k)
+            mv, vv = self.fused.m_views[k], self.fused.v_views[k]
+            t = float(self.fused.adam_t[0, k].item())
+            for name, p in m.named_parameters():      # from here on torch's state tensors are the plan's buffers
+                opt.state[p] = {'step': torch.tensor(t, dtype=torch.float32), 'exp_avg': mv[name], 'exp_avg_sq': vv[name]}
+
+    def sync(self) -> None:
+        """Bring torch's per-parameter ``step`` counters up to date with the device (one host synchronisation): call before
+        ``optimizers[k].state_dict()`` (checkpoints) -- the moments and the learning rate are shared and always current."""
+        if self.fused is None or not self._steps_stale:
+            return
+        t = self.fused.adam_t[0].tolist()
+        for key, m, k in self._models():
+            for p in m.parameters():
+                self.optimizers[key].state[p]['step'] = torch.tensor(float(t[k]), dtype=torch.float32)
+        self._steps_stale = False
+
+    def _after_torch_step(self) -> None:
+        if self.fused is None:
+            return
+        for key, m, k in self._models():
+            st = self.optimizers[key].state
+            self.fused.adam_t[0, k] = int(float(st[next(iter(m.parameters()))]['step']))
+        self.fused.repack()                   # the plan's weight images must follow the parameters
+
+    def health(self) -> None:
+        if self.fused is not None:
+            self.fused.health()
+
+    # ---- the iteration ---------------------------------------------------------------------------------------------------------
+    def step(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
+        """One optimisation step.  Returns (loss, n_bg, err): device scalars / 1-element device tensors, no host sync on the
+        fused path."""
+        n = rays.shape[0]
+        fusable = image_indices is not None and fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n)
+        if self.fused is None and fusable:
+            self._make_plan(n)
+        self.iteration += 1
+        if fusable and n == self.fused.n_rays:
+            lrs = [float(o.param_groups[0]['lr']) for o in self.optimizers.values()]
+            assert all(v == lrs[0] for v in lrs), 'foreground and background optimisers on different learning rates'
+            self.fused.step_count = self.iteration - 1
+            loss, n_bg, err = self.fused([(rays, image_indices, rgbs)], lr=lrs[0])
+            self._steps_stale = True
+            for s in self.schedulers.values():
+                s.step()
             return loss[0], n_bg[0:1], err[0:1]
-        for o in self.opts:
+        # stage-by-stage path under autograd, same optimisers (their state tensors are the plan's buffers when one exists)
+        self.sync()
+        for o in self.optimizers.values():
             o.zero_grad(set_to_none=True)
         results, n_bg, err = render_rays_train(self.nerf, self.bg_nerf, rays, image_indices, self.hparams, self.sc, self.sr,
                                                False, True, False)
-        loss = torch.nn.functional.mse_loss(results['rgb_fine'], rgbs, reduction='mean')
+        typ = 'fine' if 'rgb_fine' in results else 'coarse'
+        loss = torch.nn.functional.mse_loss(results['rgb_' + typ], rgbs, reduction='mean')
+        if self.hparams.use_cascade and typ != 'coarse':
+            loss = (loss + torch.nn.functional.mse_loss(results['rgb_coarse'], rgbs, reduction='mean')) / 2
         loss.backward()
-        for o in self.opts:          # NB: the reference skips the bg optimiser when no ray had a bg segment
-            o.step()                 # (runner.py:269-272); with zero bg rays every bg gradient is exactly 0 here
-        # torch's fused Adam updates the parameters WITHOUT bumping their version counters, which is what NeRF.packed() keys
-        # its packed-weight cache on: without this the next step would run on the previous weights (rounds 1-2 did: the
-        # benchmark's timed region skipped the four re-pack launches, and TrainStep did not learn)
+        bg_present = n_bg is not None and int(n_bg.item()) > 0          # runner.py:268-272 (this path synchronises, like the reference)
+        for key, o in self.optimizers.items():
+            if key == 'bg_nerf' and not bg_present:
+                continue
+            o.step()
         for m in (self.nerf, self.bg_nerf):
             for sub in (m.modules() if m is not None else ()):
                 if hasattr(sub, 'weights_changed'):
                     sub.weights_changed()
-        for s in self.scheds:
+        self._after_torch_step()
+        for s in self.schedulers.values():
             s.step()
-        return loss, n_bg, err
+        return loss.detach(), n_bg, err
+
+
+class TrainStep(CellTrainer):
+    """One optimisation step of the reference trainer (runner.py:244-277, fp32): render -> MSE -> backward ->
+    Adam on fg and bg -> LR decay, as a callable (bench.py, smoke, tests).  See :class:`CellTrainer`."""
+
+    def __init__(self, nerf: nn.Module, bg_nerf: Optional[nn.Module], hparams: Namespace, sphere_center, sphere_radius,
+                 lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000):
+        super().__init__(nerf, bg_nerf, hparams, sphere_center, sphere_radius, lr=lr, lr_decay_factor=lr_decay_factor,
+                         train_iterations=train_iterations)
+
+    @property
+    def opts(self):
+        return list(self.optimizers.values())
+
+    @property
+    def _fused(self):
+        return self.fused
+
+    def __call__(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
+        return self.step(rays, image_indices, rgbs)

@@ -51,3 +51,89 @@ def test_train_then_eval_entry_points(tmp_path):
     assert abs(a - b) < 0.05, (a, b)            # north star: PSNR within 0.05 dB
     assert a > 5.0
     assert abs(metric(m_train, 'val/ssim') - metric(m_eval, 'val/ssim')) < 1e-3 and 0.0 < metric(m_eval, 'val/ssim') <= 1.0
+
+
+def _dataset(tmp_path):
+    data = tmp_path / 'data'
+    subprocess.run([sys.executable, str(ROOT / 'mega-nerf_amd' / 'tools' / 'make_synthetic_dataset.py'), '--out', str(data),
+                    '--images', '8', '--val_every', '4', '--size', '32', '--samples', '64', '128'], check=True)
+    return data
+
+
+def _hparams(data, exp, extra):
+    from mega_nerf.opts import get_opts_base
+    p = get_opts_base()
+    p.add_argument('--exp_name', type=str, required=True)
+    p.add_argument('--dataset_path', type=str, required=True)
+    return p.parse_args(['--dataset_path', str(data), '--exp_name', str(exp), '--coarse_samples', '64', '--fine_samples', '128', '--near', '0.01',
+                         '--ray_altitude_range', '-0.5', '0.2', '--val_scale_factor', '1', '--batch_size', '384'] + extra)
+
+
+def test_runner_train_runs_the_fused_step_and_resumes(tmp_path, monkeypatch):
+    """train.py's loop (Runner.train, reference runner.py:244-277) on the default architecture must run the ONE-CALL training step
+    (mnr_train_step through training.CellTrainer) -- the thing bench.py times -- and stay a drop-in:
+      * same trained weights as the stage-by-stage autograd loop (MNR_RUNNER_AUTOGRAD=1) from the same seed, on deterministic
+        renders (models pinned to eval mode: the two paths draw their random numbers from different generators);
+      * 7168 training pixels in batches of 384 leave a ragged last batch of 256 rays per epoch: those steps take the autograd path
+        INSIDE the fused trainer, on the same Adam moments / step counts / learning rate;
+      * the checkpoint keeps the reference's keys and its `optimizers` entry loads into a plain torch.optim.Adam;
+      * a run resumed from its own 20-iteration checkpoint ends where the uninterrupted run ends."""
+    import numpy as np
+    from mega_nerf.models.nerf import NeRF
+    from mega_nerf.runner import Runner
+    data = _dataset(tmp_path)
+    monkeypatch.setattr(NeRF, 'train', lambda self, mode=True: torch.nn.Module.train(self, False))
+
+    def run(tag, extra, autograd=False):
+        if autograd:
+            monkeypatch.setenv('MNR_RUNNER_AUTOGRAD', '1')
+        else:
+            monkeypatch.delenv('MNR_RUNNER_AUTOGRAD', raising=False)
+        r = Runner(_hparams(data, tmp_path / tag, ['--train_iterations', '40', '--ckpt_interval', '20'] + extra))
+        w0 = {k: v.detach().clone() for k, v in list(r.nerf.state_dict().items()) + [('bg.' + k, v) for k, v in r.bg_nerf.state_dict().items()]}
+        r.train()
+        w = {k: v.detach().clone() for k, v in list(r.nerf.state_dict().items()) + [('bg.' + k, v) for k, v in r.bg_nerf.state_dict().items()]}
+        return r, w0, w
+
+    ra, w0, wa = run('fused', [])
+    assert ra.trainer is not None and ra.trainer.fused is not None and ra.trainer.fused.n_rays == 384
+    assert ra.trainer.iteration == 40
+    rb, w0b, wb = run('autograd', [], autograd=True)
+    assert rb.trainer is None
+    for k in w0:
+        np.testing.assert_array_equal(w0[k].cpu().numpy(), w0b[k].cpu().numpy())
+    # 40 Adam steps amplify rounding differences between two implementations of the same gradients (|update| ~ lr whatever the
+    # gradient's size): compare the MOVEMENT of every tensor
+    worst = {}
+    for k in wa:
+        moved = float((wb[k] - w0[k]).norm())
+        if moved > 0:
+            worst[k] = float((wa[k] - wb[k]).norm()) / moved
+    print('fused vs autograd loop, |dw| / |movement|:', {k: '%.2e' % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert max(worst.values()) < 0.05, worst
+    ck = torch.load(tmp_path / 'fused' / '0' / 'models' / '40.pt', map_location='cpu', weights_only=False)
+    for key in ('model_state_dict', 'bg_model_state_dict', 'optimizers', 'iteration', 'torch_random_state', 'np_random_state', 'random_state',
+                'dataset_index', 'scaler'):
+        assert key in ck, key
+    ckb = torch.load(tmp_path / 'autograd' / '0' / 'models' / '40.pt', map_location='cpu', weights_only=False)
+    for key in ('nerf', 'bg_nerf'):
+        sa, sb = ck['optimizers'][key], ckb['optimizers'][key]
+        assert sa['param_groups'][0].keys() == sb['param_groups'][0].keys() and sa['state'].keys() == sb['state'].keys()
+        assert abs(sa['param_groups'][0]['lr'] - sb['param_groups'][0]['lr']) < 1e-12
+        for i in sa['state']:
+            assert float(sa['state'][i]['step']) == float(sb['state'][i]['step']) == 40.0
+            assert sa['state'][i]['exp_avg'].shape == sb['state'][i]['exp_avg'].shape
+        # ... and the entry loads into a plain torch.optim.Adam over a fresh model, the way the reference resumes (runner.py:181-184)
+        m = (ra.nerf if key == 'nerf' else ra.bg_nerf)
+        opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+        sd = opt.state_dict()
+        sd.update(sa)
+        opt.load_state_dict(sd)
+        assert float(opt.state[next(iter(m.parameters()))]['step']) == 40.0
+    # resume from the run's own 20-iteration checkpoint: same weights at iteration 40 as the uninterrupted run (kernel sums are
+    # not bit-reproducible run to run: atomics in the head / embedding gradients)
+    rc, _, wc = run('resumed', ['--ckpt_path', str(tmp_path / 'fused' / '0' / 'models' / '20.pt')])
+    assert rc.trainer.fused is not None and rc.trainer.iteration == 40
+    worst = {k: float((wa[k] - wc[k]).norm()) / max(float((wa[k] - w0[k]).norm()), 1e-30) for k in wa if float((wa[k] - w0[k]).norm()) > 0}
+    print('resumed vs uninterrupted:', {k: '%.2e' % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert max(worst.values()) < 0.02, worst

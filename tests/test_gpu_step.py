@@ -427,3 +427,135 @@ def test_fused_render_on_two_streams_changes_nothing(monkeypatch):
     for k in outs[0]:
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
         np.testing.assert_array_equal(outs[0][k], outs[2][k], err_msg=k)
+
+
+def test_background_optimiser_is_gated_on_the_device_and_state_dict_round_trips():
+    """runner.py:268-272: the background optimiser steps only on batches that had background rays.  The fused step decides that on the
+    device (AdamTensor::gate = the cell's background-ray count) and keeps torch.optim.Adam's per-optimiser step count there too
+    (mnr_step_model::adam_steps_dev).  Protocol: batch A (far bound inside the ellipsoid: no background ray), batch B (the golden batch),
+    A again -- against the reference-style loop with the same rule, eval-mode models; then the optimiser state exported in the
+    reference's checkpoint layout, loaded into a second plan and into plain torch optimisers, continues identically."""
+    from mega_nerf.rendering import render_rays
+    from mega_nerf.training import FusedTrainStep
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays_b, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    rays_a = rays_b.clone()
+    rays_a[:, 7] = 0.3                    # far = 0.3 from a camera well inside the ellipsoid: every ray ends before the sphere
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    hp, nerf, bg_nerf = native_models('render_fgbg_train')
+    hpn = Namespace(**vars(hp))
+    nerf.eval(), bg_nerf.eval()
+    bg0 = {k: v.detach().clone() for k, v in bg_nerf.state_dict().items()}
+    step = FusedTrainStep([(nerf, bg_nerf)], hpn, sc, sr, rays_b.shape[0])
+    seq = [rays_a, rays_b, rays_a, rays_b]
+    fused, nbg = [], []
+    for i, r in enumerate(seq):
+        l, nb, err = step([(r, idx, tgt)])
+        fused.append(float(l[0]))
+        nbg.append(int(nb[0]))
+        assert int(err[0]) == 0
+        if i == 0:       # no background ray: the background model has not moved, its optimiser has not stepped
+            assert nbg[0] == 0
+            for k, v in bg_nerf.state_dict().items():
+                np.testing.assert_array_equal(v.cpu().numpy(), bg0[k].cpu().numpy())
+            assert step.adam_t.tolist() == [[1, 0]]
+            assert float(step.adam_m[0, sum((p.numel() + 3) // 4 * 4 for p in nerf.parameters()):].abs().max()) == 0.0
+    assert nbg[1] > 0 and step.adam_t.tolist() == [[4, 2]]
+    assert int(step.sticky.max()) == 0
+    # reference-style loop
+    hp, n2, b2 = native_models('render_fgbg_train')
+    n2.eval(), b2.eval()
+    opts = {'nerf': torch.optim.Adam(n2.parameters(), lr=5e-4), 'bg_nerf': torch.optim.Adam(b2.parameters(), lr=5e-4)}
+    scheds = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=0.1 ** (1 / 500000)) for o in opts.values()]
+    plain = []
+    for r in seq:
+        for o in opts.values():
+            o.zero_grad(set_to_none=True)
+        res, present = render_rays(n2, b2, r, idx, hpn, sc, sr, False, True, False)
+        loss = torch.nn.functional.mse_loss(res['rgb_fine'], tgt)
+        loss.backward()
+        for key, o in opts.items():
+            if key == 'bg_nerf' and not present:
+                continue
+            o.step()
+        for sch in scheds:
+            sch.step()
+        plain.append(float(loss.detach()))
+    np.testing.assert_allclose(fused, plain, rtol=5e-5)
+    for (k, a), (_, b) in zip(bg_nerf.state_dict().items(), b2.state_dict().items()):
+        assert float((a - b).abs().max()) <= 2 * 5e-4 * 2 + 1e-6, k        # two Adam steps: |dw| <= 2 lr each side
+        assert float((a - b).abs().mean()) <= 2e-5, k
+    # ---- checkpoint layout ----
+    sd = step.state_dict()
+    ref_sd = {k: o.state_dict() for k, o in opts.items()}
+    for key in ('nerf', 'bg_nerf'):
+        assert sd[key]['param_groups'][0].keys() == ref_sd[key]['param_groups'][0].keys()
+        assert sd[key]['state'].keys() == ref_sd[key]['state'].keys()
+        assert abs(sd[key]['param_groups'][0]['lr'] - ref_sd[key]['param_groups'][0]['lr']) < 1e-15
+        for i in sd[key]['state']:
+            assert float(sd[key]['state'][i]['step']) == float(ref_sd[key]['state'][i]['step']) == (4.0 if key == 'nerf' else 2.0)
+            a, b = sd[key]['state'][i]['exp_avg_sq'], ref_sd[key]['state'][i]['exp_avg_sq']
+            # (second moments of noise-level gradients: two summation orders of g, squared)
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-20
+    # a second plan over copies of the models, fed the exported state, takes the same next step
+    hp, n3, b3 = native_models('render_fgbg_train')
+    n3.load_state_dict(nerf.state_dict()), b3.load_state_dict(bg_nerf.state_dict())
+    n3.eval(), b3.eval()
+    step3 = FusedTrainStep([(n3, b3)], hpn, sc, sr, rays_b.shape[0])
+    step3.load_state_dict(sd)
+    assert step3.adam_t.tolist() == [[4, 2]] and abs(step3.lr - step.lr) < 1e-18
+    step3.repack()
+    l1 = float(step([(rays_b, idx, tgt)])[0][0])
+    l3 = float(step3([(rays_b, idx, tgt)])[0][0])
+    np.testing.assert_allclose(l3, l1, rtol=2e-6)
+    for (k, a), (_, b) in zip(nerf.state_dict().items(), n3.state_dict().items()):
+        assert float((a - b).abs().max()) <= 2 * 5e-4 + 1e-6 and float((a - b).abs().mean()) <= 1e-6, k
+
+
+def test_cell_trainer_mixes_fused_and_autograd_steps_on_one_state():
+    """training.CellTrainer: batches of the planned size run mnr_train_step, any other batch the stage-by-stage autograd path -- on
+    the same torch.optim.Adam objects, whose moment tensors are views of the plan's buffers (one source of truth).
+    Against the reference-style loop over the same batch sequence (eval-mode models), incl. the ragged 592 -> 200-ray batch."""
+    from mega_nerf.rendering import render_rays
+    from mega_nerf.training import CellTrainer
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    n = rays.shape[0]
+    small = slice(0, 200)
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    hp, nerf, bg_nerf = native_models('render_fgbg_train')
+    hpn = Namespace(**vars(hp))
+    nerf.eval(), bg_nerf.eval()
+    tr = CellTrainer(nerf, bg_nerf, hpn, sc, sr)
+    seq = ['full', 'full', 'small', 'full', 'small', 'full']
+    got = []
+    for what in seq:
+        b = (rays, idx, tgt) if what == 'full' else (rays[small], idx[small], tgt[small])
+        got.append(float(tr.step(*b)[0]))
+    assert tr.fused is not None and tr.fused.n_rays == n
+    tr.sync()
+    for key, o in tr.optimizers.items():
+        for st in o.state.values():
+            assert float(st['step']) == 6.0
+    assert tr.fused.adam_t.tolist() == [[6, 6]]
+    hp, n2, b2 = native_models('render_fgbg_train')
+    n2.eval(), b2.eval()
+    opts = [torch.optim.Adam(m.parameters(), lr=5e-4) for m in (n2, b2)]
+    scheds = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=0.1 ** (1 / 500000)) for o in opts]
+    plain = []
+    for what in seq:
+        b = (rays, idx, tgt) if what == 'full' else (rays[small], idx[small], tgt[small])
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        res, _ = render_rays(n2, b2, b[0], b[1], hpn, sc, sr, False, True, False)
+        loss = torch.nn.functional.mse_loss(res['rgb_fine'], b[2])
+        loss.backward()
+        for o in opts:
+            o.step()
+        for sch in scheds:
+            sch.step()
+        plain.append(float(loss.detach()))
+    np.testing.assert_allclose(got, plain, rtol=1e-4)
+    assert abs(tr.optimizers['nerf'].param_groups[0]['lr'] - opts[0].param_groups[0]['lr']) < 1e-15
