@@ -392,47 +392,67 @@ def config_sweep(args, dev):
 
 def runner_loop(args, dev, value):
     """Rays/s of the DROP-IN trainer: mega_nerf.runner.Runner.train() (the loop train.py runs, reference runner.py:244-277) over a
-    device-resident synthetic dataset at the headline shape, timed from iteration 20 to the last one (a hook the Runner calls after
-    every iteration synchronises at the two ends): dataset.batches() gathers + the one-call step + scheduler + periodic health check."""
+    device-resident dataset of the benchmark's own camera (three 400 x 400 images of the SURVEY 8(d) pose, the benchmark's ellipsoid:
+    the same ~13 % of rays with a background segment as the headline batch), timed from iteration 20 to the last one (a hook the Runner
+    calls after every iteration synchronises at the two ends): dataset.batches() gathers + the one-call step + ExponentialLR + the
+    periodic health check.  Image contents are noise: throughput does not depend on them."""
+    import contextlib
+    import io
     import shutil
-    import subprocess
     import tempfile
-    from mega_nerf.runner import Runner
+    import numpy as np
+    import synthetic_scene as S
+    from PIL import Image
     from mega_nerf.opts import get_opts_base
+    from mega_nerf.runner import Runner
     tmp = Path(tempfile.mkdtemp(prefix='mnr_bench_'))
     try:
-        data = tmp / 'data'
-        subprocess.run([sys.executable, str(ROOT / 'mega-nerf_amd' / 'tools' / 'make_synthetic_dataset.py'), '--out', str(data), '--images', '8',
-                        '--val_every', '8', '--size', '96', '--samples', '64', '128'], check=True, stdout=subprocess.DEVNULL)
+        data, sc = tmp / 'data', S.SCENE
+        rng = np.random.default_rng(7)
+        torch.save({'origin_drb': torch.zeros(3), 'pose_scale_factor': 1.0}, _mkdir(data) / 'coordinates.pt')
+        for i, split in enumerate(('train', 'train', 'val')):
+            c2w = torch.from_numpy(sc['c2w'].copy())
+            c2w[:, 3] += torch.tensor([0.0, 0.01 * i, -0.01 * i])              # (distinct camera centres: the Runner derives its bounds from them)
+            Image.fromarray(rng.integers(0, 256, (sc['H'], sc['W'], 3), dtype=np.uint8)).save(_mkdir(data / split / 'rgbs') / ('%06d.png' % i))
+            torch.save({'W': sc['W'], 'H': sc['H'], 'intrinsics': torch.tensor([sc['fx'], sc['fy'], sc['cx'], sc['cy']]), 'c2w': c2w},
+                       _mkdir(data / split / 'metadata') / ('%06d.pt' % i))
         p = get_opts_base()
         p.add_argument('--exp_name', type=str, required=True)
         p.add_argument('--dataset_path', type=str, required=True)
         iters, first = 20 + args.steps, 20
         hp = p.parse_args(['--dataset_path', str(data), '--exp_name', str(tmp / 'exp'), '--coarse_samples', '64', '--fine_samples', '128',
-                           '--near', '0.01', '--ray_altitude_range', '-0.5', '0.2', '--val_scale_factor', '4', '--batch_size', str(args.rays),
-                           '--train_iterations', str(iters)])
-        r = Runner(hp)
-        marks = {}
-
-        def hook(it):
-            if it in (first, iters):
-                torch.cuda.synchronize()
-                marks[it] = time.perf_counter()
-        r.iteration_hook = hook
-        import contextlib
-        import io
+                           '--near', str(sc['near']), '--ray_altitude_range'] + [str(v) for v in sc['ray_altitude_range']] +
+                          ['--val_scale_factor', '8', '--batch_size', str(args.rays), '--train_iterations', str(iters)])
         with contextlib.redirect_stdout(io.StringIO()):
+            r = Runner(hp)
+            r.sphere_center = torch.from_numpy(sc['sphere_center']).to(dev)       # the benchmark's ellipsoid instead of the one three
+            r.sphere_radius = torch.from_numpy(sc['sphere_radius']).to(dev)       # near-identical cameras would span
+            marks = {}
+
+            def hook(it):
+                if it in (first, iters):
+                    torch.cuda.synchronize()
+                    marks[it] = time.perf_counter()
+                    if it == iters:
+                        marks['n_bg'] = int(r.trainer.fused.n_bg[0]) if r.trainer is not None and r.trainer.fused is not None else -1
+            r.iteration_hook = hook
             r.train()
         dt = (marks[iters] - marks[first]) / (iters - first)
         fused = r.trainer is not None and r.trainer.fused is not None
         return {'rays_per_sec': round(args.rays / dt, 1), 'ms_per_iteration': round(dt * 1e3, 4), 'iterations_timed': iters - first,
-                'fraction_of_value': round(args.rays / dt / value, 4), 'one_call_step': bool(fused),
-                'what': 'Runner.train() on a %d-pixel device-resident MemoryDataset, batch %d: batch gathers + mnr_train_step + ExponentialLR + '
-                        'health check every 100 iterations' % (8 * 96 * 96 - 96 * 48, args.rays)}
+                'fraction_of_value': round(args.rays / dt / value, 4), 'one_call_step': bool(fused), 'bg_rays_in_last_batch': marks.get('n_bg'),
+                'what': 'mega_nerf.runner.Runner.train() on a device-resident MemoryDataset of the benchmark camera (%d pixels), batch %d: '
+                        'shuffled batch gathers + mnr_train_step + ExponentialLR + health check every 100 iterations' % (
+                            int(2.5 * sc['H'] * sc['W']), args.rays)}
     except Exception as e:
         return {'error': '%s: %s' % (type(e).__name__, e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _mkdir(p: Path) -> Path:
+    p.mkdir(parents=True, exist_ok=True)
+    return p
 
 
 def run_config(args, rank, world, dev, dist):
@@ -738,7 +758,10 @@ def run_config(args, rank, world, dev, dist):
             p = pmc.get(pmc_key, {})
             return {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': p.get('hbm_bytes_per_launch'),
-                    'mfma_busy': p.get('mfma_busy'), 'kernel': kernel, 'avg_launch_ms': round(avg * 1e3, 4),
+                    'mfma_busy': p.get('mfma_busy'),
+                    # traffic / mfma_busy are PMC figures from the committed summary (separate --pmc passes), NOT from this run:
+                    'pmc_source': {'file': str(PMC_FILE.relative_to(ROOT)), 'git_head_when_summarised': pmc.get('_meta', {}).get('git_head_when_summarised')},
+                    'kernel': kernel, 'avg_launch_ms': round(avg * 1e3, 4),
                     'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
         mlp = lambda nf_, nb_: nf_ * FG_FLOP_PER_SAMPLE + nb_ * BG_FLOP_PER_SAMPLE                      # noqa: E731
@@ -747,7 +770,9 @@ def run_config(args, rank, world, dev, dist):
         if args.container:
             # whole-step figure from the device-side routed row counts (a row inside the boundary margin is evaluated by two cells)
             r_fg, r_bg = routed_timed
-            fl = (r_fg * FG_FLOP_PER_SAMPLE + r_bg * BG_FLOP_PER_SAMPLE) / args.steps
+            mac_np = lambda w_: sum(v.size for k_, v in w_.items() if k_.endswith('weight') and not k_.startswith('embedding_a'))   # noqa: E731
+            cn = work[0]['cells_np']                  # (FLOPs per sample from the cells' own shapes: 1 211 392 / 1 236 992 at W = 256)
+            fl = (r_fg * 2.0 * mac_np(cn['fg'][0]) + r_bg * 2.0 * mac_np(cn['bg'][0])) / args.steps
             ach = fl / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,

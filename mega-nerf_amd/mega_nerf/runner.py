@@ -70,6 +70,7 @@ class Runner:
             self.experiment_path = self._get_experiment_path() if self.is_master else None
             self.model_path = self.experiment_path / 'models' if self.is_master else None
         self.writer = None
+        self.iteration_hook = None        # optional callable(train_iterations), called after every training iteration (bench.py times the loop with it)
         if not torch.cuda.is_available():
             raise RuntimeError('mega_nerf (MI355X build) needs a HIP device: there is no CPU fallback')
         self.device = torch.device('cuda', torch.cuda.current_device())
@@ -213,6 +214,8 @@ class Runner:
                                               dataset.get_state() if filesystem else None, epoch)
                     if train_iterations % hp.val_interval == 0:
                         self._run_validation(train_iterations)
+                    if self.iteration_hook is not None:
+                        self.iteration_hook(train_iterations)
                     if last:
                         break
                     continue
@@ -245,6 +248,8 @@ class Runner:
                                           dataset.get_state() if filesystem else None, epoch)
                 if train_iterations % hp.val_interval == 0:
                     self._run_validation(train_iterations)
+                if self.iteration_hook is not None:
+                    self.iteration_hook(train_iterations)
                 if train_iterations >= hp.train_iterations:
                     break
             else:

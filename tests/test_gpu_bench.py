@@ -1,0 +1,54 @@
+"""bench.py as the driver runs it: the multi-rank launch (two ranks sharing the one GPU of the test box over gloo -- RCCL refuses two
+ranks on one device; MNR_BENCH_SHARE_GPU) and the default single-GPU line with every BASELINE config in it."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, text[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_step_the_fixed_eight_cell_set():
+    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --submodules 8`: the 8 Rubble cells dealt 4 + 4 to two ranks, every rank
+    steps its cells with one mnr_train_step call per iteration, ONE JSON line from rank 0, strong scaling, max-over-ranks timing."""
+    env = dict(os.environ, MNR_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29533',
+           str(ROOT / 'bench.py'), '--gpus', '2', '--submodules', '8', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras']
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['steps'] == 3
+    assert line['config']['submodules'] == 8
+    # value = rays of ALL 8 cells per step of the set / the slower rank's time
+    assert abs(line['value'] - 8 * 1024 / (line['ms_per_step'] * 1e-3)) < 1e-6 * line['value']
+    assert line['host']['launches_per_step'] == 11 + 2 * 4            # each rank: its four cells in one fused call
+
+
+def test_default_line_carries_every_baseline_config():
+    """The driver's command (short timed region): headline = configs[1] train rays/s; `baseline_configs` = the 8-cell set, the 8- and
+    25-cell containers, W = 512 and the SH shape, each with its own ms_per_step / rays/s / roofline fraction (none above 1: the round-3
+    tally bug); `runner_loop` = Runner.train() itself at >= 0.9 of `value` through the one-call step."""
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3', '--no-cpu-baseline'], cwd=str(ROOT),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line['metric'].startswith('train rays/sec') and line['dtype'] == 'f32' and 0.3 < line['roofline']['frac'] < 1.0
+    cfgs = {k: v for k, v in line['baseline_configs'].items() if not k.startswith('_')}
+    assert len(cfgs) == 7
+    for name, c in cfgs.items():
+        assert 'error' not in c, (name, c)
+        assert c['ms_per_step'] > 0 and c['rays_per_sec'] > 0 and c['frac'] is not None and 0.05 < c['frac'] < 1.0, (name, c)
+    rl = line['runner_loop']
+    assert 'error' not in rl, rl
+    assert rl['one_call_step'] is True and rl['fraction_of_value'] > 0.9, rl
+    print(json.dumps({'value': line['value'], 'runner_loop': rl, 'baseline_configs': {k: (v['ms_per_step'], v['frac']) for k, v in cfgs.items()}}))
