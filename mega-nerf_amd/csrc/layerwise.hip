@@ -433,9 +433,12 @@ extern "C" int mnr_linear(float *Y, int64_t ldy, const float *X1, int64_t ldx1, 
     MNR_REQUIRE(grid.y <= 65535, "too many rows for one mnr_linear launch (chunk the batch)");
     const bool vec = lw_aligned(X1, ldx1, K1) && lw_aligned(W, ldw, K1) && (K2 == 0 || (lw_aligned(X2, ldx2, K2) && lw_aligned(W + K1, ldw, K2)));
     auto go = [&](auto kern) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
-        (void)attr;
+        static bool attr_dev[MAX_DEVICES] = {};                      // (one static per kernel instantiation; attributes are per device)
+        bool &attr = attr_dev[device_slot()];
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
+            attr = true;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(256), LW_LDS_BYTES, as_stream(stream), Y, (long)ldy, X1, (long)ldx1, K1, X2, (long)ldx2, K2,
                            W, (long)ldw, bias, row_add, (long)B, N, act);
     };
@@ -467,9 +470,12 @@ extern "C" int mnr_gemm(float *C, int64_t ldc, const float *A, int64_t sam, int6
     const bool vec = (ak ? lw_aligned(A, sam, K) : lw_aligned(A, sak, M)) && (bk ? lw_aligned(B, sbn, K) : lw_aligned(B, sbk, N));
     const dim3 grid((unsigned)tiles_n, (unsigned)tiles_m, (unsigned)splits);
     auto go = [&](auto kern) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
-        (void)attr;
+        static bool attr_dev[MAX_DEVICES] = {};                      // (one static per kernel instantiation; attributes are per device)
+        bool &attr = attr_dev[device_slot()];
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LW_LDS_BYTES);
+            attr = true;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(256), LW_LDS_BYTES, as_stream(stream), C, (long)ldc, A, (long)sam, (long)sak, B, (long)sbn,
                            (long)sbk, (long)M, N, (long)K, kps, mode);
     };

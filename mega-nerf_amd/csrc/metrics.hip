@@ -92,7 +92,8 @@ extern "C" int mnr_image_metrics(const float *pred, const float *target, int H, 
     const int hw = filter_size / 2, RH = MT_H + 2 * hw, RW = MT_W + 2 * hw;
     const size_t lds = (size_t)(2 * RH * RW + 5 * RH * MT_W) * sizeof(float);
     const float c1 = (k1 * max_val) * (k1 * max_val), c2 = (k2 * max_val) * (k2 * max_val);
-    static size_t lds_enabled = 0;
+    static size_t lds_enabled_dev[MAX_DEVICES] = {};            // function attributes are per device
+    size_t &lds_enabled = lds_enabled_dev[device_slot()];
     if (lds > 64 * 1024 && lds > lds_enabled) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_image_metrics), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_image_metrics)");

@@ -832,7 +832,8 @@ extern "C" int mnr_mlp_backward_weights(const mnr_model_desc *d, const mnr_mlp_g
     MNR_REQUIRE(io->work_counter, "work_counter (device int32) required");
     wa.work_counter = io->work_counter;
     if (io->n_rows > 0) {
-        static size_t lds_enabled = 0;       // raise the dynamic-LDS cap once (monotonic; benign if raced)
+        static size_t lds_enabled_dev[MAX_DEVICES] = {};       // raise the dynamic-LDS cap once per device (monotonic; benign if raced)
+        size_t &lds_enabled = lds_enabled_dev[device_slot()];
         if (lds > 64 * 1024 && lds > lds_enabled) {
             for (const void *fn : {reinterpret_cast<const void *>(k_wgrad<true>), reinterpret_cast<const void *>(k_wgrad<false>)}) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

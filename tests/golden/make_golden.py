@@ -360,6 +360,107 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
     save(name, **out)
 
 
+def run_overfit(name, all_rays, N=1024, steps=30, seed=31, deltas=None):
+    """The regime in which the reference's OWN importance sampling is decided by rounding, pinned by the
+    reference itself.  Protocol = bench.py's: the reference trains fg + bg on ONE batch (training mode: jitter, sigma noise, random u;
+    random target colours; mse_loss; Adam 5e-4 on both models, runner.py:169-171,244-277) for ``steps`` iterations, then renders that
+    batch with the evaluation flags -- once in its native fp32 and once in fp64 (same weights cast up).  Overfitting puts a ray's
+    weight on the last coarse sample, which _sample_pdf never sees (rendering.py:213), leaving a pdf of 1e-8 floors and fp32
+    ``1 - exp(-x)`` quanta: fp32 and fp64 then draw different fine samples.  Stored: the weights, both renders, both sets of
+    fine-sample indices, and per output the number of rays on which the two reference runs differ by more than the north-star
+    bound (1e-4 relative) -- the yardstick tests hold this implementation to.
+    To keep the fixture near 1 MB the stored weights are the seeded initialisation plus the Adam displacement quantised to int8 per
+    tensor (step = max|displacement| / 127); BOTH reference renders use exactly these weights, so nothing is approximate about
+    what is pinned -- only the weights are 'about 30 steps' rather than exactly 30 steps from the initialisation.
+    ``deltas``: instead of training here, take rays / seeds / quantised displacements from a file written on the GPU box by
+    tests/golden/export_hip_overfit.py (the implementation under test overfitting ITS batch with its one-call step: the weights
+    bench.py's evaluation extras and the parity tests of rounds 2-3 render) -- the reference then only renders them, fp32 and fp64."""
+    s = common.SCENE
+    if deltas is not None:
+        src = np.load(deltas)
+        return _overfit_renders(name, {k: src[k] for k in src.files if k in ('rays', 'idx', 'seed_fg', 'seed_bg', 'steps', 'losses') or k[:3] in ('dq_', 'ds_')})
+    hp = Namespace(**vars(make_hparams(coarse_samples=64, fine_samples=128)))
+    rays, idx = common.pick_rays(all_rays, N, seed)
+    A = s['appearance_count']
+    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    w0 = (common.make_weights(fcfg, A, seed * 1000), common.make_weights(bcfg, A, seed * 1000 + 500))
+    nerf, bg_nerf = ref_model(hp, fcfg, w0[0], A), ref_model(hp, bcfg, w0[1], A)
+    nerf.train(), bg_nerf.train()
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed + 1)
+    target = T(rng.uniform(0, 1, (N, 3)).astype(f32))
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    opts = [torch.optim.Adam(nerf.parameters(), lr=5e-4), torch.optim.Adam(bg_nerf.parameters(), lr=5e-4)]
+    idx_i = T(idx.astype(np.int32))
+    losses = []
+    for it in range(steps):
+        res, present = R.render_rays(nerf, bg_nerf, T(rays), idx_i, hp, sc, sr, False, True, False)
+        loss = torch.nn.functional.mse_loss(res['rgb_fine'], target)
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        loss.backward()
+        for i, o in enumerate(opts):
+            if i == 1 and not present:
+                continue
+            o.step()
+        losses.append(float(loss.detach()))
+        print('overfit step', it, losses[-1], flush=True)
+    out = dict(rays=rays, idx=idx.astype(np.int32), seed_fg=seed * 1000, seed_bg=seed * 1000 + 500, steps=steps, losses=np.array(losses, f32))
+    for tag, m, init in (('fg', nerf, w0[0]), ('bg', bg_nerf, w0[1])):
+        for k, v in m.state_dict().items():
+            d = v.detach().numpy().astype(np.float64) - init[k].astype(np.float64)
+            scale = f32(max(float(np.abs(d).max()), 1e-30) / 127.0)
+            out['dq_%s_%s' % (tag, k)] = np.clip(np.rint(d / scale), -127, 127).astype(np.int8)
+            out['ds_%s_%s' % (tag, k)] = scale
+    _overfit_renders(name, out)
+
+
+def _overfit_renders(name, out):
+    """rays + seeds + quantised displacements -> the reference's fp32 and fp64 renders of the decoded weights, the indices both runs drew
+    and the per-output count of rays on which they differ beyond the north-star bound."""
+    s = common.SCENE
+    hp = Namespace(**vars(make_hparams(coarse_samples=64, fine_samples=128)))
+    A = s['appearance_count']
+    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    rays, idx = out['rays'], out['idx']
+    N = rays.shape[0]
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    weights = []
+    for tag, cfg, sd in (('fg', fcfg, int(out['seed_fg'])), ('bg', bcfg, int(out['seed_bg']))):
+        init = common.make_weights(cfg, A, sd)
+        weights.append({k: (init[k] + out['dq_%s_%s' % (tag, k)].astype(f32) * f32(out['ds_%s_%s' % (tag, k)])).astype(f32) for k in init})
+    E = (True, False, True)
+    keys = ('rgb_fine', 'fg_rgb_fine', 'bg_rgb_fine', 'depth_fine', 'fg_depth_fine', 'bg_depth_fine', 'bg_lambda_fine')
+    runs = {}
+    for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        torch.set_default_dtype(dt)
+        try:
+            n2, b2 = ref_model(hp, fcfg, weights[0], A), ref_model(hp, bcfg, weights[1], A)
+            n2.eval(), b2.eval()
+            with Recorder(hp.coarse_samples) as rec, torch.inference_mode():
+                res, present = R.render_rays(n2, b2, T(rays).to(dt), T(idx.astype(f32)), hp, sc.to(dt), sr.to(dt), *E)
+            runs[tag] = {k: res[k].numpy().astype(np.float64) for k in keys}
+            for k in keys:
+                out['res_%s_%s' % (tag, k)] = res[k].numpy()
+            for k, v in rec.inds.items():
+                out['inds_%s_%s' % (tag, k)] = v.astype(np.int16)
+            out['present'] = np.array(present)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    bad_any = np.zeros(N, bool)
+    for k in keys:
+        a, b = runs['f32'][k], runs['f64'][k]
+        bad = (np.abs(a - b) > 2e-5 + 1e-4 * np.abs(b)).reshape(N, -1).any(1)
+        out['selfdiff_' + k] = np.int32(bad.sum())
+        bad_any |= bad
+        print('reference fp32 vs fp64, %s: %d rays beyond 1e-4' % (k, bad.sum()))
+    out['selfdiff_rays'] = np.flatnonzero(bad_any).astype(np.int32)
+    moved = out['inds_f32_fg'] != out['inds_f64_fg']
+    print('reference fp32 vs fp64: %d of %d fg fine indices differ on %d rays; %d rays beyond the bound in some output'
+          % (moved.sum(), moved.size, moved.any(1).sum(), bad_any.sum()))
+    save(name, **out)
+
+
 def main(only=None):
     torch.set_num_threads(8)
     all_rays = scene_rays()
@@ -409,6 +510,14 @@ def main(only=None):
     case('render_container25_eval', dict(base, container_path='dummy'), 24, 25, E, container=25, layer_dim=512, bg_layer_dim=512)
     case('render_nerf_cfg_train', dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0), 32, 15, TR,
          bg=False, cascade=True, fg_train=True, with_grad=True, layer_dim=160)
+    # round 4: the overfit regime (sampling decided by rounding), fp32 and fp64 runs of the reference on the same weights
+    if only is None or 'render_overfit_eval' in only:
+        run_overfit('render_overfit_eval', all_rays)
+    if only is None or 'render_overfit_hip_eval' in only:
+        # weights overfitted on the GPU box by the implementation under test (export_hip_overfit.py); without a fresh export the
+        # displacements stored in the committed fixture are re-rendered (idempotent)
+        src = ROOT / 'gpurun_out' / 'hip_overfit_deltas.npz'
+        run_overfit('render_overfit_hip_eval', all_rays, deltas=src if src.exists() else HERE / 'render_overfit_hip_eval.npz')
 
 
 if __name__ == '__main__':

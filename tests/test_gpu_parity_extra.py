@@ -12,7 +12,7 @@ import torch
 import common
 import fp64_ref
 from oracle import nerf_oracle as O
-from test_oracle_golden import build_case, load, mlp_variant
+from test_oracle_golden import OVERFIT_KEYS, build_case, load, mlp_variant, overfit_case, rays_beyond_bound
 from test_gpu_parity import DEV, T, close, native_models, native_nerf
 
 pytestmark = pytest.mark.gpu
@@ -160,11 +160,29 @@ def _benchmark_shape_check(train_steps=0, max_offenders=9, same_batch=False):
     moved = rnd['_inds_fg'].cpu().numpy() != dbg['fg']['inds']
     keys = ('rgb_fine', 'fg_rgb_fine', 'bg_rgb_fine', 'depth_fine', 'fg_depth_fine', 'bg_depth_fine', 'bg_lambda_fine')
     offenders, worst, zmove = all_ray_violations(res, ores, rnd, dbg, keys)
+    per_output = {k: int(rays_beyond_bound(res[k].cpu().numpy(), ores[k], 1024).sum()) for k in keys}
+    print('rays beyond the bound per output:', per_output)
     print('moved fine indices: %d of %d (%d at the last u), rays with a moved index: %d; worst error per output in units of the '
           'bound: %s; rays missing the bound: %s' % (moved.sum(), moved.size, moved[:, -1].sum(), moved.any(1).sum(),
                                                      {k: '%.3f' % v for k, v in worst.items()}, offenders.tolist()))
     if train_steps == 0:
+        # "bit-exact sample indices", stated as the mechanism: an index may differ from the oracle's only (i) at the last u = 1.0, which
+        # sits on cdf[-1] = 1 -+ ulp, or (ii) where u is within GEMM rounding of a cdf entry, in which case the SAMPLE does not move
+        # (_sample_cdf is continuous across an entry), or (iii) across a run of zero-probability bins (equal cdf entries)
         assert moved.mean() < 5e-3
+        zg_, zo_ = rnd['_fine_z_fg'].cpu().numpy(), dbg['fg']['fine_z']
+        inner = np.argwhere(moved[:, :-1])
+        jumps = 0
+        for r_, j_ in inner:
+            if abs(zg_[r_, j_] - zo_[r_, j_]) <= 1e-5 * max(abs(zo_[r_, j_]), 1e-9):
+                continue                                                    # (ii): same sample to 1e-5 relative
+            a_, b_ = sorted((int(rnd['_inds_fg'][r_, j_]), int(dbg['fg']['inds'][r_, j_])))
+            w_ = dbg['fg']['weights_coarse'][r_, 1:-1]
+            pdf = (w_ + 1e-8) / (w_ + 1e-8).sum()
+            assert pdf[max(a_ - 1, 0):b_].sum() <= 1e-6, ('a moved index that is not explained', r_, j_, a_, b_)      # (iii)
+            jumps += 1
+        print('moved indices away from the last u: %d, of which across zero-probability runs: %d' % (len(inner), jumps))
+        assert jumps <= 9
     elif moved.mean() >= 5e-3:
         r = int(np.argmax(moved.sum(1)))
         wc = dbg['fg']['weights_coarse'][r]
@@ -182,23 +200,56 @@ def test_benchmark_shape_render_against_oracle():
 
 
 def test_benchmark_shape_render_against_oracle_after_training_steps():
-    """The same all-ray assertion on the weights the benchmark's evaluation actually sees -- 25 fused training steps away from the
-    initialisation: a ray may still miss the bound only where one of its fine samples sits elsewhere than the oracle's."""
-    _benchmark_shape_check(train_steps=25, max_offenders=80)
+    """The same all-ray assertion on lightly trained weights -- 25 fused training steps (a fresh batch each) away from the
+    initialisation: a ray may still miss the bound only where one of its fine samples sits elsewhere than the oracle's (measured: none)."""
+    _benchmark_shape_check(train_steps=25, max_offenders=9)
 
 
-def test_benchmark_shape_render_against_oracle_after_overfitting_one_batch():
-    """... and after 30 steps on the rendered batch itself (bench.py's protocol: warm-up + timed steps on one batch, then the
-    evaluation side measurements on it).  Overfitting drives most rays into a regime where the reference's importance sampling is
-    decided by rounding: all of a ray's weight sits on the LAST coarse sample, which _sample_pdf excludes (rendering.py:213
-    ``weights_coarse[:, 1:-1]``), so the pdf is made of the 1e-8 floor plus interior weights alpha * T with alpha = 1 - exp(-delta
-    sigma) of a few 1e-8 -- and in fp32 ``1 - exp(-x)`` is either 0 or a multiple of 6e-8 (one ulp of 1.0).  A sigma that differs in
-    its last bit (GEMM summation order) flips a bin's probability by a factor 7: a quarter of the fine-sample INDICES then differ
-    from the oracle's on ~60 % of the rays (measured: 35 157 of 131 072 on 685 rays), the samples move by up to 10 % -- through
-    space that is empty to 1e-8, so the rendered outputs still agree: the foreground outputs on every ray, and a few dozen rays
-    miss the bound in the background outputs, each with a moved sample.  Any two fp32 implementations differ this way (the fp32 and the
-    split-precision kernels do: bench.py ``rgb_difference_to_f32_kernels``); it is a property of the algorithm, recorded here."""
-    _benchmark_shape_check(train_steps=30, max_offenders=100, same_batch=True)
+@pytest.mark.parametrize('fixture', ['render_overfit_eval', 'render_overfit_hip_eval'])
+@pytest.mark.parametrize('path', ['stages', 'fused', 'split'])
+def test_overfit_regime_against_the_references_own_fp32_and_fp64_runs(path, fixture, monkeypatch):
+    """Where the reference's OWN importance sampling is decided by rounding, pinned by the reference itself
+    (tests/golden/make_golden.py::run_overfit): weights ~30 Adam steps into overfitting one 1024-ray batch -- trained by the reference
+    (render_overfit_eval) or by this implementation's one-call step with bench.py's protocol (render_overfit_hip_eval: the weights the
+    round-3 tests allowed 100 offenders on) -- rendered BY THE REFERENCE in fp32 and in fp64.  Its two runs draw different fine
+    samples on practically every ray (14 % / 45 % of the indices) and differ beyond the north-star bound on 131 rays in depth_fine /
+    bg_depth_fine (first fixture) resp. on 28 rays in rgb_fine / bg_rgb_fine / depth_fine / bg_depth_fine (second); foreground outputs
+    and bg_lambda agree on every ray.  This implementation (stage-by-stage launches, the one-call render, the split-precision kernels)
+    is held to exactly that: an output the reference pins with both of its runs must be met on EVERY ray against both; in an output
+    where the reference's fp32 run misses its fp64 run on `own` rays, at most 1.5 own + 4 rays may miss the fp64 run and at most
+    2 own + 4 the fp32 run (two rounding-noise parties)."""
+    from mega_nerf import rendering
+    from mega_nerf.rendering import render_rays
+    g, hp, fcfg, bcfg, fw, bw = overfit_case(fixture)
+    s = common.SCENE
+    nerf, bg_nerf = native_nerf(fcfg, fw).to(DEV).eval(), native_nerf(bcfg, bw).to(DEV).eval()
+    monkeypatch.setattr(rendering, 'FUSED_RENDER', path != 'stages')
+    monkeypatch.setattr(rendering, 'SPLIT_PRECISION', path == 'split')
+    rnd = {'_want_inds': True}
+    with torch.no_grad():
+        res, present = render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)), T(s['sphere_center']),
+                                   T(s['sphere_radius']), True, False, True, _randoms=rnd if path == 'stages' else None)
+    n = g['rays'].shape[0]
+    assert present == bool(g['present'])
+    report = {}
+    for k in OVERFIT_KEYS:
+        self_bad = rays_beyond_bound(g['res_f32_' + k], g['res_f64_' + k], n)
+        bad64 = rays_beyond_bound(res[k].cpu().numpy(), g['res_f64_' + k], n)
+        bad32 = rays_beyond_bound(res[k].cpu().numpy(), g['res_f32_' + k], n)
+        report[k] = (int(bad64.sum()), int(bad32.sum()), int(self_bad.sum()), int((bad64 & ~self_bad).sum()))
+    print(path, '(vs fp64, vs fp32, reference fp32 vs fp64, vs fp64 outside the reference\'s own rays):', report)
+    if path == 'stages':
+        mine = rnd['_inds_fg'].cpu().numpy()
+        print('fg fine indices differing: mine vs ref fp32 %d, mine vs ref fp64 %d, ref fp32 vs ref fp64 %d of %d' % (
+            (mine != g['inds_f32_fg']).sum(), (mine != g['inds_f64_fg']).sum(), (g['inds_f32_fg'] != g['inds_f64_fg']).sum(), mine.size))
+        # the index disagreement is the regime's, not this implementation's: no larger against either reference run than theirs with each other
+        own = int((g['inds_f32_fg'] != g['inds_f64_fg']).sum())
+        assert (mine != g['inds_f64_fg']).sum() <= 1.25 * own and (mine != g['inds_f32_fg']).sum() <= 1.6 * own
+    for k, (b64, b32, own, outside) in report.items():
+        if own == 0:        # the reference agrees with itself on every ray: so must this implementation, with both of its runs
+            assert b64 == 0 and b32 == 0, (k, report)
+        else:
+            assert b64 <= 1.5 * own + 4 and b32 <= 2 * own + 4, (k, report)
 
 
 def test_training_render_deviates_only_where_sample_indices_moved():
