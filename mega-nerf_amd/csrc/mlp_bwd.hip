@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "mlp_bwd_device.h"
+#include "sh_device.h"
 #include "pack_device.h"
 #include "step_internal.h"
 
@@ -601,7 +602,68 @@ __global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads_jobs(HeadJobs js
     const HeadJob &j = js.job[blockIdx.y];
     if ((int)blockIdx.x >= j.n_blocks) return;
     head_grads_body(j.dheads, j.a_last, W, j.dact, W / 2, j.row0, j.n_rows, j.n_units_dev, j.rows_per_unit, j.d_sigma_w, j.d_sigma_b,
-                    j.d_rgb_w, j.d_rgb_b, 1, (int)blockIdx.x, j.n_blocks);
+                    j.d_rgb_w, j.d_rgb_b, j.d_rgb_w ? 1 : 0, (int)blockIdx.x, j.n_blocks);
+}
+
+
+// Spherical-harmonics colour head, backward (rendering.py:301-306: rgb = sigmoid(eval_sh(coef, dir)), coef = rgb layer of 3 x nb
+// outputs, channel-major): per row  g_c = d_rgb_c * s_c (1 - s_c),  d_coef[c][k] = g_c * basis_k(dir)  and from there
+//     dd[j]          = sum_ck d_coef[ck] * W_rgb[ck][j]      dL/d(dir_a output), handed to the data-gradient chain (MlpBwdArgs::dd_in)
+//     dW_rgb[ck][j] += d_coef[ck] * a[j],  db_rgb[ck] += d_coef[ck]        (a = dir_a output row on the tape)
+// One wavefront per row, lanes over the 128 features (two each): the lane's two columns of W_rgb and of the dW accumulator live in
+// registers for the block's whole row range, d_coef is wave-uniform; a block's four wavefronts meet in LDS and add their sums with
+// one set of atomics.  HBM: 1 KB per row (a in, dd out) -- ~0.2 GB per benchmark step; few long blocks like k_head_grads.
+struct ShHeadJobs { ShHeadJob job[SH_HEAD_MAX_JOBS]; };
+template <int NB>
+__global__ __launch_bounds__(256) void k_sh_head_bwd(ShHeadJobs js) {
+    constexpr int NC = 3 * NB, H2 = 128;
+    const ShHeadJob &j = js.job[blockIdx.y];
+    if ((int)blockIdx.x >= j.n_blocks) return;
+    const long n = j.n_units_dev ? (long)(*j.n_units_dev) * j.rows_per_unit : j.n_rows;
+    const long per = ((n + j.n_blocks - 1) / j.n_blocks + 3) / 4 * 4;
+    const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
+    if (rb >= re) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w0[NC], w1[NC], a0[NC], a1[NC], bsum[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        w0[c] = j.rgb_w[c * H2 + lane]; w1[c] = j.rgb_w[c * H2 + 64 + lane];
+        a0[c] = 0.f; a1[c] = 0.f; bsum[c] = 0.f;
+    }
+    for (long r = rb + wave; r < re; r += 4) {
+        const long ro = j.out_row0 + r, rt = j.tape_row0 + r;
+        const float4 go = *reinterpret_cast<const float4 *>(j.d_out + ro * 4), o = *reinterpret_cast<const float4 *>(j.out + ro * 4);
+        const float *dv = j.dirs + (ro / j.rows_per_ray) * j.dir_stride;
+        float b[25];
+        sh_basis(j.sh_deg, dv[0], dv[1], dv[2], b);
+        const float g[3] = {go.x * (o.x * (1.f - o.x)), go.y * (o.y * (1.f - o.y)), go.z * (o.z * (1.f - o.z))};
+        const float x0 = j.dact[rt * H2 + lane], x1 = j.dact[rt * H2 + 64 + lane];
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const float dc = g[c] * b[k];
+                d0 = fmaf(dc, w0[c * NB + k], d0); d1 = fmaf(dc, w1[c * NB + k], d1);
+                a0[c * NB + k] = fmaf(dc, x0, a0[c * NB + k]); a1[c * NB + k] = fmaf(dc, x1, a1[c * NB + k]);
+                bsum[c * NB + k] += dc;
+            }
+        j.dd[ro * H2 + lane] = d0; j.dd[ro * H2 + 64 + lane] = d1;
+    }
+    // combine the four wavefronts: NC x 128 sums in passes of one coefficient row (128 floats per wavefront) to stay inside 64 KB of LDS
+    __shared__ float acc[4][H2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        acc[wave][lane] = a0[c]; acc[wave][64 + lane] = a1[c];
+        __syncthreads();
+        if (threadIdx.x < H2) atomicAdd(j.d_rgb_w + c * H2 + threadIdx.x, acc[0][threadIdx.x] + acc[1][threadIdx.x] + acc[2][threadIdx.x] + acc[3][threadIdx.x]);
+        __syncthreads();
+    }
+    // bias sums are wave-uniform: lane c of every wavefront carries coefficient c
+    float mine = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) mine = lane == c ? bsum[c] : mine;
+    if (lane < NC) atomicAdd(j.d_rgb_b + lane, mine);
 }
 
 }  // namespace mnr
@@ -626,6 +688,23 @@ int mnr::head_grads_jobs(const HeadJob *jobs, int n_jobs, int W, hipStream_t s) 
     for (int i = 0; i < n_jobs; ++i) { js.job[i] = jobs[i]; max_blocks = jobs[i].n_blocks > max_blocks ? jobs[i].n_blocks : max_blocks; }
     hipLaunchKernelGGL(k_head_grads_jobs, dim3((unsigned)max_blocks, (unsigned)n_jobs), dim3(256 * HG_GROUPS), 0, s, js, W);
     return check_launch("k_head_grads_jobs");
+}
+
+int mnr::sh_head_bwd_jobs(const ShHeadJob *jobs, int n_jobs, hipStream_t s) {
+    MNR_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= SH_HEAD_MAX_JOBS, "1..%d colour-head jobs per launch", SH_HEAD_MAX_JOBS);
+    ShHeadJobs js{};
+    int max_blocks = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        MNR_REQUIRE(jobs[i].sh_deg == jobs[0].sh_deg && jobs[i].n_blocks >= 1, "colour-head jobs of one launch share the SH degree");
+        js.job[i] = jobs[i];
+        max_blocks = jobs[i].n_blocks > max_blocks ? jobs[i].n_blocks : max_blocks;
+    }
+    const dim3 grid((unsigned)max_blocks, (unsigned)n_jobs);
+    switch (jobs[0].sh_deg) {
+        case 2: hipLaunchKernelGGL(k_sh_head_bwd<9>, grid, dim3(256), 0, s, js); break;
+        default: return set_err(MNR_E_UNSUPPORTED, "the fused colour-head adjoint is instantiated for sh_deg 2 (configs/mega-nerf-sh-3)");
+    }
+    return check_launch("k_sh_head_bwd");
 }
 
 // sigma / rgb head weight gradients of the rows of one segment (dheads was just written by the chain kernel)
@@ -680,24 +759,17 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
 
 // Data-gradient chains of several segments (coarse + fine rows of the foreground and background models) in ONE launch,
 // then the head gradients of every segment.  Default 8x256 fg / bg architectures only (MNR_E_UNSUPPORTED otherwise).
-int mnr::mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
-    using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
-    using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
-    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
+template <class CfgFG, class CfgBG>
+static int mlp_backward_chain_multi_pair(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
     MlpBwdMulti mm{};
     long wg = 0;
     for (int i = 0; i < n_segs; ++i) {
         const mnr_mlp_grad_launch &L = segs[i];
-        MNR_REQUIRE(L.desc && L.io, "segment %d: NULL argument", i);
         const mnr_model_desc *d = L.desc;
         ModelLayout m;
         BwdLayout b;
         int rc = layout_from_desc(d, m);
         if (rc != MNR_OK) return rc;
-        const bool common = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 256 &&
-                            d->layers == 8 && d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
-        if (!common || (d->xyz_dim != 3 && d->xyz_dim != 4))
-            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_backward_data_multi covers the default 8x256 fg / bg models");
         rc = bwd_layout_from_desc(d, b);
         if (rc != MNR_OK) return rc;
         rc = fill_bwd_args(mm.seg[i], m, L.packed_fwd_dev, L.packed_bwd_dev, d, L.io);
@@ -724,6 +796,31 @@ int mnr::mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_se
     const unsigned ny = cells ? (unsigned)(segs[0].io->n_rows / cells[0].cell_rows) : 1u;
     hipLaunchKernelGGL((k_mlp_bwd_multi<CfgFG, CfgBG>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
     return check_launch("k_mlp_bwd_multi");
+}
+
+// Data-gradient chains of several segments (coarse + fine rows of the foreground and background models) in ONE launch.
+// The default 8x256 fg / bg architectures, and their spherical-harmonics form (sh_deg 2: rgb_dim 27, no direction encoding; the
+// gradient at the dir_a output comes in through mnr_mlp_grad_io::dd_in); MNR_E_UNSUPPORTED otherwise.
+int mnr::mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
+    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_BWD_MAX_SEGS, "1..%d segments per launch", MLP_BWD_MAX_SEGS);
+    int pair = -1;
+    for (int i = 0; i < n_segs; ++i) {
+        MNR_REQUIRE(segs[i].desc && segs[i].io, "segment %d: NULL argument", i);
+        const mnr_model_desc *d = segs[i].desc;
+        const bool trunk = (d->xyz_dim == 3 || d->xyz_dim == 4) && d->pos_xyz_dim == 12 && d->appearance_dim == 48 && d->layer_dim == 256 &&
+                           d->layers == 8 && d->skip_mask == 16 && (d->mfma_tile == 0 || d->mfma_tile == 16);
+        const int p = !trunk ? 0 : (d->pos_dir_dim == 4 && d->rgb_dim == 3 ? 1 : (d->pos_dir_dim == 0 && d->rgb_dim == 27 ? 2 : 0));
+        if (p == 0 || (pair >= 0 && p != pair))
+            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_backward_data_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2) form");
+        pair = p;
+    }
+    if (pair == 1)
+        return mlp_backward_chain_multi_pair<MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>>(segs, n_segs, cells, s);
+#ifdef MNR_ALL_VARIANTS
+    return mlp_backward_chain_multi_pair<MlpCfg<3, 12, 0, 48, 256, 8, 16, 27, 16>, MlpCfg<4, 12, 0, 48, 256, 8, 16, 27, 16>>(segs, n_segs, cells, s);
+#else
+    return set_err(MNR_E_UNSUPPORTED, "built without MNR_ALL_VARIANTS: no spherical-harmonics multi-segment kernels");
+#endif
 }
 
 extern "C" int mnr_mlp_backward_chain_multi(const mnr_mlp_grad_launch *segs, int n_segs, void *stream) {

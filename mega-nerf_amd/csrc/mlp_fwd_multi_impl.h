@@ -1,0 +1,62 @@
+// mlp_fwd_multi_impl.h -- body of mnr_mlp_forward_multi for one (foreground, background) configuration pair; included by the
+// translation units that instantiate a pair (mlp_fwd_multi.hip: the default models; mlp_fwd_multi_sh.hip: the spherical-harmonics
+// models of configs/mega-nerf-sh-3) so that the pairs compile in parallel.
+#pragma once
+#include "mlp_fwd_kernels.h"
+#include "step_internal.h"
+
+namespace mnr {
+
+static inline long n_cells_of(const mnr_mlp_launch &L, const CellTable &c) { return c.cell_rows > 0 ? L.io->n_rows / c.cell_rows : 0; }
+
+template <class CfgFG, class CfgBG>
+static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
+    MlpFwdMulti mm{};
+    const bool train = segs[0].tape_dev != nullptr;
+    long wg = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const mnr_mlp_launch &L = segs[i];
+        MNR_REQUIRE(L.packed_dev && L.desc && L.io && L.io->xyz && L.io->out, "segment %d: NULL pointer argument", i);
+        MNR_REQUIRE((L.tape_dev != nullptr) == train, "segments must be all training or all inference launches");
+        MNR_REQUIRE(!L.io->row_index && !L.io->sigma_only, "segment %d: gather / sigma_only are single-launch features", i);
+        // spherical-harmonics pair: the colour epilogue (eval_sh + sigmoid) must be ON -- a multi-segment launch writes 4 floats per row
+        MNR_REQUIRE(CfgFG::RGB == 3 ? L.io->apply_sh_deg < 0 : L.io->apply_sh_deg >= 0, "segment %d: apply_sh_deg does not fit the architecture", i);
+        MNR_REQUIRE(L.io->rows_per_ray >= 1 && L.io->n_rows >= 0, "segment %d: bad row counts", i);
+        MNR_REQUIRE(L.io->dir && L.io->idx && L.desc->embedding_a, "segment %d: dir / idx / embedding_a required", i);
+        if (train) MNR_REQUIRE(L.tape_row0 >= 0 && L.tape_rows >= L.tape_row0 + L.io->n_rows, "segment %d: tape buffer too small", i);
+        ModelLayout m;
+        int rc = layout_from_desc(L.desc, m);
+        if (rc != MNR_OK) return rc;
+        const bool is_bg = L.desc->xyz_dim == 4;
+        rc = !is_bg ? fill_fwd_args<CfgFG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0)
+                    : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0);
+        if (rc != MNR_OK) return rc;
+        if (cells && cells[i].dcells) {
+            MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % CfgFG::ROWS_PER_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
+                        "segment %d: rows per cell must be a multiple of %d", i, CfgFG::ROWS_PER_WG);
+            mm.seg[i].dcells = cells[i].dcells;
+            mm.seg[i].cell_rows = cells[i].cell_rows;
+        }
+        mm.is_b[i] = is_bg ? 1 : 0;
+        mm.wg0[i] = (int32_t)wg;
+        if (cells) {                       // grid = (workgroups per cell, cells): every segment spans the same cells
+            MNR_REQUIRE(cells[i].dcells && n_cells_of(L, cells[i]) == n_cells_of(segs[0], cells[0]) && n_cells_of(L, cells[i]) >= 1,
+                        "multi-cell launch: every segment needs a cell table over the same number of cells");
+            wg += cells[i].cell_rows / CfgFG::ROWS_PER_WG;
+        } else
+        wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
+        MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
+    }
+    for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
+    mm.nseg = n_segs;
+    if (wg == 0) return MNR_OK;
+    const unsigned ny = cells ? (unsigned)n_cells_of(segs[0], cells[0]) : 1u;
+    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    return check_launch("k_mlp_fwd_multi");
+}
+
+// the pair of the spherical-harmonics configuration (mlp_fwd_multi_sh.hip)
+int mlp_forward_multi_sh(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
+
+}  // namespace mnr

@@ -107,11 +107,13 @@ struct StepWs {
     size_t tape_f, gtape_f, dheads_f, tape_b, gtape_b, dheads_b;
     size_t ep_job, slab;
     size_t tab_cells, tab_pack, tab_adam, t_c, t_bc, t_f, t_bf;
+    size_t dd_fc, dd_ff, dd_bc, dd_bf;        // spherical-harmonics models: dL/d(dir_a output) of the four (branch, pass) row sets [rows][W/2]
     size_t sticky;                            // int32 [MAXC]: health bits that survive the per-step memset (cleared by mnr_step_create)
     size_t grad_stride, total;
 };
 struct StepDims {
     long C, N, Nc, Nf, Sb, Sfb, cap_f, cap_b, fpr_f, fpr_b;
+    int sh_deg;        // >= 0: spherical-harmonics colour head (rgb_dim = 3 (sh_deg + 1)^2, no direction encoding); -1: the plain rgb head
 };
 
 static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mnr_model_desc *bg, StepDims &D) {
@@ -129,12 +131,17 @@ static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mn
     D.cap_f = D.N * (D.Nc + D.Nf); D.cap_b = D.N * (D.Sb + D.Sfb);
     D.fpr_f = mnr_tape_floats_per_row(fg); D.fpr_b = mnr_tape_floats_per_row(bg);
     if (D.fpr_f <= 0 || D.fpr_b <= 0) return set_err(MNR_E_UNSUPPORTED, "no training kernels for this architecture");
-    const bool arch = fg->xyz_dim == 3 && bg->xyz_dim == 4 && fg->pos_xyz_dim == 12 && bg->pos_xyz_dim == 12 && fg->pos_dir_dim == 4 &&
-                      bg->pos_dir_dim == 4 && fg->appearance_dim == 48 && bg->appearance_dim == 48 && fg->layer_dim == 256 &&
-                      bg->layer_dim == 256 && fg->layers == 8 && bg->layers == 8 && fg->skip_mask == 16 && bg->skip_mask == 16 &&
-                      fg->rgb_dim == 3 && bg->rgb_dim == 3 && (fg->mfma_tile == 0 || fg->mfma_tile == 16) &&
-                      (bg->mfma_tile == 0 || bg->mfma_tile == 16);
-    if (!arch) return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models");
+    const bool trunk = fg->xyz_dim == 3 && bg->xyz_dim == 4 && fg->pos_xyz_dim == 12 && bg->pos_xyz_dim == 12 && fg->appearance_dim == 48 &&
+                       bg->appearance_dim == 48 && fg->layer_dim == 256 && bg->layer_dim == 256 && fg->layers == 8 && bg->layers == 8 &&
+                       fg->skip_mask == 16 && bg->skip_mask == 16 && (fg->mfma_tile == 0 || fg->mfma_tile == 16) &&
+                       (bg->mfma_tile == 0 || bg->mfma_tile == 16);
+    const bool plain = fg->pos_dir_dim == 4 && bg->pos_dir_dim == 4 && fg->rgb_dim == 3 && bg->rgb_dim == 3;
+    // configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0 -> 27 colour coefficients, dir_a_encoding over [features | appearance]
+    const bool sh2 = fg->pos_dir_dim == 0 && bg->pos_dir_dim == 0 && fg->rgb_dim == 27 && bg->rgb_dim == 27;
+    if (!trunk || !(plain || sh2))
+        return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models and their sh_deg 2 form");
+    if (sh2 && cfg->split_precision) return set_err(MNR_E_UNSUPPORTED, "no split-precision kernels for the spherical-harmonics colour head");
+    D.sh_deg = sh2 ? 2 : -1;
     return MNR_OK;
 }
 
@@ -168,6 +175,10 @@ static void step_layout(const mnr_step_cfg *cfg, const StepDims &D, StepWs &L) {
     L.tab_adam = take(0);
     L.t_c = take(D.Nc * 4); L.t_bc = take(D.Sb * 4); L.t_f = take(D.Nf * 4); L.t_bf = take(D.Sfb * 4);
     L.sticky = take(MAXC * 4);
+    L.dd_fc = L.dd_ff = L.dd_bc = L.dd_bf = 0;
+    if (D.sh_deg >= 0) {
+        L.dd_fc = take(CN * D.Nc * 128 * 4); L.dd_ff = take(CN * D.Nf * 128 * 4); L.dd_bc = take(CN * D.Sb * 128 * 4); L.dd_bf = take(CN * D.Sfb * 128 * 4);
+    }
     L.total = off;
 }
 
@@ -1158,14 +1169,14 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         io[0].rows_per_ray = (int32_t)Sf;
         io[0].sigma_noise = noise ? F(pass ? L.noise_ff : L.noise_fc) : nullptr;
         io[0].out = F(pass ? L.raw_f : L.raw_c); io[0].out_stride = 4;
-        io[0].n_rows = D.C * D.N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = -1;
+        io[0].n_rows = D.C * D.N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = D.sh_deg;
         io[1].xyz = F(pass ? L.pts_f : L.pts_c); io[1].xyz_stride = 4;
         io[1].dir = F(L.rays_bg) + 3; io[1].dir_stride = 8;
         io[1].idx = ws + L.idx_bg; io[1].idx_stride = 1; io[1].idx_is_float = batches[0].idx_is_float;
         io[1].rows_per_ray = (int32_t)Sbb;
         io[1].sigma_noise = noise ? F(pass ? L.noise_bf : L.noise_bc) : nullptr;
         io[1].out = F(pass ? L.braw_f : L.braw_c); io[1].out_stride = 4;
-        io[1].n_rows = D.C * D.N * Sbb; io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = -1;
+        io[1].n_rows = D.C * D.N * Sbb; io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = D.sh_deg;
         mnr_mlp_launch seg[2] = {};
         seg[0].packed_dev = split ? M0f.packed_h2_dev : M0f.packed_dev; seg[0].desc = &M0f.desc; seg[0].io = &io[0];
         seg[0].tape_dev = F(L.tape_f); seg[0].tape_rows = capT_f; seg[0].tape_row0 = 0;
@@ -1241,6 +1252,37 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         rc = check_launch("k_step_tail");
         if (rc) return rc;
     }
+    // ---- spherical-harmonics colour head: dL/d(raw rgb) -> dL/d(dir_a output) + rgb layer gradients, every (cell, branch, pass) ----
+    if (D.sh_deg >= 0) {
+        const TapeLayout tlf = tape_layout(ArchDims{M0f.desc.xyz_dim, M0f.desc.pos_xyz_dim, M0f.desc.pos_dir_dim, M0f.desc.layers, M0f.desc.skip_mask,
+                                                    M0f.desc.layer_dim, M0f.desc.appearance_dim, M0f.desc.rgb_dim, M0f.desc.mfma_tile});
+        const TapeLayout tlb = tape_layout(ArchDims{M0b.desc.xyz_dim, M0b.desc.pos_xyz_dim, M0b.desc.pos_dir_dim, M0b.desc.layers, M0b.desc.skip_mask,
+                                                    M0b.desc.layer_dim, M0b.desc.appearance_dim, M0b.desc.rgb_dim, M0b.desc.mfma_tile});
+        std::vector<ShHeadJob> jobs;
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < 2; ++k)
+                for (int pass = 0; pass < 2; ++pass) {
+                    const mnr_step_model &M = p->models[2 * c + k];
+                    const long S = k == 0 ? (pass ? D.Nf : D.Nc) : (pass ? D.Sfb : D.Sb);
+                    ShHeadJob j{};
+                    j.d_out = F(k ? (pass ? L.bdraw_f : L.bdraw_c) : (pass ? L.draw_f : L.draw_c));
+                    j.out = F(k ? (pass ? L.braw_f : L.braw_c) : (pass ? L.raw_f : L.raw_c));
+                    j.dirs = F(k ? L.rays_bg : L.rays) + 3; j.dir_stride = 8; j.rows_per_ray = (int)S; j.sh_deg = D.sh_deg;
+                    j.dact = F(k ? L.tape_b : L.tape_f) + (long)(k ? tlb : tlf).dact_off * (k ? capT_b : capT_f);
+                    j.dd = F(k ? (pass ? L.dd_bf : L.dd_bc) : (pass ? L.dd_ff : L.dd_fc));
+                    j.rgb_w = M.desc.rgb_w; j.d_rgb_w = M.grad.rgb_w; j.d_rgb_b = M.grad.rgb_b;
+                    j.out_row0 = (long)c * D.N * S;
+                    j.tape_row0 = (long)c * (k ? D.cap_b : D.cap_f) + (pass ? D.N * (k ? D.Sb : D.Nc) : 0);
+                    j.n_rows = D.N * S;
+                    j.n_units_dev = k ? scal + c : nullptr; j.rows_per_unit = (int)S;
+                    const long nb = (D.N * S + 1023) / 1024;
+                    j.n_blocks = (int)(k ? 32 : (nb > 192 ? 192 : (nb < 1 ? 1 : nb)));
+                    jobs.push_back(j);
+                }
+        for (size_t i = 0; i < jobs.size() && rc == MNR_OK; i += SH_HEAD_MAX_JOBS)
+            rc = sh_head_bwd_jobs(jobs.data() + i, (int)std::min<size_t>(SH_HEAD_MAX_JOBS, jobs.size() - i), s);
+        if (rc) return rc;
+    }
     mark(4, 1);
     // ---- data-gradient chains: fg coarse, fg fine, bg coarse, bg fine (all cells each) ----
     mark(5, 0);
@@ -1261,6 +1303,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
                 g[i].idx = ws + (k ? L.idx_bg : L.idx); g[i].idx_stride = 1; g[i].idx_is_float = batches[0].idx_is_float;
                 g[i].rows_per_ray = (int32_t)S; g[i].n_rows = D.C * D.N * S; g[i].rows_per_unit = (int32_t)S;
                 g[i].grad = M.grad;
+                if (D.sh_deg >= 0) g[i].dd_in = F(k ? (pass ? L.dd_bf : L.dd_bc) : (pass ? L.dd_ff : L.dd_fc));
                 seg[i].packed_fwd_dev = split ? M.packed_h2_dev : M.packed_dev; seg[i].packed_bwd_dev = split ? M.packed_bwd_h2_dev : M.packed_bwd_dev;
                 seg[i].desc = &M.desc; seg[i].io = &g[i];
                 ct[i] = CellTable{tabs + i * C, D.N * S};
@@ -1281,11 +1324,12 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
             const mnr_model_grads &Gf = p->models[2 * c].grad, &Gb = p->models[2 * c + 1].grad;
             const long bf = (D.cap_f + 767) / 768;
             jobs.push_back(HeadJob{F(L.dheads_f), F(L.tape_f) + (long)tlf.act_off[M0f.desc.layers - 1] * capT_f, F(L.tape_f) + (long)tlf.dact_off * capT_f,
-                                   c * D.cap_f, D.cap_f, nullptr, 0, (int)(bf > 256 ? 256 : bf), Gf.sigma_w, Gf.sigma_b, Gf.rgb_w, Gf.rgb_b});
+                                   c * D.cap_f, D.cap_f, nullptr, 0, (int)(bf > 256 ? 256 : bf), Gf.sigma_w, Gf.sigma_b, D.sh_deg >= 0 ? nullptr : Gf.rgb_w,
+                                   D.sh_deg >= 0 ? nullptr : Gf.rgb_b});
             for (int pass = 0; pass < 2; ++pass)
                 jobs.push_back(HeadJob{F(L.dheads_b), F(L.tape_b) + (long)tlb.act_off[M0b.desc.layers - 1] * capT_b, F(L.tape_b) + (long)tlb.dact_off * capT_b,
                                        c * D.cap_b + (pass ? D.N * D.Sb : 0), D.N * (pass ? D.Sfb : D.Sb), scal + c, (int)(pass ? D.Sfb : D.Sb), 48,
-                                       Gb.sigma_w, Gb.sigma_b, Gb.rgb_w, Gb.rgb_b});
+                                       Gb.sigma_w, Gb.sigma_b, D.sh_deg >= 0 ? nullptr : Gb.rgb_w, D.sh_deg >= 0 ? nullptr : Gb.rgb_b});
         }
         for (size_t i = 0; i < jobs.size() && rc == MNR_OK; i += HEAD_MAX_JOBS)
             rc = head_grads_jobs(jobs.data() + i, (int)std::min<size_t>(HEAD_MAX_JOBS, jobs.size() - i), 256, s);
@@ -1395,6 +1439,9 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
     const long N = r->n_rays, Nc = r->coarse_samples, Nf = r->fine_samples, Sb = Nc / 2, Sfb = Nf / 2;
     int rc = render_dims_ok(N, Nc, Nf);
     if (rc != MNR_OK) return rc;
+    // spherical-harmonics models (rgb_dim = 3 (deg + 1)^2 coefficients, configs/mega-nerf-sh-3: deg 2): colour epilogue inside the MLP launches
+    const int sh_deg = r->fg->rgb_dim == 27 && r->bg->rgb_dim == 27 ? 2 : -1;
+    MNR_REQUIRE(sh_deg < 0 || !r->split_precision, "no split-precision kernels for the spherical-harmonics colour head");
     RenderWs L;
     render_layout(N, Nc, Nf, L);
     MNR_REQUIRE(r->workspace_bytes >= L.total, "workspace too small: %zu < %zu", r->workspace_bytes, L.total);
@@ -1427,11 +1474,11 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         const long Sf = pass ? Nf : Nc, Sbb = pass ? Sfb : Sb;
         io[0].xyz = F(pass ? L.xyz_f : L.xyz_c); io[0].xyz_stride = 3; io[0].dir = F(L.rays) + 3; io[0].dir_stride = 8;
         io[0].idx = ws + L.idx; io[0].idx_stride = 1; io[0].idx_is_float = r->idx_is_float; io[0].rows_per_ray = (int32_t)Sf;
-        io[0].out = F(pass ? L.raw_f : L.raw_c); io[0].out_stride = 4; io[0].n_rows = N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = -1;
+        io[0].out = F(pass ? L.raw_f : L.raw_c); io[0].out_stride = 4; io[0].n_rows = N * Sf; io[0].rows_per_unit = (int32_t)Sf; io[0].apply_sh_deg = sh_deg;
         io[1].xyz = F(pass ? L.pts_f : L.pts_c); io[1].xyz_stride = 4; io[1].dir = F(L.rays_bg) + 3; io[1].dir_stride = 8;
         io[1].idx = ws + L.idx_bg; io[1].idx_stride = 1; io[1].idx_is_float = r->idx_is_float; io[1].rows_per_ray = (int32_t)Sbb;
         io[1].out = F(pass ? L.braw_f : L.braw_c); io[1].out_stride = 4; io[1].n_rows = N * Sbb; io[1].n_units_dev = r->n_bg;
-        io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = -1;
+        io[1].rows_per_unit = (int32_t)Sbb; io[1].apply_sh_deg = sh_deg;
         mnr_mlp_launch seg[2] = {};
         seg[0].packed_dev = r->fg_packed; seg[0].desc = r->fg; seg[0].io = &io[0];
         seg[1].packed_dev = r->bg_packed; seg[1].desc = r->bg; seg[1].io = &io[1];

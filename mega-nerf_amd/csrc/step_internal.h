@@ -37,6 +37,23 @@ int head_grads_jobs(const HeadJob *jobs, int n_jobs, int W, hipStream_t s);
 // ... the job of one mnr_mlp_grad_io (all rows [tape_row0, tape_row0 + n_rows) of its tape)
 int head_job_of(const mnr_model_desc *d, const mnr_mlp_grad_io *io, HeadJob &job);
 
+// spherical-harmonics colour head backward (k_sh_head_bwd, csrc/mlp_bwd.hip): one job per (cell, branch, pass)
+struct ShHeadJob {
+    const float *d_out, *out;      // [..][4]: dL/d(rgb after the sigmoid, sigma), the forward's output rows -- row = out_row0 + r
+    const float *dirs;             // ray directions: dirs + ((out_row0 + r) / rows_per_ray) * dir_stride
+    long dir_stride;
+    int rows_per_ray, sh_deg;
+    const float *dact;             // tape plane of the dir_a output [tape rows][128]: row = tape_row0 + r
+    float *dd;                     // out [..][128] dL/d(dir_a output), row = out_row0 + r (mnr_mlp_grad_io::dd_in of the chain launch)
+    const float *rgb_w;            // nn.Linear(128, 3 nb).weight
+    float *d_rgb_w, *d_rgb_b;      // += (zeroed by the caller)
+    long out_row0, tape_row0, n_rows;
+    const int32_t *n_units_dev;    // NULL, or the device-side unit count: rows = *n_units_dev * rows_per_unit
+    int rows_per_unit, n_blocks;
+};
+constexpr int SH_HEAD_MAX_JOBS = 16;
+int sh_head_bwd_jobs(const ShHeadJob *jobs, int n_jobs, hipStream_t s);
+
 // weight gradients with caller-placed control words (so that the step's single memset can clear them): as
 // mnr_mlp_backward_weights_multi, but counters_dev (256 bytes, ZEROED by the caller), ep_job_dev and slab_dev are separate
 int wgrad_regions_launch(const mnr_wgrad_region *regions, int n_regions, int32_t *counters_dev, int32_t *ep_job_dev, float *slab_dev,

@@ -374,8 +374,14 @@ def _empty_results(hparams: Namespace, has_bg: bool, get_depth: bool, get_depth_
 
 
 FUSED_RENDER = True          # inference renders of the default configuration go through mnr_render_fwd (six launches)
-_render_ws: Dict[str, torch.Tensor] = {}
-_render_side: Dict[str, C.c_void_p] = {}       # device -> mnr_side handle (host object: stream + two events), created on first use
+_render_ws: Dict[tuple, torch.Tensor] = {}
+_render_side: Dict[tuple, C.c_void_p] = {}     # (device, stream) -> mnr_side handle (host object: stream + two events), created on first use
+
+
+def release_render_workspaces() -> None:
+    """Drop the cached scratch of the one-call render (~2.7 GB after 65 536-ray batches at 256 + 512 samples); the next render re-allocates."""
+    _render_ws.clear()
+
 
 
 def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_depth_variance, rnd) -> bool:
@@ -387,8 +393,12 @@ def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_d
         return False
     if (hparams.coarse_samples, hparams.fine_samples) not in ((64, 128), (256, 512)):
         return False
+    # the default models, or their spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; fp32 kernels only)
+    sh = hparams.sh_deg is not None and hparams.pos_dir_dim == 0
+    if sh and (hparams.sh_deg != 2 or SPLIT_PRECISION):
+        return False
     for m in (nerf, bg_nerf):
-        if not (isinstance(m, NeRF) and m.is_default_arch()) or m.training:
+        if not isinstance(m, NeRF) or m.training or not (m.is_sh2_arch() if sh else m.is_default_arch()):
             return False
     return nerf.xyz_dim == 3 and bg_nerf.xyz_dim == 4
 
@@ -399,7 +409,8 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
     dev = rays.device
     n = rays.shape[0]
     Nc, Nf = hparams.coarse_samples, hparams.fine_samples
-    key = str(dev)
+    # scratch and side handle per (device, stream): two renders enqueued on different streams must not share intermediates
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
     need = lib.mnr_render_workspace_bytes(n, Nc, Nf)
     ws = _render_ws.get(key)
     if ws is None or ws.numel() < need:

@@ -715,14 +715,21 @@ def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
     return results, aux.get('n_bg'), aux.get('err')
 
 
-def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int) -> bool:
-    """True if mnr_train_step (csrc/step.hip) covers this configuration: the default foreground / background architectures,
-    no cascade, 64 + 128 or 256 + 512 samples per ray, background rows of a batch filling whole 64-row tiles."""
+def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int, split_precision: bool = False) -> bool:
+    """True if mnr_train_step (csrc/step.hip) covers this configuration: the default foreground / background architectures or their
+    spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; fp32 kernels only), no cascade, 64 + 128 or 256 + 512
+    samples per ray, background rows of a batch filling whole 64-row tiles."""
     import os
     from mega_nerf.models.nerf import NeRF
-    if os.environ.get('MNR_NO_FUSED_STEP') or bg_nerf is None or not _fast_path_ok(nerf, bg_nerf, hparams):
+    if os.environ.get('MNR_NO_FUSED_STEP') or bg_nerf is None or hparams.use_cascade or hparams.fine_samples == 0:
         return False
-    if not (isinstance(nerf, NeRF) and isinstance(bg_nerf, NeRF) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
+    if not (isinstance(nerf, NeRF) and isinstance(bg_nerf, NeRF)):
+        return False
+    sh = hparams.sh_deg is not None and hparams.pos_dir_dim == 0
+    if sh:
+        if hparams.sh_deg != 2 or split_precision or not (nerf.is_sh2_arch() and bg_nerf.is_sh2_arch()):
+            return False
+    elif hparams.sh_deg is not None or not (_fast_path_ok(nerf, bg_nerf, hparams) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
         return False
     if nerf.xyz_dim != 3 or bg_nerf.xyz_dim != 4 or hparams.container_path is not None or hparams.train_mega_nerf is not None:
         return False

@@ -23,14 +23,15 @@ def _grads(models):
     return {'%s.%s' % (t, k): p.grad.detach().cpu().numpy().copy() for t, m in models for k, p in m.named_parameters()}
 
 
-def test_fused_step_equals_the_stagewise_path_and_the_reference():
-    """render_fgbg_train (the reference's captured random draws): loss, rgb_fine, depth variance, bg_lambda and every parameter
+@pytest.mark.parametrize('name', ['render_fgbg_train', 'render_sh2_256_train'])
+def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
+    """render_fgbg_train / render_sh2_256_train (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0 -- the colour head's adjoint runs in
+    k_sh_head_bwd inside the step) on the reference's captured random draws: loss, rgb_fine, depth variance, bg_lambda and every parameter
     gradient of ONE mnr_train_step call against (i) the stage-by-stage path on the same random numbers -- same kernels for the
     MLP, restated kernels for the ray stages: equal up to the summation order of the atomically accumulated head / embedding
     gradients -- and (ii) the reference's own outputs and gradients."""
     from mega_nerf.rendering import render_rays
     from mega_nerf.training import FusedTrainStep, fused_step_supported
-    name = 'render_fgbg_train'
     g = load(name)
     s = common.SCENE
     rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
@@ -55,6 +56,7 @@ def test_fused_step_equals_the_stagewise_path_and_the_reference():
     np.testing.assert_array_equal(step.rgb[0].cpu().numpy(), ref_out['rgb_fine'])
     np.testing.assert_array_equal(step.depth_variance[0].cpu().numpy(), ref_out['depth_variance_fine'])
     np.testing.assert_array_equal(step.bg_lambda[0].cpu().numpy(), ref_out['bg_lambda_fine'])
+    np.testing.assert_allclose(step.rgb[0].cpu().numpy(), g['res_rgb_fine'], rtol=1e-4, atol=2e-5)
     got = _grads((('fg', nerf2), ('bg', bg2)))
     worst = {k: float(np.abs(got[k] - ref[k]).max()) / max(float(np.abs(ref[k]).max()), 1e-30) for k in ref}
     print({k: '%.1e' % v for k, v in worst.items()})
@@ -184,8 +186,8 @@ def test_generated_random_numbers_are_uniform_and_keyed():
     assert abs(l1 - l2) < 0.05 * max(l1, l2)
 
 
-@pytest.mark.parametrize('split', [False, True])
-@pytest.mark.parametrize('name', ['render_fgbg_eval', 'render_default_samples_eval'])
+@pytest.mark.parametrize('name,split', [('render_fgbg_eval', False), ('render_fgbg_eval', True), ('render_default_samples_eval', False),
+                                        ('render_default_samples_eval', True), ('render_sh2_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches) against the stage-by-stage render -- identical outputs, bit for bit, for the fp32 kernels --
     and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
