@@ -720,6 +720,36 @@ def run_config(args, rank, world, dev, dist):
                 'step_spans_ms': {k: round(sum(d_[k] for d_ in sp) / len(sp), 4) for k in sp[0]}}
             del fs
             fgm.eval(), bgm.eval()
+        if args.mode == 'train' and not args.only_split_extras:
+            # Launch quantisation, measured: the same fp32 step with the background branch of the forward on the plan's side stream, forked
+            # behind the FOREGROUND's coarse pass (MNR_STEP_TWO_STREAMS=2, opt-in: csrc/step.hip).  The foreground's coarse launch -- 1024
+            # workgroups = two whole rounds of the 512 resident slots -- then runs alone: its span is a clean single launch of the dominant
+            # kernel WITHOUT the partial round the background's 69 workgroups add in the default one-stream schedule.
+            from mega_nerf.training import FusedTrainStep
+            fgm.train(), bgm.train()
+            os.environ['MNR_STEP_TWO_STREAMS'] = '2'
+            try:
+                fs2 = FusedTrainStep([(fgm, bgm)], hp, sc, sr, args.rays)
+            finally:
+                os.environ.pop('MNR_STEP_TWO_STREAMS', None)
+            t_2s = timed(lambda: fs2([w['batch']]), args.steps, 3)
+            fs2.profile(8)
+            for _ in range(8):
+                fs2([w['batch']])
+            torch.cuda.synchronize()
+            sp2 = [fs2.kernel_times(i) for i in range(8)]
+            fc_ms = sum(d_['fwd_c'] for d_ in sp2) / len(sp2)
+            fc_fl = args.rays * Nc * FG_FLOP_PER_SAMPLE
+            extras['train_background_branch_on_side_stream'] = {
+                'ms_per_step': t_2s * 1e3, 'rays_per_sec': args.rays / t_2s,
+                'foreground_coarse_launch_alone': {'kernel': 'k_mlp_fwd_multi<fg, bg, true>, %d fg rows = %d workgroups = %.2f rounds of 512 slots' % (
+                    args.rays * Nc, args.rays * Nc // 64, args.rays * Nc / 64 / 512), 'avg_launch_ms': round(fc_ms, 4),
+                    'algorithmic_gflop': round(fc_fl / 1e9, 2), 'achieved_tflops': round(fc_fl / fc_ms / 1e9, 2),
+                    'frac_of_f32_mfma_peak': round(fc_fl / fc_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)},
+                'step_spans_ms': {k: round(sum(d_[k] for d_ in sp2) / len(sp2), 4) for k in sp2[0]},
+                'note': 'opt-in (MNR_STEP_TWO_STREAMS=2); `value` and `roofline` are the one-stream schedule, whose per-launch durations are not overlapped'}
+            del fs2
+            fgm.eval(), bgm.eval()
         if not args.only_split_extras:
             hp_ref = get_opts_base().parse_args([])                         # the reference's default 256 + 512 samples (opts.py:32-35)
             extras['eval_rays_per_sec_256+512_samples'] = args.rays / timed(ev_fn(w['batch'], hp_ref), 5, 1)

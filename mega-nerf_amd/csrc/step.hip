@@ -872,6 +872,7 @@ struct mnr_step_plan {
     // partial round behind each of them (section 3e of DESIGN.md)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_after_coarse = false;   // side-stream schedule: the background branch beside the foreground's fine pass only (see mnr_train_step)
     ~mnr_step_plan() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -1065,6 +1066,8 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
     // the partial rounds weigh less) -- within the box-to-box spread, and it would make every per-launch duration of the forward
     // kernel an overlapped one, so the fp32 step keeps one stream unless MNR_STEP_TWO_STREAMS is set.
     if (C == 1 && !getenv("MNR_STEP_ONE_STREAM") && (cfg->split_precision || getenv("MNR_STEP_TWO_STREAMS"))) {
+        const char *mode = getenv("MNR_STEP_TWO_STREAMS");
+        plan->fork_after_coarse = mode && mode[0] == '2';
         // (failure to get the side stream is not an error: the step then runs its two branches in one launch each, as multi-cell plans do)
         if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess) plan->side = nullptr;
         if (plan->side && (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1203,7 +1206,29 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     };
     int rc = MNR_OK;
     const long CN = D.C * D.N;
-    if (p->side) {
+    if (p->side && p->fork_after_coarse) {
+        // The background branch (coarse pass -> fine samples -> fine pass: 69 + 138 workgroups at the benchmark shape) beside the
+        // foreground's FINE pass only: the foreground's coarse launch (1024 workgroups = two whole rounds of the 512 resident slots)
+        // runs alone and ends without a partial round; the background's workgroups then share the 4.4 rounds of the fine phase
+        // instead of adding a partial round to each of the two passes.
+        hipStream_t s2 = p->side;
+        mark(1, 0);
+        if ((rc = fwd_pass(0, 1, s))) return rc;
+        mark(1, 1);
+        if (hipEventRecord(p->ev_fork, s) != hipSuccess || hipStreamWaitEvent(s2, p->ev_fork, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        if ((rc = fwd_pass(0, 2, s2)) || (rc = mid(CN, 2 * CN, s2)) || (rc = fwd_pass(1, 2, s2))) return rc;
+        if (hipEventRecord(p->ev_join, s2) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+        mark(2, 0);
+        if ((rc = mid(0, CN, s))) return rc;
+        mark(2, 1);
+        mark(3, 0);
+        if ((rc = fwd_pass(1, 1, s))) return rc;
+        if (hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "mnr_train_step: stream join failed: %s", hipGetErrorString(hipGetLastError()));
+        mark(3, 1);
+    } else if (p->side) {
         // two branches side by side: the background's coarse pass -> fine samples -> fine pass on the plan's own stream, forked behind the
         // sample kernel and joined in front of the ray tail; the spans below then time the FOREGROUND launches (the background runs inside them)
         hipStream_t s2 = p->side;
