@@ -2,9 +2,9 @@
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box from the repo root):
 #   kernel trace + stats of the default training bench and of the eval bench, then separate --pmc passes
 #   (HBM counters in their own passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).
-# Output: $OUT (default gpurun_out/r03_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r03
+# Output: $OUT (default gpurun_out/r04_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r04
 set -u
-OUT=${1:-$PWD/gpurun_out/r03_prof}
+OUT=${1:-$PWD/gpurun_out/r04_prof}
 B=$PWD/bench.py
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -42,4 +42,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE 
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
     --kernel-trace -d "$OUT/pmc_sq_split" -o p --output-format csv -- \
     python "$B" $SP > /dev/null 2> "$OUT/pmc_sq_split.err" < /dev/null
+# spherical-harmonics shape (configs/mega-nerf-sh-3: sh_deg 2): kernel trace of the one-call step incl. k_sh_head_bwd
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace_sh2" -o t --output-format csv -- \
+    python "$B" --sh-deg 2 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_sh2_under_rocprof.json" 2> "$OUT/trace_sh2.err" < /dev/null
 ls "$OUT"
