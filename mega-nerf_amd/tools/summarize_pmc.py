@@ -100,6 +100,8 @@ def main():
         sha = subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent)).stdout.strip()
     except Exception:
         sha = None
+    import os
+    sha = sha or os.environ.get('MNR_GIT_HEAD')        # (the GPU box has no .git: the caller passes the revision it snapshotted)
     out['_meta'] = {'git_head_when_summarised': sha, 'source': str(src), 'command': 'tools/collect_profiles.sh; tools/summarize_pmc.py %s %s %s' % (src, dst, rnd),
                     'formulae': 'hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB * 1024; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * GRBM_GUI_ACTIVE / 8); medians over the launches of the pass'}
     (dst / ('%s_pmc_summary.json' % rnd)).write_text(json.dumps(out, indent=1) + '\n')
