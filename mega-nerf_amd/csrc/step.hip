@@ -1300,8 +1300,8 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
                     j.tape_row0 = (long)c * (k ? D.cap_b : D.cap_f) + (pass ? D.N * (k ? D.Sb : D.Nc) : 0);
                     j.n_rows = D.N * S;
                     j.n_units_dev = k ? scal + c : nullptr; j.rows_per_unit = (int)S;
-                    const long nb = (D.N * S + 1023) / 1024;
-                    j.n_blocks = (int)(k ? 32 : (nb > 192 ? 192 : (nb < 1 ? 1 : nb)));
+                    const long nb = (D.N * S + 255) / 256;           // 256 rows per block: 16 iterations of 4 wavefronts x 4 rows
+                    j.n_blocks = (int)(k ? 64 : (nb > 512 ? 512 : (nb < 1 ? 1 : nb)));
                     jobs.push_back(j);
                 }
         for (size_t i = 0; i < jobs.size() && rc == MNR_OK; i += SH_HEAD_MAX_JOBS)
