@@ -439,10 +439,25 @@ def runner_loop(args, dev, value):
             r.train()
         dt = (marks[iters] - marks[first]) / (iters - first)
         fused = r.trainer is not None and r.trainer.fused is not None
+        bare = None
+        if fused:
+            # the bare step on a batch of THIS dataset (random rays of the whole image carry more background segments than the headline
+            # batch: the loop's own cost is the difference to this figure, not to `value`)
+            fs, batch = r.trainer.fused, r.trainer.fused._keep[0]
+            for _ in range(3):
+                fs([batch])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(iters - first):
+                fs([batch])
+            torch.cuda.synchronize()
+            bare = (time.perf_counter() - t1) / (iters - first)
         return {'rays_per_sec': round(args.rays / dt, 1), 'ms_per_iteration': round(dt * 1e3, 4), 'iterations_timed': iters - first,
                 'fraction_of_value': round(args.rays / dt / value, 4), 'one_call_step': bool(fused), 'bg_rays_in_last_batch': marks.get('n_bg'),
+                'bare_step_on_its_last_batch_ms': round(bare * 1e3, 4) if bare else None,
+                'fraction_of_bare_step_on_its_last_batch': round(bare / dt, 4) if bare else None,
                 'what': 'mega_nerf.runner.Runner.train() on a device-resident MemoryDataset of the benchmark camera (%d pixels), batch %d: '
-                        'shuffled batch gathers + mnr_train_step + ExponentialLR + health check every 100 iterations' % (
+                        'row selections gathered inside mnr_train_step (no torch kernel per iteration) + ExponentialLR + health check every 100 iterations' % (
                             int(2.5 * sc['H'] * sc['W']), args.rays)}
     except Exception as e:
         return {'error': '%s: %s' % (type(e).__name__, e)}

@@ -609,6 +609,12 @@ typedef struct mnr_step_batch {      /* one cell's batch: device pointers, read 
     const void *idx;                 /* [n_rays] image indices, int32 or float */
     int32_t idx_is_float;
     const float *target;             /* [n_rays][3] ground-truth colours */
+    /* Gathered form -- a device-resident training set (memory_dataset.py, filesystem_dataset.py chunks): with select != NULL the batch is
+     * rows select[0 .. n_rays) of `rays` / `idx` / `target` (or `target_u8`), which then point at the WHOLE set; the gather that the
+     * reference's DataLoader collation does on the host (runner.py:228-238) happens inside the step's first kernel. */
+    const int64_t *select;           /* [n_rays] row numbers, or NULL */
+    const uint8_t *target_u8;        /* instead of `target`: uint8 colours [rows][3] (dataset_utils.py:30 keeps them as bytes) ... */
+    const float *u8_table;           /* ... converted through this DEVICE table of 256 floats (the CPU's i / 255. values) */
 } mnr_step_batch;
 typedef struct mnr_step_randoms {    /* optional injected uniforms of one cell (parity tests); NULL members are generated */
     const float *fg_perturb, *bg_perturb;            /* [n_rays][coarse], [n_bg][coarse / 2] */

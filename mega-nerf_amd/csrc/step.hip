@@ -203,15 +203,22 @@ __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphe
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
         uint32_t ix = 0;
         if (i < N) {
-            r0 = reinterpret_cast<const float4 *>(b.rays)[2 * i];
-            r1 = reinterpret_cast<const float4 *>(b.rays)[2 * i + 1];
-            ix = reinterpret_cast<const uint32_t *>(b.idx)[i];
+            // the batch itself, or rows select[i] of a device-resident training set (mnr_step_batch::select: the gathers of
+            // memory_dataset.py:47-53 / a DataLoader's collation folded into this copy)
+            const long src = b.select ? (long)b.select[i] : i;
+            r0 = reinterpret_cast<const float4 *>(b.rays)[2 * src];
+            r1 = reinterpret_cast<const float4 *>(b.rays)[2 * src + 1];
+            ix = reinterpret_cast<const uint32_t *>(b.idx)[src];
             reinterpret_cast<float4 *>(rays_o)[2 * (base + i)] = r0;
             reinterpret_cast<float4 *>(rays_o)[2 * (base + i) + 1] = r1;
             idx_o[base + i] = ix;
-            if (b.target) {
-                target_o[3 * (base + i)] = b.target[3 * i]; target_o[3 * (base + i) + 1] = b.target[3 * i + 1];
-                target_o[3 * (base + i) + 2] = b.target[3 * i + 2];
+            if (b.target_u8) {
+                // uint8 colours -> fp32 through the caller's 256-entry table of the CPU's i / 255. values (dataset_utils.py:30)
+                target_o[3 * (base + i)] = b.u8_table[b.target_u8[3 * src]]; target_o[3 * (base + i) + 1] = b.u8_table[b.target_u8[3 * src + 1]];
+                target_o[3 * (base + i) + 2] = b.u8_table[b.target_u8[3 * src + 2]];
+            } else if (b.target) {
+                target_o[3 * (base + i)] = b.target[3 * src]; target_o[3 * (base + i) + 1] = b.target[3 * src + 1];
+                target_o[3 * (base + i) + 2] = b.target[3 * src + 2];
             }
             // rendering.py:33-45, 396-417 (as render.hip::k_ray_setup)
             const float ray[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
@@ -1120,7 +1127,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
     for (int c = 0; c < C; ++c) {
-        MNR_REQUIRE(batches[c].rays && batches[c].idx && batches[c].target, "cell %d: NULL batch pointer", c);
+        MNR_REQUIRE(batches[c].rays && batches[c].idx && (batches[c].target || (batches[c].target_u8 && batches[c].u8_table)), "cell %d: NULL batch pointer", c);
         MNR_REQUIRE(batches[c].idx_is_float == batches[0].idx_is_float, "all cells must pass image indices of the same type");
     }
     if (hipMemsetAsync(ws + L.zero_begin, 0, L.zero_end - L.zero_begin, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(step)");

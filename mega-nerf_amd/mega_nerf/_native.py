@@ -156,7 +156,8 @@ class StepLayout(C.Structure):
 
 class StepBatch(C.Structure):
     """struct mnr_step_batch"""
-    _fields_ = [('rays', C.c_void_p), ('idx', C.c_void_p), ('idx_is_float', C.c_int32), ('target', C.c_void_p)]
+    _fields_ = [('rays', C.c_void_p), ('idx', C.c_void_p), ('idx_is_float', C.c_int32), ('target', C.c_void_p),
+                ('select', C.c_void_p), ('target_u8', C.c_void_p), ('u8_table', C.c_void_p)]
 
 
 class StepRandoms(C.Structure):

@@ -25,6 +25,13 @@ def unit_rgb(rgb_u8: torch.Tensor) -> torch.Tensor:
     return _UNIT[key][rgb_u8.long()]
 
 
+def unit_table(device) -> torch.Tensor:
+    """The 256-entry table behind :func:`unit_rgb` on ``device`` (``mnr_step_batch::u8_table``)."""
+    probe = torch.zeros(1, dtype=torch.uint8, device=device)
+    unit_rgb(probe)
+    return _UNIT[str(probe.device)]
+
+
 def get_rgb_index_mask(metadata: ImageMetadata) -> Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]:
     """Pixels of one image that take part in training (reference dataset_utils.py:8-39): validation images keep
     only their left half; cluster masks select the pixels of this submodule."""
@@ -80,7 +87,16 @@ class MemoryDataset(Dataset):
 
     def batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
         """One shuffled epoch of device-resident batches."""
+        for sel in self.index_batches(batch_size, generator):
+            yield {'rgbs': unit_rgb(self._rgbs[sel]), 'rays': self._rays[sel], 'img_indices': self._img_indices[sel]}
+
+    def index_batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
+        """The same epoch as :meth:`batches`, as row selections (int64, on the device): a consumer that gathers by itself -- the one-call
+        training step (``training.GatheredBatch``) -- pairs them with :meth:`gather_source`."""
         perm = torch.randperm(len(self), generator=generator).to(self._rays.device)
         for i in range(0, len(self), batch_size):
-            sel = perm[i:i + batch_size]
-            yield {'rgbs': unit_rgb(self._rgbs[sel]), 'rays': self._rays[sel], 'img_indices': self._img_indices[sel]}
+            yield perm[i:i + batch_size]
+
+    def gather_source(self):
+        """(rays [P, 8] fp32, img_indices [P] int32, rgbs [P, 3] uint8, u8 -> fp32 table): the resident arrays :meth:`index_batches` selects from."""
+        return self._rays, self._img_indices, self._rgbs, unit_table(self._rays.device)

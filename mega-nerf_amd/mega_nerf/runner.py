@@ -154,7 +154,7 @@ class Runner:
         # whenever the configuration has a fused step, on the SAME optimiser / scheduler objects (their moment tensors become views
         # of the step's buffers, so checkpoints keep the reference's `optimizers` entry); anything else, and ragged last batches,
         # take the stage-by-stage autograd path inside the same trainer.  MNR_RUNNER_AUTOGRAD=1 keeps the reference-shaped loop below.
-        from mega_nerf.training import CellTrainer, fused_step_supported
+        from mega_nerf.training import CellTrainer, GatheredBatch, fused_step_supported
         trainer = None
         if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD') and \
                 fused_step_supported(self.nerf, self.bg_nerf, hp, hp.batch_size):
@@ -193,12 +193,15 @@ class Runner:
             if usable == 0:
                 raise Exception('{} training pixels give fewer batches of {} than there are ranks ({}): nothing to train on'.format(
                     len(dataset), hp.batch_size, world))
-            for dataset_index, item in enumerate(dataset.batches(hp.batch_size, gen)):
+            # the one-call step gathers its batch itself from the resident arrays (training.GatheredBatch): the loop then enqueues NO torch
+            # kernel per iteration; every other path gets materialised batches
+            source = dataset.gather_source() if trainer is not None else None
+            feed = dataset.index_batches(hp.batch_size, gen) if trainer is not None else dataset.batches(hp.batch_size, gen)
+            for dataset_index, item in enumerate(feed):
                 if dataset_index < discard or dataset_index >= usable or dataset_index % world != rank:
                     continue
-                image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 if trainer is not None:
-                    loss_dev, _, _ = trainer.step(item['rays'], image_indices, item['rgbs'])
+                    loss_dev, _, _ = trainer.step_gathered(GatheredBatch(source[0], source[1], source[2], item, source[3]))
                     train_iterations += 1
                     last = train_iterations >= hp.train_iterations
                     if train_iterations % check_every == 0 or last or train_iterations % hp.ckpt_interval == 0:
@@ -219,6 +222,7 @@ class Runner:
                     if last:
                         break
                     continue
+                image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)
                 for key, val in metrics.items():
                     val = float(val.detach()) if isinstance(val, torch.Tensor) else float(val)

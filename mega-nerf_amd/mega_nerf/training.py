@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 from argparse import Namespace
-from typing import Dict, Optional
+from typing import NamedTuple, Dict, Optional
 
 import torch
 from torch import nn
@@ -738,6 +738,17 @@ def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int, split_precision: b
     return (n_rays * (hparams.coarse_samples // 2)) % 64 == 0 and (n_rays * (hparams.fine_samples // 2)) % 64 == 0
 
 
+class GatheredBatch(NamedTuple):
+    """A batch given as rows ``select`` of a device-resident training set (``mnr_step_batch::select``): the step's first kernel does
+    the gather that MemoryDataset.__getitem__ / a DataLoader's collation would do.  ``rays`` [P, 8] fp32, ``img_indices`` [P] int32 or
+    fp32, ``rgbs_u8`` [P, 3] uint8, ``select`` [n_rays] int64, ``u8_table`` [256] fp32 (the CPU's ``i / 255.`` values)."""
+    rays: torch.Tensor
+    img_indices: torch.Tensor
+    rgbs_u8: torch.Tensor
+    select: torch.Tensor
+    u8_table: torch.Tensor
+
+
 class FusedTrainStep:
     """The reference trainer's iteration (runner.py:244-277: render_rays with the training flags, mse_loss, backward, Adam on the
     foreground and the background model, ExponentialLR) for ONE OR SEVERAL independent cells a rank owns, as one call of
@@ -936,7 +947,23 @@ class FusedTrainStep:
         assert len(batches) == nc
         arr = (N.StepBatch * nc)()
         keep = []
-        for i, (rays, idx, rgbs) in enumerate(batches):
+        for i, batch in enumerate(batches):
+            if isinstance(batch, GatheredBatch):
+                N.require_device(batch.rays, 'rays')
+                ok = (batch.rays.dtype == torch.float32 and batch.rays.is_contiguous() and batch.rays.shape[1:] == (8,) and
+                      batch.rgbs_u8.dtype == torch.uint8 and batch.rgbs_u8.is_contiguous() and batch.rgbs_u8.shape == (batch.rays.shape[0], 3) and
+                      batch.img_indices.dtype in (torch.float32, torch.int32) and batch.img_indices.is_contiguous() and
+                      batch.img_indices.numel() == batch.rays.shape[0] and batch.select.dtype == torch.int64 and batch.select.is_contiguous() and
+                      batch.u8_table.dtype == torch.float32 and batch.u8_table.numel() == 256)
+                if not ok or batch.select.numel() != self.n_rays:
+                    raise N.NativeError('GatheredBatch: contiguous fp32 rays [P, 8], uint8 colours [P, 3], int32 / fp32 indices [P], int64 select '
+                                        '[{}] expected'.format(self.n_rays))
+                keep.append(batch)
+                arr[i].rays, arr[i].idx, arr[i].target_u8 = batch.rays.data_ptr(), batch.img_indices.data_ptr(), batch.rgbs_u8.data_ptr()
+                arr[i].select, arr[i].u8_table = batch.select.data_ptr(), batch.u8_table.data_ptr()
+                arr[i].idx_is_float = 1 if batch.img_indices.dtype == torch.float32 else 0
+                continue
+            rays, idx, rgbs = batch
             N.require_device(rays, 'rays')
             rays, rgbs = rays.contiguous().float(), rgbs.contiguous().float()
             if idx.dtype not in (torch.float32, torch.int32):
@@ -1046,23 +1073,36 @@ class CellTrainer:
             self.fused.health()
 
     # ---- the iteration ---------------------------------------------------------------------------------------------------------
+    def step_gathered(self, batch: 'GatheredBatch'):
+        """:meth:`step` for a batch given as rows of a device-resident training set: the fused step gathers them itself (no torch
+        kernels at all in the iteration); anything the fused step does not take is gathered here and goes through :meth:`step`."""
+        n = batch.select.numel()
+        if fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n) and (self.fused is None or n == self.fused.n_rays):
+            return self._fused_call(batch, n)
+        sel = batch.select
+        return self.step(batch.rays[sel], batch.img_indices[sel], batch.u8_table[batch.rgbs_u8[sel].long()])
+
+    def _fused_call(self, batch, n: int):
+        if self.fused is None:
+            self._make_plan(n)
+        self.iteration += 1
+        lrs = [float(o.param_groups[0]['lr']) for o in self.optimizers.values()]
+        assert all(v == lrs[0] for v in lrs), 'foreground and background optimisers on different learning rates'
+        self.fused.step_count = self.iteration - 1
+        loss, n_bg, err = self.fused([batch], lr=lrs[0])
+        self._steps_stale = True
+        for s in self.schedulers.values():
+            s.step()
+        return loss[0], n_bg[0:1], err[0:1]
+
     def step(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
         """One optimisation step.  Returns (loss, n_bg, err): device scalars / 1-element device tensors, no host sync on the
         fused path."""
         n = rays.shape[0]
         fusable = image_indices is not None and fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n)
-        if self.fused is None and fusable:
-            self._make_plan(n)
+        if fusable and (self.fused is None or n == self.fused.n_rays):
+            return self._fused_call((rays, image_indices, rgbs), n)
         self.iteration += 1
-        if fusable and n == self.fused.n_rays:
-            lrs = [float(o.param_groups[0]['lr']) for o in self.optimizers.values()]
-            assert all(v == lrs[0] for v in lrs), 'foreground and background optimisers on different learning rates'
-            self.fused.step_count = self.iteration - 1
-            loss, n_bg, err = self.fused([(rays, image_indices, rgbs)], lr=lrs[0])
-            self._steps_stale = True
-            for s in self.schedulers.values():
-                s.step()
-            return loss[0], n_bg[0:1], err[0:1]
         # stage-by-stage path under autograd, same optimisers (their state tensors are the plan's buffers when one exists)
         self.sync()
         for o in self.optimizers.values():

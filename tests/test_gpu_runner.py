@@ -137,3 +137,25 @@ def test_runner_train_runs_the_fused_step_and_resumes(tmp_path, monkeypatch):
     worst = {k: float((wa[k] - wc[k]).norm()) / max(float((wa[k] - w0[k]).norm()), 1e-30) for k in wa if float((wa[k] - w0[k]).norm()) > 0}
     print('resumed vs uninterrupted:', {k: '%.2e' % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
     assert max(worst.values()) < 0.02, worst
+
+
+def test_sh_config_trains_through_the_fused_step_and_evaluates(tmp_path):
+    """configs/mega-nerf-sh-3 (sh_deg 2, pos_dir_dim 0) end to end through the reference's entry points: train.py runs the one-call step
+    (k_sh_head_bwd inside mnr_train_step), the checkpoint evaluates through eval.py (mnr_render_fwd with the SH epilogue) to the PSNR
+    written after training."""
+    from mega_nerf import eval as ev
+    from mega_nerf.runner import Runner
+    data = _dataset(tmp_path)
+    sh = ['--sh_deg', '2', '--pos_dir_dim', '0', '--batch_size', '512']
+    r = Runner(_hparams(data, tmp_path / 'exp', ['--train_iterations', '30', '--ckpt_interval', '30'] + sh))
+    r.train()
+    assert r.trainer is not None and r.trainer.fused is not None and r.nerf.rgb_dim == 27
+    run0 = tmp_path / 'exp' / '0'
+    m_train = (run0 / 'metrics.txt').read_text()
+    ev.main(_hparams(data, tmp_path / 'exp', ['--ckpt_path', str(run0 / 'models' / '30.pt')] + sh))
+    m_eval = (tmp_path / 'exp' / '1' / 'metrics.txt').read_text()
+
+    def metric(text, key):
+        return float([ln for ln in text.splitlines() if ln.startswith('Average ' + key)][0].split(':')[1])
+    a, b = metric(m_train, 'val/psnr'), metric(m_eval, 'val/psnr')
+    assert abs(a - b) < 0.05 and a > 5.0, (a, b)

@@ -64,12 +64,12 @@ def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
     check_gradients_against_reference(g, (('fg', nerf2), ('bg', bg2)))
 
 
-def _cell(seed, n_rays):
-    """A cell of the benchmark's kind: default fg + bg models with their own weights, their own batch."""
+def _cell(seed, n_rays, sh=False):
+    """A cell of the benchmark's kind: default fg + bg models (``sh``: their sh_deg 2 form) with their own weights, their own batch."""
     from oracle import nerf_oracle as O
     from test_gpu_parity import native_nerf
     s = common.SCENE
-    hp = O.make_hparams(coarse_samples=64, fine_samples=128)
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, **(dict(sh_deg=2, pos_dir_dim=0) if sh else {}))
     fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
     fg = native_nerf(fcfg, common.make_weights(fcfg, s['appearance_count'], seed)).train()
     bg = native_nerf(bcfg, common.make_weights(bcfg, s['appearance_count'], seed + 500)).train()
@@ -80,8 +80,8 @@ def _cell(seed, n_rays):
     return hp, fg, bg, (T(rays), T(idx.astype(np.int32)), T(tgt))
 
 
-@pytest.mark.parametrize('split', [False, True], ids=['f32', 'split'])
-def test_cells_sharing_a_step_are_independent(split):
+@pytest.mark.parametrize('split,sh', [(False, False), (True, False), (False, True)], ids=['f32', 'split', 'f32-sh2'])
+def test_cells_sharing_a_step_are_independent(split, sh):
     """Three cells (own weights, own batches, own optimiser moments) stepped by ONE plan -- their rows side by side in every MLP
     launch -- against the same cells stepped one plan each (cell c of a plan draws its random numbers with key seed + c, so a
     lone plan seeded seed + c sees the same numbers): per-cell loss, rendered colours and gradients of the first step agree --
@@ -95,7 +95,7 @@ def test_cells_sharing_a_step_are_independent(split):
     n_rays, seeds = 128, (11, 12, 13)
 
     def run(groups):
-        cells = [_cell(sd, n_rays) for sd in seeds]
+        cells = [_cell(sd, n_rays, sh) for sd in seeds]
         hpn = Namespace(**vars(cells[0][0]))
         first = {}
         for grp in groups:
@@ -561,3 +561,44 @@ def test_cell_trainer_mixes_fused_and_autograd_steps_on_one_state():
         plain.append(float(loss.detach()))
     np.testing.assert_allclose(got, plain, rtol=1e-4)
     assert abs(tr.optimizers['nerf'].param_groups[0]['lr'] - opts[0].param_groups[0]['lr']) < 1e-15
+
+
+def test_gathered_batch_equals_the_materialised_batch():
+    """mnr_step_batch::select (training.GatheredBatch): the step's first kernel gathers rows of a device-resident training set -- rays,
+    image indices, uint8 colours through the CPU's i / 255. table (dataset_utils.py:30) -- exactly as MemoryDataset.__getitem__ +
+    collation would: colours bit-identical, loss and gradients equal up to the order of atomically accumulated sums, against the same batch
+    materialised with torch indexing."""
+    from mega_nerf.datasets.memory_dataset import unit_rgb, unit_table
+    from mega_nerf.training import FusedTrainStep, GatheredBatch
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    n = g['rays'].shape[0]
+    rng = np.random.default_rng(5)
+    P = 5 * n
+    # a "training set" of P rows that contains the golden batch's rays at shuffled positions, byte colours, int32 indices
+    pos = rng.permutation(P)[:n]
+    rays_all = np.tile(g['rays'], (5, 1)).astype(f32)
+    rays_all[:, :3] += rng.normal(0, 1e-3, (P, 3)).astype(f32)
+    rays_all[pos] = g['rays']
+    idx_all = rng.integers(0, s['appearance_count'], P).astype(np.int32)
+    idx_all[pos] = g['idx'].astype(np.int32)
+    rgb_all = rng.integers(0, 256, (P, 3), dtype=np.uint8)
+    src = (T(rays_all), T(idx_all), T(rgb_all), unit_table(DEV))
+    sel = T(pos.astype(np.int64))
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    out = []
+    for gathered in (True, False):
+        hp, nerf, bg_nerf = native_models('render_fgbg_train')
+        step = FusedTrainStep([(nerf, bg_nerf)], Namespace(**vars(hp)), sc, sr, n, seed=3)
+        batch = GatheredBatch(src[0], src[1], src[2], sel, src[3]) if gathered else (src[0][sel], src[1][sel], unit_rgb(src[2][sel]))
+        loss, n_bg, err = step([batch], optimize=False)
+        torch.cuda.synchronize()
+        assert int(err[0]) == 0 and int(n_bg[0]) > 0
+        out.append((float(loss[0]), step.rgb[0].cpu().numpy().copy(), {k: v.cpu().numpy().copy() for q in range(2) for k, v in
+                                                                         (('%d.%s' % (q, a), b) for a, b in step.grad_views[q].items())}))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)            # (the loss is an atomically accumulated sum over rays)
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    # (gradients: head / embedding sums are accumulated with atomics -- equal up to their order)
+    for k in out[0][2]:
+        sc_ = max(float(np.abs(out[1][2][k]).max()), 1e-30)
+        assert float(np.abs(out[0][2][k] - out[1][2][k]).max()) / sc_ < 2e-5, k
