@@ -303,7 +303,7 @@ def parse_args(argv=None):
     ap.add_argument('--submodules', type=int, default=0, metavar='S',
                     help='strong scaling: a fixed set of S submodules dealt round-robin to the ranks (0 = one private submodule per rank)')
     ap.add_argument('--layer-dim', type=int, default=256,
-                    help='MLP width (256 = the headline Rubble config; 512 = configs/mega-nerf Building: layer-by-layer tiled GEMM path)')
+                    help='MLP width (256 = the headline Rubble config; 512 = configs/mega-nerf Building: training through the tiled per-layer GEMMs, inference through the wavefront-pair kernel)')
     ap.add_argument('--sh-deg', type=int, default=None,
                     help='spherical-harmonics colour head (BASELINE configs[4], configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -821,7 +821,7 @@ def run_config(args, rank, world, dev, dist):
             ach = fl / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'kernel': 'whole step (k_mlp_fwd gather mode: all cells of a pass in one launch; k_route, k_route_combine, render stages), wall clock',
+                    'kernel': 'whole step (k_mlp_fwd%s gather mode: all cells of a pass in one launch; k_route, k_route_combine, render stages), wall clock' % ('_pair' if args.layer_dim == 512 else ''),
                     'routed_rows_per_step': {'fg': r_fg // args.steps, 'bg': r_bg // args.steps,
                                              'unrouted': {'fg': args.rays * (Nc + Nf), 'bg': max(n_bg, 0) * (Nc // 2 + Nf // 2)}},
                     'algorithmic_gflop_per_step': round(fl / 1e9, 1)}
@@ -833,7 +833,9 @@ def run_config(args, rank, world, dev, dist):
             ach = fl * len(work) / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'kernel': 'whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages',
+                    'kernel': ('whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages' if args.mode == 'train' and args.sh_deg is None
+                               else 'whole step (one-call step / render of the SH pair), wall clock incl. render stages' if args.sh_deg is not None
+                               else 'whole step (k_mlp_fwd_pair: 512-wide foreground, two wavefronts per SIMD; k_mlp_fwd background), wall clock incl. render stages'),
                     'algorithmic_gflop_per_step': round(fl * len(work) / 1e9, 1)}
         elif not args.container and (Nc, Nf) == (64, 128):
             if args.mode == 'train':

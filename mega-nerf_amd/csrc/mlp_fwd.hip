@@ -11,6 +11,8 @@
 // 8 trunk layers (+skip), sigma head (VALU dot + cross-lane add), xyz_encoding_final, dir/appearance
 // layer, rgb head, sigmoid / shifted softplus -- nothing but the inputs (<= 36 B) and the 16 B result
 // touches HBM.
+#include <stdlib.h>
+
 #include "mlp_fwd_kernels.h"
 
 #ifdef MNR_PROBE_TRAIN      // codegen probes (not part of the library): -DMNR_PROBE_TRAIN=1 the foreground training kernel,
@@ -26,6 +28,9 @@ template __global__ void mnr::k_mlp_fwd<mnr::MlpCfg<3, 12, 4, 48, 256, 8, 16, 3,
 using namespace mnr;
 
 namespace mnr {
+// mlp_fwd_pair.hip: 512-wide default architectures, two wavefronts per SIMD (a wavefront pair splits the output features)
+int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                              const mnr_mlp_cell *cells, int n_cells);
 // mlp_fwd_train.hip: launches the tape-writing instantiation for this architecture (MNR_E_UNSUPPORTED if there is none)
 int mlp_forward_train_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                                float *tape, long tape_rows, long tape_row0);
@@ -121,7 +126,12 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
     // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
     MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)
     MNR_TRY_T(4, 12, 4, 48, 256, 8, 16, 3, 32)
-    // configs/mega-nerf Building: 512 channels
+    // configs/mega-nerf Building: 512 channels -- the wavefront-pair kernel (two wavefronts per SIMD); MNR_NO_PAIR_KERNEL=1 keeps the
+    // one-wavefront-per-SIMD instantiations below (comparison runs)
+    if (d->layer_dim == 512 && !getenv("MNR_NO_PAIR_KERNEL")) {
+        const int prc = mlp_forward_pair_dispatch(m, packed_dev, d, io, s, cells, n_cells);
+        if (prc != MNR_E_UNSUPPORTED) return prc;
+    }
     MNR_TRY(3, 12, 4, 48, 512, 8, 16, 3)
     MNR_TRY(4, 12, 4, 48, 512, 8, 16, 3)
 #ifdef MNR_ALL_VARIANTS

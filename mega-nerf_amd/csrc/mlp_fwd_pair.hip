@@ -1,0 +1,308 @@
+// mlp_fwd_pair.hip -- register-chained forward for layer_dim 512 (configs/mega-nerf Building, README "Larger models") with TWO wavefronts
+// per SIMD: a wavefront PAIR owns 16 samples and splits the 512 output features of every layer between its halves.
+//
+// Why: with one wavefront owning all 512 features of its 16 samples (k_mlp_fwd<MlpCfg<.., 512, ..>>) a lane holds 128 input + 128
+// accumulator registers -- one wavefront per SIMD, nothing to hide its LDS waits and chunk barriers behind (0.63 of the fp32-MFMA peak).
+// Here a lane holds the 128 input registers of the FULL previous layer but only the 64 accumulators of its half of the output blocks:
+// ~230 VGPRs, two wavefronts per SIMD (one 8-wavefront workgroup per CU), the shape the 256-wide kernel runs at 0.80-0.83.  By the K
+// ordering of mlp_layout.h a half's accumulator registers are a contiguous half of the next layer's B-operand registers, lane for lane,
+// so the exchange between the halves of a pair is a lane-wise copy through LDS: 16 KB per wavefront and layer against 2 048 MFMAs.
+// Same packed image, same chunk stream (every wavefront reads its half of each group's A fragments), same aux block, same numerics as
+// the one-wavefront kernel up to the order in which nothing is summed differently: a feature's K loop is the same fmaf chain.
+//
+// Inference only (plain launches and the routed gather mode of merged containers); training of 512-wide models stays on the tiled
+// per-layer GEMMs (csrc/tgemm.hip).
+#include "lds_asm.h"
+#include "mlp_fwd_kernels.h"
+
+namespace mnr {
+
+constexpr int PAIR_THREADS = 512;
+constexpr int PAIR_XBUF_F4 = 8 * 512;                                   // exchange space: 8 wavefronts x 32 registers x 64 lanes (float4 units)
+constexpr size_t PAIR_LDS_BYTES = (size_t)2 * CHUNK_BYTES + (size_t)PAIR_XBUF_F4 * 16 + 4 * 16 * 4 * sizeof(float);
+
+struct WStream8 {      // WStream (mlp_device.h) for a 512-thread workgroup
+    const float4 *g;
+    float4 *lds;
+    int cur;
+    __device__ __forceinline__ void issue() {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;
+        const unsigned lane_off = threadIdx.x * 16u;
+#pragma unroll
+        for (int i = 0; i < CHUNK_F4 / PAIR_THREADS; ++i) {
+            unsigned lo = lane_off;
+            asm("" : "+v"(lo));
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + i * PAIR_THREADS)) + lo),
+                                             (lds_void_t *)(dst + i * PAIR_THREADS), 16, 0, 0);
+        }
+        g += CHUNK_F4;
+    }
+    __device__ __forceinline__ void next_chunk() {
+        __syncthreads();
+        cur ^= 1;
+        issue();
+    }
+};
+
+// One K segment for one half of the output blocks: NOBH blocks starting at block ob0 of the layer's NOB_FULL.
+// The A fragments are read with inline-asm ds_read_b128 and hand-counted waits (lds_asm.h), two batches of four blocks in flight:
+// left to the compiler, all 16 reads of a group are hoisted in front of its MFMAs (64 registers on top of 128 inputs + 64 accumulators:
+// 31-78 spilled VGPRs), and scheduling fences / group barriers either spilled more or did not finish compiling.
+template <int NOBH, int NOB_FULL, int NG, int GPC, int G0, int NB>
+__device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const float (&b)[NB], WStream8 &st, int lane, int ob0) {
+    static_assert(NB >= 4 * NG, "B register array too small");
+    static_assert(NOBH % 8 == 0, "blocks per half: whole pairs of four-block batches");
+    static_for<0, NG>([&](auto gi) {
+        constexpr int g = G0 + decltype(gi)::value;
+        constexpr int gl = decltype(gi)::value;
+        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
+        const unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ((g % GPC) * NOB_FULL + ob0) * 64 + lane);
+        floatx4 a0[4], a1[4];
+        auto load = [&](floatx4 (&a)[4], auto batch) {
+            constexpr int o0 = decltype(batch)::value * 4;
+            a[0] = lds_ld4<(o0 + 0) * 1024>(addr); a[1] = lds_ld4<(o0 + 1) * 1024>(addr);
+            a[2] = lds_ld4<(o0 + 2) * 1024>(addr); a[3] = lds_ld4<(o0 + 3) * 1024>(addr);
+        };
+        auto mfmas = [&](floatx4 (&a)[4], auto batch) {
+            constexpr int o0 = decltype(batch)::value * 4;
+            pin(a[0]); pin(a[1]); pin(a[2]); pin(a[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], b[4 * gl + k], acc[o0 + ob], 0, 0, 0);
+        };
+        constexpr int NBATCH = NOBH / 4;
+        load(a0, std::integral_constant<int, 0>{});
+        load(a1, std::integral_constant<int, 1>{});
+        static_for<0, NBATCH / 2>([&](auto pc) {
+            constexpr int bp = decltype(pc)::value * 2;                 // batches bp (in a0) and bp + 1 (in a1)
+            wait_lgkm<4>();
+            mfmas(a0, std::integral_constant<int, bp>{});
+            if constexpr (bp + 2 < NBATCH) { load(a0, std::integral_constant<int, bp + 2>{}); wait_lgkm<4>(); }
+            else wait_lgkm<0>();
+            mfmas(a1, std::integral_constant<int, bp + 1>{});
+            if constexpr (bp + 3 < NBATCH) load(a1, std::integral_constant<int, bp + 3>{});
+        });
+    });
+}
+
+// The halves of a pair swap their NH output registers (lane for lane) through LDS in two rounds of NH / 2 registers:
+// h[own0 .. own0 + NH) = own, h[oth0 .. oth0 + NH) = the partner's.
+template <int NH, int NHF>
+__device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[NH], float4 *xb, int wave, int lane, bool upper) {
+    static_assert(NH % 8 == 0 && NH <= 64 && NHF >= 2 * NH, "exchange in two rounds of at most 32 registers");
+    constexpr int Q = NH / 8;                 // float4 pieces per round
+    float4 *mine = xb + wave * 512 + lane, *theirs = xb + (wave ^ 4) * 512 + lane;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = 4 * (round * Q + q);
+            mine[q * 64] = make_float4(o[i], o[i + 1], o[i + 2], o[i + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = 4 * (round * Q + q);
+            const float4 v = theirs[q * 64];
+            // `upper` is wave-uniform but not a compile-time constant: every h register is written once, by a VALUE select between
+            // the own and the partner's number (an `if` around the two stores is turned into one store to a selected ADDRESS, which
+            // sends the whole array to scratch)
+            h[i] = upper ? v.x : o[i];          h[NH + i] = upper ? o[i] : v.x;
+            h[i + 1] = upper ? v.y : o[i + 1];  h[NH + i + 1] = upper ? o[i + 1] : v.y;
+            h[i + 2] = upper ? v.z : o[i + 2];  h[NH + i + 2] = upper ? o[i + 2] : v.z;
+            h[i + 3] = upper ? v.w : o[i + 3];  h[NH + i + 3] = upper ? o[i + 3] : v.w;
+        }
+        __syncthreads();
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) {
+    static_assert(C::TILE == 16 && C::W == 512 && C::HAS_FINAL && C::RGB == 3, "pair kernel: the 512-wide default architectures");
+    constexpr int P = C::P, H = C::H, NOB = C::NOB, NOBH = NOB / 2, HH = H / 2;          // H = 128 input registers, HH = 64 own outputs
+    constexpr int NOB2 = C::NOB2, NOB2H = NOB2 / 2, H2 = C::H2, H2H = H2 / 2;             // dir_a: 256 outputs -> 64 registers, 32 own
+    extern __shared__ float4 lds_ring[];
+    float4 *xb = lds_ring + 2 * CHUNK_F4;
+    float *rsum = reinterpret_cast<float *>(xb + PAIR_XBUF_F4);                          // [4 pairs][16 rows][4]
+
+    const mnr_mlp_io &io = a.io;
+    const float4 *chunks = a.chunks;
+    const float *aux = a.aux, *emb_a = a.emb_a;
+    const int32_t *row_index = io.row_index;
+    float *outp = io.out;
+    long n_rows, blk = blockIdx.x;
+    if (a.cells) {          // routed evaluation: workgroups laid out cell after cell (see mlp_fwd_body)
+        int c = 0;
+        n_rows = 0;
+        for (; c < a.n_cells; ++c) {
+            const long n = *a.cells[c].count, t = (n + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+            if (blk < t) { n_rows = n; break; }
+            blk -= t;
+        }
+        if (c == a.n_cells) return;
+        const mnr_mlp_cell cell = a.cells[c];
+        chunks = reinterpret_cast<const float4 *>(cell.packed_dev);
+        aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(cell.packed_dev) + a.aux_byte_off);
+        emb_a = cell.embedding_a;
+        row_index = cell.row_index;
+        outp = cell.out;
+    } else {
+        n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
+        if (blk * C::ROWS_PER_WG >= n_rows) return;
+    }
+    aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(aux)));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & 3, half = wave >> 2;            // waves w and w + 4 share their 16 rows
+    const int part = lane / 16;
+    const long lrow = (blk * 4 + pair) * 16 + (lane % 16);
+    const bool valid = lrow < n_rows;
+    const long rc = valid ? lrow : n_rows - 1;
+    const long src = row_index ? (long)row_index[rc] : rc;
+    const long ray = src / io.rows_per_ray;
+
+    WStream8 st;
+    st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));
+    st.lds = lds_ring;
+    st.cur = 1;
+    st.issue();
+
+    float h[H];
+    floatx4 acc[NOBH];
+    const int ob0 = half * NOBH;
+    // ---- trunk -------------------------------------------------------------------------------------
+    static_for<0, C::NL>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        init_acc<NOBH, 4>(acc, aux + a.bias_off[l] + part * H + half * HH);
+        st.next_chunk();
+        if constexpr (l == 0 || ((C::SKIP >> l) & 1)) {
+            // the positional encoding is evaluated where it is consumed (layer 0 and the skip layer) instead of living in 20 registers
+            // across the layers in between: the kernel sits at its 256-register budget
+            float x[C::XYZ];
+#pragma unroll
+            for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
+            float ex[C::EX];
+            embed<C::XYZ, C::LX, P>(ex, x, part);
+            run_segment_half<NOBH, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane, ob0);
+            if constexpr (l > 0) run_segment_half<NOBH, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane, ob0);
+        } else {
+            run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0);
+        }
+        float o[HH];
+        acc_to_regs<NOBH, 4, true>(o, acc);
+        pair_exchange<HH>(h, o, xb, wave, lane, half != 0);
+    });
+
+    // ---- sigma head (both halves hold the full activation: computed twice, written once) ------------
+    float sigma;
+    {
+        const float *ws = aux + a.sigma_off;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < H / 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(ws + part * H + 4 * q);
+            s = fmaf(h[4 * q + 0], w4.x, s); s = fmaf(h[4 * q + 1], w4.y, s);
+            s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
+        }
+        s = reduce_parts<P>(s) + ws[P * H];
+        if (io.sigma_noise) s += io.sigma_noise[src];
+        sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
+    }
+    if (io.sigma_only) {
+        if (valid && part == 0 && half == 0) outp[lrow * io.out_stride] = sigma;
+        return;
+    }
+
+    // ---- xyz_encoding_final (no activation) -----------------------------------------------------------
+    {
+        init_acc<NOBH, 4>(acc, aux + a.bias_off[C::NL] + part * H + half * HH);
+        st.next_chunk();
+        run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0);
+        float o[HH];
+        acc_to_regs<NOBH, 4, false>(o, acc);
+        pair_exchange<HH>(h, o, xb, wave, lane, half != 0);
+    }
+
+    // ---- dir_a_encoding: 256 outputs, 128 per half --------------------------------------------------------
+    floatx4 acc2[NOB2H];
+    init_acc<NOB2H, 4>(acc2, aux + a.bias_off[C::NL + 1] + part * H2 + half * H2H);
+    st.next_chunk();
+    run_segment_half<NOB2H, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane, half * NOB2H);
+    if constexpr (C::ED > 0) {
+        float dv[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
+        float ed[C::ED];
+        embed<3, C::LD, P>(ed, dv, part);
+        run_segment_half<NOB2H, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane, half * NOB2H);
+    }
+    if constexpr (C::AP > 0) {
+        long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
+                                   : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
+        idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);
+        const float *ea = emb_a + idx * C::APP + part * (C::APP / P);
+        float ap[C::AP];
+#pragma unroll
+        for (int i = 0; i < C::AP; ++i) ap[i] = (i < C::APP / P) ? ea[i] : 0.f;
+        run_segment_half<NOB2H, NOB2, C::AP / 4, C::GPC2, H / 4 + C::ED / 4>(acc2, ap, st, lane, half * NOB2H);
+    }
+    float dreg[H2H];
+    acc_to_regs<NOB2H, 4, true>(dreg, acc2);
+
+    // ---- rgb head: each half sums its 128 features; the upper half hands its partial sums over through LDS ----
+    const float *wr = aux + a.rgb_off;
+    float rgbp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < H2H / 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wr + (c * P + part) * H2 + half * H2H + 4 * q);
+            s = fmaf(dreg[4 * q + 0], w4.x, s); s = fmaf(dreg[4 * q + 1], w4.y, s);
+            s = fmaf(dreg[4 * q + 2], w4.z, s); s = fmaf(dreg[4 * q + 3], w4.w, s);
+        }
+        rgbp[c] = reduce_parts<P>(s);
+    }
+    float *rs = rsum + (pair * 16 + (lane % 16)) * 4;
+    if (half == 1 && part == 0) { rs[0] = rgbp[0]; rs[1] = rgbp[1]; rs[2] = rgbp[2]; }
+    __syncthreads();
+    if (!(valid && part == 0 && half == 0)) return;
+    float *o = outp + lrow * io.out_stride;
+    o[0] = sigmoidf_(rgbp[0] + rs[0] + wr[3 * P * H2 + 0]);
+    o[1] = sigmoidf_(rgbp[1] + rs[1] + wr[3 * P * H2 + 1]);
+    o[2] = sigmoidf_(rgbp[2] + rs[2] + wr[3 * P * H2 + 2]);
+    o[3] = sigma;
+}
+
+template <class C>
+static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t stream,
+                           const mnr_mlp_cell *cells, int n_cells) {
+    MlpFwdArgs a;
+    const int rc = fill_fwd_args<C>(a, m, packed, d, io, nullptr, 0, 0, cells, n_cells);
+    if (rc != MNR_OK) return rc;
+    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
+    if (nwg <= 0) return MNR_OK;
+    if (nwg > 0x7fffffffL) return set_err(MNR_E_INVALID, "too many rows for one MLP launch");
+    static bool lds_enabled_dev[MAX_DEVICES] = {};
+    bool &lds_enabled = lds_enabled_dev[device_slot()];
+    if (!lds_enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_fwd_pair<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES) != hipSuccess)
+            return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_mlp_fwd_pair): %s", hipGetErrorString(hipGetLastError()));
+        lds_enabled = true;
+    }
+    hipLaunchKernelGGL((k_mlp_fwd_pair<C>), dim3((unsigned)nwg), dim3(PAIR_THREADS), PAIR_LDS_BYTES, stream, a);
+    return check_launch("k_mlp_fwd_pair");
+}
+
+// inference launch of a 512-wide default architecture through the pair kernel; MNR_E_UNSUPPORTED for anything else
+int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                              const mnr_mlp_cell *cells, int n_cells) {
+    const bool arch = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 512 && d->layers == 8 &&
+                      d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
+    if (arch && d->xyz_dim == 3) return launch_fwd_pair<MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>>(m, packed_dev, d, io, s, cells, n_cells);
+    if (arch && d->xyz_dim == 4) return launch_fwd_pair<MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>>(m, packed_dev, d, io, s, cells, n_cells);
+    return set_err(MNR_E_UNSUPPORTED, "the pair kernel covers the 512-wide default fg / bg architectures");
+}
+
+}  // namespace mnr

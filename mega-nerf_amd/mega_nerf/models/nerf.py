@@ -248,9 +248,12 @@ class NeRF(nn.Module):
         """Enqueue one fused MLP launch on the current stream (no host sync).  All tensors are raw device
         buffers; see ``mnr_mlp_io`` in include/mnr_api.h for the row/ray addressing."""
         # layer_dim >= 512: once a launch fills the chip the tiled per-layer GEMMs (csrc/tgemm.hip, 118 TFLOP/s at 196 608
-        # rows of the 8 x 512 model) beat the register-chained kernel (100: one wave per SIMD, nothing hides its weight stream)
+        # rows of the 8 x 512 model) beat the one-wavefront-per-SIMD register-chained kernel (100).  The 512-wide DEFAULT architectures
+        # (Building) have the wavefront-pair kernel (csrc/mlp_fwd_pair.hip: two wavefronts per SIMD, whole render at 0.82 of the
+        # fp32-MFMA peak against 0.70 through the tiled GEMMs) and stay on the fused path at every launch size.
         wide = (self.prefer_wide_layerwise and self.layer_dim >= 512 and self.layer_dim % 256 == 0 and n_units_dev is None and
-                n_rows >= 65536 and os.environ.get('MNR_NO_TGEMM') is None)
+                n_rows >= 65536 and os.environ.get('MNR_NO_TGEMM') is None and
+                not (self.is_wide_default_arch() and os.environ.get('MNR_NO_PAIR_KERNEL') is None))
         if wide or not self.fused_supported():
             return self._evaluate_layerwise(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, n_rows, out,
                                             sigma_noise, sigma_only, apply_sh_deg, n_units_dev, rows_per_unit)
@@ -319,6 +322,13 @@ class NeRF(nn.Module):
         frequency bands, 48-d appearance, skip at 4, rgb head) -- the pair the multi-segment launches are instantiated for."""
         return (self.xyz_dim in (3, 4) and self.pos_xyz_dim == 12 and self.pos_dir_dim == 4 and self.layers == 8 and
                 list(self.skip_layers) == [4] and self.layer_dim == 256 and self.appearance_dim == 48 and self.rgb_dim == 3 and
+                self.embedding_a is not None and self.affine is None and self.mfma_tile in (0, 16))
+
+    def is_wide_default_arch(self) -> bool:
+        """True for the default architectures at 512 channels (README "Larger models", configs/mega-nerf Building): the shapes
+        k_mlp_fwd_pair is instantiated for."""
+        return (self.xyz_dim in (3, 4) and self.pos_xyz_dim == 12 and self.pos_dir_dim == 4 and self.layers == 8 and
+                list(self.skip_layers) == [4] and self.layer_dim == 512 and self.appearance_dim == 48 and self.rgb_dim == 3 and
                 self.embedding_a is not None and self.affine is None and self.mfma_tile in (0, 16))
 
     def is_sh2_arch(self) -> bool:
