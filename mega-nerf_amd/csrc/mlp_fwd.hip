@@ -30,7 +30,7 @@ using namespace mnr;
 namespace mnr {
 // mlp_fwd_pair.hip: 512-wide default architectures, two wavefronts per SIMD (a wavefront pair splits the output features)
 int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
-                              const mnr_mlp_cell *cells, int n_cells);
+                              const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0);
 // mlp_fwd_train.hip: launches the tape-writing instantiation for this architecture (MNR_E_UNSUPPORTED if there is none)
 int mlp_forward_train_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                                float *tape, long tape_rows, long tape_row0);
@@ -58,6 +58,9 @@ extern "C" int mnr_fused_supported(const mnr_model_desc *d) {
 extern "C" int mnr_fused_train_supported(const mnr_model_desc *d) {
     ModelLayout m;
     if (layout_from_desc(d, m) != MNR_OK) return 0;
+    // 512-wide models have a tape-writing FORWARD (k_mlp_fwd_pair<.., true>: activation planes for the tiled per-layer backward of
+    // models/layerwise.py) but no register-chained data-gradient chain: not "fused training" in the sense of this query
+    if (d->layer_dim > 256) return 0;
     mnr_mlp_io io{};
     float dummy;
     io.xyz = &dummy; io.out = &dummy; io.dir = &dummy; io.idx = &dummy; io.rows_per_ray = 1; io.n_rows = 0;
@@ -122,14 +125,18 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
     MNR_TRY(3, 12, 4, 48, 256, 8, 16, 3)
     MNR_TRY(4, 12, 4, 48, 256, 8, 16, 3)
     // training variants (forward pass that also writes the activation tape): instantiated in mlp_fwd_train.hip
+    if (tape && d->layer_dim == 512) {       // activation planes only (no sign-bit / encoding planes): the forward of the tiled training path
+        const int prc = mlp_forward_pair_dispatch(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0);
+        if (prc != MNR_E_UNSUPPORTED) return prc;
+    }
     if (tape) return mlp_forward_train_dispatch(m, packed_dev, d, io, s, tape, tape_rows, tape_row0);
     // 32-samples-per-wave variants (v_mfma_f32_32x32x2_f32, one workgroup per CU)
     MNR_TRY_T(3, 12, 4, 48, 256, 8, 16, 3, 32)
     MNR_TRY_T(4, 12, 4, 48, 256, 8, 16, 3, 32)
     // configs/mega-nerf Building: 512 channels -- the wavefront-pair kernel (two wavefronts per SIMD); MNR_NO_PAIR_KERNEL=1 keeps the
     // one-wavefront-per-SIMD instantiations below (comparison runs)
-    if (d->layer_dim == 512 && !getenv("MNR_NO_PAIR_KERNEL")) {
-        const int prc = mlp_forward_pair_dispatch(m, packed_dev, d, io, s, cells, n_cells);
+    if (d->layer_dim == 512 && !tape && !getenv("MNR_NO_PAIR_KERNEL")) {
+        const int prc = mlp_forward_pair_dispatch(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
         if (prc != MNR_E_UNSUPPORTED) return prc;
     }
     MNR_TRY(3, 12, 4, 48, 512, 8, 16, 3)

@@ -49,14 +49,16 @@ struct WStream8 {      // WStream (mlp_device.h) for a 512-thread workgroup
 // The A fragments are read with inline-asm ds_read_b128 and hand-counted waits (lds_asm.h), two batches of four blocks in flight:
 // left to the compiler, all 16 reads of a group are hoisted in front of its MFMAs (64 registers on top of 128 inputs + 64 accumulators:
 // 31-78 spilled VGPRs), and scheduling fences / group barriers either spilled more or did not finish compiling.
-template <int NOBH, int NOB_FULL, int NG, int GPC, int G0, int NB>
-__device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const float (&b)[NB], WStream8 &st, int lane, int ob0) {
+struct NoHook { template <class G> __device__ __forceinline__ void operator()(G) const {} };
+
+template <int NOBH, int NOB_FULL, int NG, int GPC, int G0, int NB, class Hook = NoHook>
+__device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const float (&b)[NB], WStream8 &st, int lane, int ob0, Hook hook = Hook()) {
     static_assert(NB >= 4 * NG, "B register array too small");
     static_assert(NOBH % 8 == 0, "blocks per half: whole pairs of four-block batches");
     static_for<0, NG>([&](auto gi) {
         constexpr int g = G0 + decltype(gi)::value;
         constexpr int gl = decltype(gi)::value;
-        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
+        if constexpr (g % GPC == 0 && g > 0) { st.next_chunk(); hook(std::integral_constant<int, g>{}); }      // (hook: right behind a chunk barrier)
         const unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ((g % GPC) * NOB_FULL + ob0) * 64 + lane);
         floatx4 a0[4], a1[4];
         auto load = [&](floatx4 (&a)[4], auto batch) {
@@ -118,7 +120,22 @@ __device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[
     }
 }
 
-template <class C>
+// TRAIN: additionally writes the activation planes of the tape (TapeLayout act[l], fin, dact -- dense row-major [rows][width], what the
+// tiled data-gradient / weight-gradient kernels of the layer-by-layer training path read: models/layerwise.py); every half stores the
+// 256 (128) columns it computed.  The stores of a layer's output are issued from the NEXT layer's input registers, a quarter behind
+// each of that layer's first four chunk barriers: a barrier drains vmcnt, so a store issued in front of one (and the exchange is four
+// barriers) would stall the wavefront for a write round trip.
+template <int Q0, int NQ, int NH2>
+__device__ __forceinline__ void pair_store_own(const float *plane, unsigned row_byte_off, const float (&h)[NH2], bool upper) {
+    constexpr int NH = NH2 / 2;
+    static_for<Q0, Q0 + NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, i = 4 * q;
+        gstore4<64 * q>(plane, row_byte_off, make_float4(upper ? h[NH + i] : h[i], upper ? h[NH + i + 1] : h[i + 1],
+                                                         upper ? h[NH + i + 2] : h[i + 2], upper ? h[NH + i + 3] : h[i + 3]));
+    });
+}
+
+template <class C, bool TRAIN>
 __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) {
     static_assert(C::TILE == 16 && C::W == 512 && C::HAS_FINAL && C::RGB == 3, "pair kernel: the 512-wide default architectures");
     constexpr int P = C::P, H = C::H, NOB = C::NOB, NOBH = NOB / 2, HH = H / 2;          // H = 128 input registers, HH = 64 own outputs
@@ -161,6 +178,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     const long rc = valid ? lrow : n_rows - 1;
     const long src = row_index ? (long)row_index[rc] : rc;
     const long ray = src / io.rows_per_ray;
+    // training: byte offset of this lane's first own column inside a 512-wide (256-wide) plane row
+    const unsigned trow = (unsigned)((blk * 4 + pair) * 16 + (lane % 16) + a.tape_row0);
+    const unsigned off512 = (trow * 512u + 4u * (unsigned)part) * 4u + 1024u * (unsigned)half;
+    const unsigned off256 = (trow * 256u + 4u * (unsigned)part) * 4u + 512u * (unsigned)half;
+    const bool upper = half != 0;
 
     WStream8 st;
     st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));
@@ -176,6 +198,14 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         constexpr int l = decltype(lc)::value;
         init_acc<NOBH, 4>(acc, aux + a.bias_off[l] + part * H + half * HH);
         st.next_chunk();
+        // deferred tape stores of layer l - 1 (its output = this layer's input registers): pieces behind chunk barriers 0 .. 3
+        auto hook = [&](auto gc) {
+            if constexpr (TRAIN && l > 0) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, off512, h, upper); }
+            }
+        };
+        hook(std::integral_constant<int, 0>{});
         if constexpr (l == 0 || ((C::SKIP >> l) & 1)) {
             // the positional encoding is evaluated where it is consumed (layer 0 and the skip layer) instead of living in 20 registers
             // across the layers in between: the kernel sits at its 256-register budget
@@ -184,14 +214,14 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
             for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
             float ex[C::EX];
             embed<C::XYZ, C::LX, P>(ex, x, part);
-            run_segment_half<NOBH, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane, ob0);
-            if constexpr (l > 0) run_segment_half<NOBH, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane, ob0);
+            run_segment_half<NOBH, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane, ob0, hook);
+            if constexpr (l > 0) run_segment_half<NOBH, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane, ob0, hook);
         } else {
-            run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0);
+            run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0, hook);
         }
         float o[HH];
         acc_to_regs<NOBH, 4, true>(o, acc);
-        pair_exchange<HH>(h, o, xb, wave, lane, half != 0);
+        pair_exchange<HH>(h, o, xb, wave, lane, upper);
     });
 
     // ---- sigma head (both halves hold the full activation: computed twice, written once) ------------
@@ -218,17 +248,31 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     {
         init_acc<NOBH, 4>(acc, aux + a.bias_off[C::NL] + part * H + half * HH);
         st.next_chunk();
-        run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0);
+        auto hook = [&](auto gc) {
+            if constexpr (TRAIN) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, off512, h, upper); }
+            }
+        };
+        hook(std::integral_constant<int, 0>{});
+        run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0, hook);
         float o[HH];
         acc_to_regs<NOBH, 4, false>(o, acc);
-        pair_exchange<HH>(h, o, xb, wave, lane, half != 0);
+        pair_exchange<HH>(h, o, xb, wave, lane, upper);
     }
 
     // ---- dir_a_encoding: 256 outputs, 128 per half --------------------------------------------------------
     floatx4 acc2[NOB2H];
     init_acc<NOB2H, 4>(acc2, aux + a.bias_off[C::NL + 1] + part * H2 + half * H2H);
     st.next_chunk();
-    run_segment_half<NOB2H, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane, half * NOB2H);
+    auto hook_fin = [&](auto gc) {              // (two groups per chunk here: a barrier every other group)
+        if constexpr (TRAIN) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g % 2 == 0 && g < 8) { if (valid) pair_store_own<2 * g, 4>(a.tape + a.tl.fin_off * a.tape_rows, off512, h, upper); }
+        }
+    };
+    hook_fin(std::integral_constant<int, 0>{});
+    run_segment_half<NOB2H, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane, half * NOB2H, hook_fin);
     if constexpr (C::ED > 0) {
         float dv[3];
 #pragma unroll
@@ -249,6 +293,14 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     }
     float dreg[H2H];
     acc_to_regs<NOB2H, 4, true>(dreg, acc2);
+    if constexpr (TRAIN) {
+        if (valid) {
+            static_for<0, H2H / 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                gstore4<64 * q>(a.tape + a.tl.dact_off * a.tape_rows, off256, make_float4(dreg[4 * q], dreg[4 * q + 1], dreg[4 * q + 2], dreg[4 * q + 3]));
+            });
+        }
+    }
 
     // ---- rgb head: each half sums its 128 features; the upper half hands its partial sums over through LDS ----
     const float *wr = aux + a.rgb_off;
@@ -275,11 +327,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     o[3] = sigma;
 }
 
-template <class C>
+template <class C, bool TRAIN>
 static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t stream,
-                           const mnr_mlp_cell *cells, int n_cells) {
+                           const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0) {
     MlpFwdArgs a;
-    const int rc = fill_fwd_args<C>(a, m, packed, d, io, nullptr, 0, 0, cells, n_cells);
+    const int rc = fill_fwd_args<C>(a, m, packed, d, io, tape, tape_rows, tape_row0, cells, n_cells);
     if (rc != MNR_OK) return rc;
     const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
@@ -287,21 +339,26 @@ static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_m
     static bool lds_enabled_dev[MAX_DEVICES] = {};
     bool &lds_enabled = lds_enabled_dev[device_slot()];
     if (!lds_enabled) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_fwd_pair<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_fwd_pair<C, TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS_BYTES) != hipSuccess)
             return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(k_mlp_fwd_pair): %s", hipGetErrorString(hipGetLastError()));
         lds_enabled = true;
     }
-    hipLaunchKernelGGL((k_mlp_fwd_pair<C>), dim3((unsigned)nwg), dim3(PAIR_THREADS), PAIR_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_mlp_fwd_pair<C, TRAIN>), dim3((unsigned)nwg), dim3(PAIR_THREADS), PAIR_LDS_BYTES, stream, a);
     return check_launch("k_mlp_fwd_pair");
 }
 
 // inference launch of a 512-wide default architecture through the pair kernel; MNR_E_UNSUPPORTED for anything else
 int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
-                              const mnr_mlp_cell *cells, int n_cells) {
+                              const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0) {
     const bool arch = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 512 && d->layers == 8 &&
                       d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
-    if (arch && d->xyz_dim == 3) return launch_fwd_pair<MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>>(m, packed_dev, d, io, s, cells, n_cells);
-    if (arch && d->xyz_dim == 4) return launch_fwd_pair<MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>>(m, packed_dev, d, io, s, cells, n_cells);
+    using FG = MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>;
+    using BG = MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>;
+    if (tape && (cells || io->sigma_only)) return set_err(MNR_E_INVALID, "the tape-writing pair kernel takes plain launches");
+    if (arch && d->xyz_dim == 3) return tape ? launch_fwd_pair<FG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0)
+                                             : launch_fwd_pair<FG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
+    if (arch && d->xyz_dim == 4) return tape ? launch_fwd_pair<BG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0)
+                                             : launch_fwd_pair<BG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
     return set_err(MNR_E_UNSUPPORTED, "the pair kernel covers the 512-wide default fg / bg architectures");
 }
 

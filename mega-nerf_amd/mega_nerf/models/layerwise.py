@@ -125,6 +125,13 @@ class LayerwiseTape:
         if Ep > E:
             emb[:, E:].zero_()
         N.check(lib.mnr_embed(emb.data_ptr(), Ep, xyz.data_ptr(), xyz_stride, D, m.pos_xyz_dim, 1, B, st()))
+        # 512-wide default architectures (Building) in training: the whole forward is ONE launch of the wavefront-pair kernel
+        # (csrc/mlp_fwd_pair.hip, TRAIN) that also writes every layer's output as a dense [rows][width] plane -- exactly the tensors the
+        # tiled data-gradient / weight-gradient launches of backward() read; only the two zero-padded side inputs are built here
+        if (keep and tiled and not sigma_only and not self.sh and not self.affine and dir_rows == rows_per_ray and idx is not None and
+                getattr(m, 'is_wide_default_arch', lambda: False)() and os.environ.get('MNR_NO_PAIR_KERNEL') is None):
+            self._fused_forward(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, out, out_stride, sigma_noise, emb)
+            return
         hs = []
         ping = [torch.empty(B, W, device=dev), torch.empty(B, W, device=dev)] if not keep else None
         cur = None
@@ -199,6 +206,34 @@ class LayerwiseTape:
             self.raw, self.table = raw, table
         if keep:
             self.emb, self.hs, self.f, self.side, self.dact, self.head = emb, hs, f, side, dact, head
+
+    def _fused_forward(self, xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, out, out_stride, sigma_noise, emb) -> None:
+        lib, st = N.lib(), N.stream_ptr
+        m, dev = self.model, out.device
+        W, L, E, ED, A, Ep = m.layer_dim, m.layers, self.E, self.ED, self.A, self.Ep
+        fpr = m.tape_floats_per_row()
+        tape = torch.empty(B * fpr, device=dev)
+        io = m.mlp_io(xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, out, sigma_noise)
+        io.out_stride = out_stride
+        m.evaluate_train(io, tape, B, 0)
+        # TapeLayout (csrc/mlp_layout.h): act[0 .. L - 1] (W columns each), fin (W), dact (W / 2) -- plane p starts at float offset off_p * rows
+        plane = lambda off, width: tape[off * B:(off + width) * B].view(B, width)      # noqa: E731
+        hs = [plane(l * W, W) for l in range(L)]
+        f, dact = plane(L * W, W), plane(L * W + W, W // 2)
+        Sp = self.Sp = _pad32(ED + A)
+        side = torch.empty(B, Sp, device=dev)
+        if Sp > ED + A:
+            side[:, ED + A:].zero_()
+        N.check(lib.mnr_embed(side.data_ptr(), Sp, dirs.data_ptr(), dir_stride, 3, m.pos_dir_dim, rows_per_ray, B, st()))
+        N.check(lib.mnr_gather_rows(side.data_ptr() + ED * _F4, Sp, m.embedding_a.weight.data_ptr(), A, m.appearance_count, idx.data_ptr(),
+                                    idx_stride, 1 if idx.dtype == torch.float32 else 0, rows_per_ray, B, st()))
+        # the zero-padded weight copies backward()'s tiled data gradients address (what tlin() would have left behind)
+        for i in m.skip_layers:
+            name = 'xyz_encodings.%d.0' % i
+            self.wp[name] = _cached_padded_weight(m, name, m.xyz_encodings[i][0].weight, [(0, E, Ep), (E, W, W)])
+        self.wp['dir_a_encoding.0'] = _cached_padded_weight(m, 'dir_a_encoding.0', m.dir_a_encoding[0].weight, [(0, W, W), (W, ED + A, Sp)])
+        self.raw = self.table = None
+        self.emb, self.hs, self.f, self.side, self.dact, self.head, self._tape = emb, hs, f, side, dact, None, tape
 
     # ------------------------------------------------------------------------------------------------------------
     def backward(self, d_out: torch.Tensor, d_out_stride: int, grads: Dict[str, torch.Tensor]) -> None:
