@@ -91,7 +91,8 @@ __device__ __forceinline__ long uniform_long(long v) {
     return (long)(((unsigned long long)hi << 32) | lo);
 }
 
-struct WStream {
+template <int NT>        // NT = threads of the workgroup that shares the stream (256: four wavefronts; 512: eight)
+struct WStreamT {
     const float4 *g;     // the next chunk to load (uniform: lives in SGPRs; the lane's 16-byte slot is added as a 32-bit offset)
     float4 *lds;         // base of the 2-chunk LDS ring
     int cur;             // buffer the MFMAs currently read
@@ -105,11 +106,11 @@ struct WStream {
         // v_lshl_add_u64 each (they exceed the 12-bit immediate) -- 8 VALU instructions per chunk inside the MFMA stream
         const unsigned lane_off = threadIdx.x * 16u;
 #pragma unroll
-        for (int i = 0; i < CHUNK_F4 / 256; ++i) {
+        for (int i = 0; i < CHUNK_F4 / NT; ++i) {
             unsigned lo = lane_off;
             asm("" : "+v"(lo));          // a fresh 32-bit value per piece: otherwise its zero-extension is hoisted and the add goes 64-bit VALU again
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + i * 256)) + lo),
-                                             (lds_void_t *)(dst + i * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + i * NT)) + lo),
+                                             (lds_void_t *)(dst + i * NT), 16, 0, 0);
         }
         g += CHUNK_F4;
     }
@@ -120,11 +121,12 @@ struct WStream {
         issue();
     }
 };
+using WStream = WStreamT<256>;
 
 // One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
 // G0 = index of the segment's first group inside the layer (chunk boundaries are static).
-template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB>
-__device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], WStream &st, int lane) {
+template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB, class Stream>
+__device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], Stream &st, int lane) {
     static_assert(NB >= 4 * NG, "B register array too small");
     static_for<0, NG>([&](auto gi) {
         constexpr int g = G0 + decltype(gi)::value;

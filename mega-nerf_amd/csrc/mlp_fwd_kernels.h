@@ -105,9 +105,10 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
     }
 }
 
-template <class C, bool TRAIN>
+// NW = wavefronts per workgroup sharing one weight stream (4: two workgroups per CU; 8: one -- half the stream traffic and barriers per CU)
+template <class C, bool TRAIN, int NW = 4>
 __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int cidx = 0) {
-    constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB;
+    constexpr int TILE = C::TILE, P = C::P, H = C::H, NOB = C::NOB, RPB = C::RPB, ROWS_WG = NW * TILE;
     using AccT = typename std::conditional<TILE == 32, floatx16, floatx4>::type;
     extern __shared__ float4 lds_ring[];
 
@@ -123,7 +124,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         int c = 0;
         n_rows = 0;
         for (; c < a.n_cells; ++c) {
-            const long n = *a.cells[c].count, t = (n + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+            const long n = *a.cells[c].count, t = (n + ROWS_WG - 1) / ROWS_WG;
             if (blk < t) { n_rows = n; break; }
             blk -= t;
         }
@@ -140,7 +141,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         // (cidx = blockIdx.y: no division; the table entry comes through vector loads -> everything is moved to SGPRs at once)
         const MlpCellSeg cell = a.dcells[cidx];
         n_rows = cell.n_units ? (long)__builtin_amdgcn_readfirstlane(*cell.n_units) * io.rows_per_unit : a.cell_rows;
-        if (blk * C::ROWS_PER_WG >= n_rows) return;
+        if (blk * ROWS_WG >= n_rows) return;
         chunks = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(cell.packed)));
         aux = reinterpret_cast<const float *>(reinterpret_cast<const char *>(chunks) + a.aux_byte_off);
         emb_a = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(cell.emb_a)));
@@ -148,7 +149,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         tape_row0 = uniform_long(cell.tape_row0);
     } else {
         n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
-        if (blk * C::ROWS_PER_WG >= n_rows) return;             // uniform per workgroup
+        if (blk * ROWS_WG >= n_rows) return;             // uniform per workgroup
     }
 
     // the per-cell pointers come out of a device table (vector loads), so the merged values would live in VGPR pairs for the
@@ -161,16 +162,16 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = lane / TILE;
-    const long lrow = (blk * 4 + wave) * TILE + (lane % TILE);          // row inside the segment (inside the cell: dcells)
+    const long lrow = (blk * NW + wave) * TILE + (lane % TILE);          // row inside the segment (inside the cell: dcells)
     const bool valid = lrow < n_rows;
     const long row = row_base + lrow;
     // first tape row of this wave (training; uniform -> SGPR; tapes hold < 2^32 rows)
-    const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * 4 + wave) * TILE + tape_row0));
+    const unsigned trow0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((blk * NW + wave) * TILE + tape_row0));
     const long rc = row_base + (valid ? lrow : n_rows - 1);
     const long src = row_index ? (long)row_index[rc] : rc;           // gathered evaluation (MegaNeRF router)
     const long ray = src / io.rows_per_ray;
 
-    WStream st;
+    WStreamT<64 * NW> st;
     st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));      // into SGPRs once: the stream pointer arithmetic stays scalar
     st.lds = lds_ring;
     st.cur = 1;
@@ -354,12 +355,12 @@ struct MlpFwdMulti {
     int32_t is_b[MLP_MAX_SEGS];
     int32_t nseg;
 };
-template <class CA, class CB, bool TRAIN>
-__global__ __launch_bounds__(256, 2) void k_mlp_fwd_multi(MlpFwdMulti m) {
+template <class CA, class CB, bool TRAIN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_mlp_fwd_multi(MlpFwdMulti m) {
     const int blk = blockIdx.x;
     const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
-    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN>(m.seg[s], blk - m.wg0[s], blockIdx.y);
-    else mlp_fwd_body<CA, TRAIN>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    else mlp_fwd_body<CA, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
 }
 
 template <class C>

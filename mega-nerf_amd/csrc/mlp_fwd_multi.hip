@@ -1,5 +1,7 @@
 // mlp_fwd_multi.hip -- mnr_mlp_forward_multi: the foreground AND the background model's rows of one pass in ONE launch
 // (k_mlp_fwd_multi, mlp_fwd_kernels.h); its own translation unit so that it compiles beside mlp_fwd.hip.
+#include <stdlib.h>
+
 #include "mlp_fwd_multi_impl.h"
 
 using namespace mnr;
@@ -28,6 +30,17 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
             return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_forward_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2) form");
         pair = p;
     }
+#ifdef MNR_EXPERIMENT_8WAVES
+    // Experiment (round 4, -DMNR_EXPERIMENT_8WAVES + MNR_FWD_8WAVES=1): eight wavefronts per workgroup share one weight stream (128 rows
+    // per pass, one workgroup per CU: half the stream traffic and half the barriers per CU).  Measured on the benchmark step: eval 2.08 ->
+    // 2.38 ms, training forward 0.84 + 1.45 -> 1.02 + 1.73 ms, the 8-cell set 47.5 -> 49.4 ms: two independent four-wavefront workgroups
+    // per CU, whose chunk barriers interleave, beat one barrier domain of eight.  Not instantiated by default.
+    if (pair == 1 && getenv("MNR_FWD_8WAVES")) {
+        bool ok = true;
+        for (int i = 0; i < n_segs; ++i) ok = ok && (!cells || cells[i].cell_rows % 128 == 0);
+        if (ok) return mlp_forward_multi_pair<CfgFG, CfgBG, 8>(segs, n_segs, cells, s);
+    }
+#endif
     return pair == 1 ? mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s) : mlp_forward_multi_sh(segs, n_segs, cells, s);
 }
 

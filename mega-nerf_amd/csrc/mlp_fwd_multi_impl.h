@@ -9,8 +9,9 @@ namespace mnr {
 
 static inline long n_cells_of(const mnr_mlp_launch &L, const CellTable &c) { return c.cell_rows > 0 ? L.io->n_rows / c.cell_rows : 0; }
 
-template <class CfgFG, class CfgBG>
+template <class CfgFG, class CfgBG, int NW = 4>
 static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
+    constexpr int ROWS_WG = NW * CfgFG::TILE;
     MlpFwdMulti mm{};
     const bool train = segs[0].tape_dev != nullptr;
     long wg = 0;
@@ -32,8 +33,8 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
                     : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0);
         if (rc != MNR_OK) return rc;
         if (cells && cells[i].dcells) {
-            MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % CfgFG::ROWS_PER_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
-                        "segment %d: rows per cell must be a multiple of %d", i, CfgFG::ROWS_PER_WG);
+            MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % ROWS_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
+                        "segment %d: rows per cell must be a multiple of %d", i, ROWS_WG);
             mm.seg[i].dcells = cells[i].dcells;
             mm.seg[i].cell_rows = cells[i].cell_rows;
         }
@@ -42,17 +43,17 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
         if (cells) {                       // grid = (workgroups per cell, cells): every segment spans the same cells
             MNR_REQUIRE(cells[i].dcells && n_cells_of(L, cells[i]) == n_cells_of(segs[0], cells[0]) && n_cells_of(L, cells[i]) >= 1,
                         "multi-cell launch: every segment needs a cell table over the same number of cells");
-            wg += cells[i].cell_rows / CfgFG::ROWS_PER_WG;
+            wg += cells[i].cell_rows / ROWS_WG;
         } else
-        wg += (L.io->n_rows + CfgFG::ROWS_PER_WG - 1) / CfgFG::ROWS_PER_WG;
+        wg += (L.io->n_rows + ROWS_WG - 1) / ROWS_WG;
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     mm.nseg = n_segs;
     if (wg == 0) return MNR_OK;
     const unsigned ny = cells ? (unsigned)n_cells_of(segs[0], cells[0]) : 1u;
-    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
-    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false>), dim3((unsigned)wg, ny), dim3(256), 2 * CHUNK_BYTES, s, mm);
+    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), 2 * CHUNK_BYTES, s, mm);
+    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), 2 * CHUNK_BYTES, s, mm);
     return check_launch("k_mlp_fwd_multi");
 }
 
