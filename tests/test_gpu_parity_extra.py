@@ -443,3 +443,53 @@ def test_default_width_model_built_under_inference_mode():
         c = native_nerf(cfg, w)(T(x)).cpu().numpy()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(a, c)
+
+
+@pytest.mark.parametrize('xyz_dim', [3, 4])
+def test_pair_kernel_equals_the_one_wavefront_kernel_and_fp64(xyz_dim, monkeypatch):
+    """k_mlp_fwd_pair (csrc/mlp_fwd_pair.hip: the 512-wide default architectures with two wavefronts per SIMD, a wavefront pair splitting
+    every layer's output features) against (i) k_mlp_fwd<MlpCfg<.., 512, ..>> on the same packed image -- a feature's K loop is the same
+    fmaf chain in both, so the densities must be BIT-identical (colours: to the order of the rgb head's last addition) -- for plain launches (ragged row count, sigma noise, sigma_only) and (ii)
+    an fp64 torch evaluation of the same weights (1e-5 of the output scale)."""
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, layer_dim=512, bg_layer_dim=512)
+    cfg = common.model_cfg(hp, xyz_dim, 512)
+    A = common.SCENE['appearance_count']
+    w = common.make_weights(cfg, A, 4400 + xyz_dim)
+    m = native_nerf(cfg, w).to(DEV).eval()
+    assert m.is_wide_default_arch()
+    rng = np.random.default_rng(17)
+    B = 1000 + 37                                           # not a multiple of the 64 rows of a workgroup
+    x = np.concatenate([rng.uniform(-.8, .8, (B, xyz_dim)), rng.standard_normal((B, 3)), rng.integers(0, A, (B, 1))], 1).astype(f32)
+    noise = rng.uniform(0, 1, (B, 1)).astype(f32)
+    outs = {}
+    for mode in ('pair', 'one'):
+        if mode == 'one':
+            monkeypatch.setenv('MNR_NO_PAIR_KERNEL', '1')
+        else:
+            monkeypatch.delenv('MNR_NO_PAIR_KERNEL', raising=False)
+        with torch.no_grad():
+            outs[mode] = (m(T(x)).cpu().numpy(), m(T(x), sigma_noise=T(noise)).cpu().numpy(),
+                          m(T(x[:, :xyz_dim].copy()), sigma_only=True).cpu().numpy())
+    for a, b in zip(outs['pair'], outs['one']):
+        # the trunk (hence sigma) is bit-identical; the rgb head sums its 256 inputs as two halves of 128 in the pair kernel
+        np.testing.assert_array_equal(a[:, -1], b[:, -1])
+        np.testing.assert_allclose(a, b, rtol=0, atol=3e-7)
+    # fp64 evaluation of nerf.py:115-160 with the same weights
+    W64 = {k: torch.from_numpy(v).double() for k, v in w.items()}
+    xt = torch.from_numpy(x).double()
+
+    def emb(v, L):
+        return torch.cat([v] + [f(v * 2.0 ** k) for k in range(L) for f in (torch.sin, torch.cos)], -1)
+    e = emb(xt[:, :xyz_dim], 12)
+    h = e
+    for i in range(8):
+        inp = torch.cat([e, h], -1) if i == 4 else h
+        h = torch.relu(inp @ W64['xyz_encodings.%d.0.weight' % i].T + W64['xyz_encodings.%d.0.bias' % i])
+    sigma = torch.nn.functional.softplus(h @ W64['sigma.weight'].T + W64['sigma.bias'] - 1)
+    f = h @ W64['xyz_encoding_final.weight'].T + W64['xyz_encoding_final.bias']
+    app = W64['embedding_a.weight'][xt[:, -1].long()]
+    d = torch.relu(torch.cat([f, emb(xt[:, xyz_dim:xyz_dim + 3], 4), app], -1) @ W64['dir_a_encoding.0.weight'].T + W64['dir_a_encoding.0.bias'])
+    rgb = torch.sigmoid(d @ W64['rgb.weight'].T + W64['rgb.bias'])
+    ref = torch.cat([rgb, sigma], -1).numpy()
+    err = np.abs(outs['pair'][0] - ref).max(0) / np.maximum(np.abs(ref).max(0), 1e-12)
+    assert err.max() < 1e-5, err
