@@ -7,19 +7,10 @@
 
 namespace mnr {
 
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
 template <int OFF>
 __device__ __forceinline__ float lds_ld(unsigned addr) {
     float v;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ floatx4 lds_ld4(unsigned addr) {
-    floatx4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
 // eight words OFF0, OFF0 + STRIDE, ... and the wait for them in ONE statement: the results are valid when the compiler sees them, so it
@@ -46,11 +37,7 @@ __device__ __forceinline__ int lds_ld_u(unsigned addr) { return __builtin_amdgcn
 __device__ __forceinline__ void lds_st_i(unsigned addr, int v) {
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-// an empty asm that "redefines" a register: MFMAs consuming it cannot be scheduled above the wait that precedes the pin
-__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(floatx4 &x) { asm volatile("" : "+v"(x)); }
+// (lds_addr, lds_ld4, wait_lgkm, pin: mlp_device.h -- the register-chained kernels read their A fragments the same way)
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // fetch-and-increment WITHOUT waiting for the result (hipcc's atomicAdd puts `s_waitcnt vmcnt(0)` right behind the
 // instruction, which also drains the LDS-DMA queue); the value is valid after the caller's next wait_vm0()

@@ -123,6 +123,27 @@ struct WStreamT {
 };
 using WStream = WStreamT<256>;
 
+// ---- LDS reads hipcc must not see ---------------------------------------------------------------------------------------------
+// Behind an LDS-DMA (global_load_lds) into an LDS array the compiler puts `s_waitcnt vmcnt(0)` in front of the next compiler-visible
+// ds_read of that array.  In the chunk ring that is the first A-fragment read of chunk c, right behind the DMA burst of chunk c + 1:
+// every wavefront waited for the prefetch it had just issued before it touched the chunk that was already there -- the double
+// buffering overlapped nothing inside a workgroup (only the CU's other workgroup ran meanwhile; rounds 1-3).  Reading the fragments
+// with inline asm and counting lgkmcnt by hand removes that wait (round 4; csrc/wgrad.hip and tgemm.hip always read this way).
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int OFF>
+__device__ __forceinline__ floatx4 lds_ld4(unsigned addr) {
+    floatx4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// an empty asm that "redefines" a register: MFMAs consuming it cannot be scheduled above the wait that precedes the pin
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(floatx4 &x) { asm volatile("" : "+v"(x)); }
+
 // One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
 // G0 = index of the segment's first group inside the layer (chunk boundaries are static).
 template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB, class Stream>
@@ -132,8 +153,8 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
         constexpr int g = G0 + decltype(gi)::value;
         constexpr int gl = decltype(gi)::value;
         if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
-        const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
         if constexpr (TILE == 32) {
+            const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 const float4 a = p[ob * 64];
@@ -143,29 +164,38 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
                 acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * gl + 3], acc[ob], 0, 0, 0);
             }
         } else {
-            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk all blocks per k step
-            // (in batches of OBB blocks so that the A fragments stay within OBB*4 registers)
-            constexpr int OBB = NOB < 4 ? NOB : 4;
+            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk a batch of OBB blocks per k step.  The A fragments of two
+            // batches are in flight (asm reads, hand-counted waits): batch i + 2 is requested as soon as the MFMAs of batch i are issued.
+            constexpr int OBB = NOB < 4 ? NOB : 4, NBATCH = NOB / OBB;
             static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
+            const unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane);
+            floatx4 a0[OBB], a1[OBB];
+            auto load = [&](floatx4 (&a)[OBB], auto batch) {
+                constexpr int o0 = decltype(batch)::value * OBB;
+                static_for<0, OBB>([&](auto oc) { a[decltype(oc)::value] = lds_ld4<(o0 + decltype(oc)::value) * 1024>(addr); });
+            };
+            auto mfmas = [&](floatx4 (&a)[OBB], auto batch) {
+                constexpr int o0 = decltype(batch)::value * OBB;
 #pragma unroll
-            for (int o0 = 0; o0 < NOB; o0 += OBB) {
-                float4 a[OBB];
+                for (int ob = 0; ob < OBB; ++ob) pin(a[ob]);
 #pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) a[ob] = p[(o0 + ob) * 64];
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, b[4 * gl + 0], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, b[4 * gl + 1], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, b[4 * gl + 2], acc[o0 + ob], 0, 0, 0);
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, b[4 * gl + 3], acc[o0 + ob], 0, 0, 0);
-                // wide layers (W = 512: 32 blocks): stop the scheduler from hoisting the A-fragment loads of many
-                // batches ahead -- it would blow the register budget (676 spilled VGPRs without this fence)
-                if constexpr (NOB > 16) {
-                    if ((o0 / OBB) % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], b[4 * gl + k], acc[o0 + ob], 0, 0, 0);
+            };
+            load(a0, std::integral_constant<int, 0>{});
+            if constexpr (NBATCH > 1) load(a1, std::integral_constant<int, 1>{});
+            static_for<0, NBATCH>([&](auto bc) {
+                constexpr int bi = decltype(bc)::value;
+                if constexpr (bi + 1 < NBATCH) wait_lgkm<OBB>(); else wait_lgkm<0>();
+                if constexpr (bi % 2 == 0) {
+                    mfmas(a0, bc);
+                    if constexpr (bi + 2 < NBATCH) load(a0, std::integral_constant<int, bi + 2>{});
+                } else {
+                    mfmas(a1, bc);
+                    if constexpr (bi + 2 < NBATCH) load(a1, std::integral_constant<int, bi + 2>{});
                 }
-            }
+            });
         }
     });
 }
