@@ -26,13 +26,14 @@ from pathlib import Path
 KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid size))
     'k_wgrad2': ('train', lambda n, g: ('k_wgrad2<' in n and 'true>' not in n) or 'k_wgrad2(' in n),
     'k_wgrad2_reduce': ('train', lambda n, g: 'k_wgrad2_reduce' in n),
-    'k_mlp_fwd_multi_train': ('train', lambda n, g: 'k_mlp_fwd_multi' in n and 'true>' in n),
+    'k_mlp_fwd_multi_train': ('train', lambda n, g: 'k_mlp_fwd_multi' in n and ', true' in n),
     'k_mlp_bwd_multi': ('train', lambda n, g: 'k_mlp_bwd_multi' in n),
     'k_head_grads': ('train', lambda n, g: 'k_head_grads' in n),
-    'k_mlp_fwd_multi_eval': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and 'false>' in n),
-    'k_mlp_fwd_multi_eval_fine': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and 'false>' in n and g >= 2048 * 256),
+    'k_mlp_fwd_multi_eval': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and ', false' in n),
+    'k_mlp_fwd_multi_eval_fine': ('eval', lambda n, g: 'k_mlp_fwd_multi' in n and ', false' in n and g >= 2048 * 256),
     # Building-shaped foreground (layer_dim 512): tiled GEMMs + job-form weight gradients of the layer-by-layer path
     'k_tgemm_forward_w512': ('w512', lambda n, g: 'k_tgemm<false' in n),
+    'k_mlp_fwd_pair_train_w512': ('w512', lambda n, g: 'k_mlp_fwd_pair' in n and 'true>' in n),      # round 4: the one-launch forward of W = 512 training
     'k_tgemm_data_gradient_w512': ('w512', lambda n, g: 'k_tgemm<true' in n),
     'k_wgrad2_jobs_w512': ('w512', lambda n, g: 'k_wgrad2<1>' in n),
     # opt-in split-precision kernels (16-bit matrix pipe, hi/lo operands)
