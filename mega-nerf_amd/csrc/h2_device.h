@@ -151,6 +151,14 @@ __device__ __forceinline__ void h2_split8(const float (&x)[8], uint4v &hi, uint4
     }
 }
 
+template <int OFF>
+__device__ __forceinline__ uint4v lds_ld4u(unsigned addr) {
+    uint4v v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void pin_u(uint4v &x) { asm volatile("" : "+v"(x)); }
+
 __device__ __forceinline__ floatx4 h2_mfma(uint4v a, uint4v b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
@@ -166,7 +174,7 @@ struct H2NoHook {
 // `hook(chunk index inside the layer)` runs right behind every chunk boundary (behind the DMA issue of the following chunk): the
 // place for the training kernels' tape stores (a boundary drains vmcnt: stores issued just BEFORE one cost a write round trip)
 // G = output blocks whose (hi, lo) fragments are read ahead of their MFMAs (32 registers at 4; the training forward takes 2)
-template <int NOB, int NK, int K0, int G, int NSRC, class Hook = H2NoHook>
+template <int NOB, int NK, int K0, int G, bool ASM_READS, int NSRC, class Hook = H2NoHook>
 __device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
     constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64);
     static_for<0, NK>([&](auto kc) {
@@ -177,8 +185,14 @@ __device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&
         for (int j = 0; j < 8; ++j) x[j] = (8 * kl + j < NSRC) ? src[(8 * kl + j < NSRC) ? 8 * kl + j : 0] : 0.f;
         uint4v bh, bl;
         h2_split8(x, bh, bl, st.one);
-        const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
         static_assert(NOB % G == 0, "output blocks per fragment group");
+#if defined(H2_EXPERIMENT_HALF_LDS)
+        constexpr bool asm_reads = false;
+#else
+        constexpr bool asm_reads = ASM_READS;
+#endif
+        if constexpr (!asm_reads) {
+        const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
 #pragma unroll
         for (int o0 = 0; o0 < NOB; o0 += G) {
             uint4v ah[G], al[G];
@@ -195,11 +209,53 @@ __device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&
 #pragma unroll
             for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
         }
+        } else {
+        // (hi, lo) fragments of G output blocks per batch, read with inline asm and hand-counted lgkmcnt, two batches in flight: a
+        // compiler-visible read of the ring gets `s_waitcnt vmcnt(0)` in front of it -- right behind the DMA burst of the NEXT chunk, so
+        // every wavefront of the (single, eight-wavefront) workgroup waited for the prefetch it had just issued (mlp_device.h; round 4)
+        constexpr int NBATCH = NOB / G;
+        const unsigned addr = lds_addr(st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane);
+        uint4v ahA[G], alA[G], ahB[G], alB[G];
+        auto load = [&](uint4v (&ah)[G], uint4v (&al)[G], auto batch) {
+            constexpr int o0 = decltype(batch)::value * G;
+            static_for<0, G>([&](auto oc) {
+                constexpr int o = o0 + decltype(oc)::value;
+                ah[decltype(oc)::value] = lds_ld4u<o * 2048>(addr);
+                al[decltype(oc)::value] = lds_ld4u<o * 2048 + 1024>(addr);
+            });
+        };
+        auto mfmas = [&](uint4v (&ah)[G], uint4v (&al)[G], auto batch) {
+            constexpr int o0 = decltype(batch)::value * G;
+#pragma unroll
+            for (int o = 0; o < G; ++o) { pin_u(ah[o]); pin_u(al[o]); }
+#pragma unroll
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
+#pragma unroll
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(al[o], bh, acc[o0 + o]);
+#pragma unroll
+            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
+        };
+        load(ahA, alA, std::integral_constant<int, 0>{});
+        if constexpr (NBATCH > 1) load(ahB, alB, std::integral_constant<int, 1>{});
+        static_for<0, NBATCH>([&](auto bc) {
+            constexpr int bi = decltype(bc)::value;
+            if constexpr (bi + 1 < NBATCH) wait_lgkm<2 * G>(); else wait_lgkm<0>();
+            if constexpr (bi % 2 == 0) {
+                mfmas(ahA, alA, bc);
+                if constexpr (bi + 2 < NBATCH) load(ahA, alA, std::integral_constant<int, bi + 2>{});
+            } else {
+                mfmas(ahB, alB, bc);
+                if constexpr (bi + 2 < NBATCH) load(ahB, alB, std::integral_constant<int, bi + 2>{});
+            }
+        });
+        }
     });
 }
 template <int NOB, int NK, int K0, int NSRC, class Hook = H2NoHook>
 __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
-    h2_segment_g<NOB, NK, K0, H2_FRAG_GROUP>(acc, src, st, lane, hook);
+    // the data-gradient chain (its only caller) reads with inline asm: measured 0.98 -> 0.94 ms on the benchmark step; the FORWARD keeps
+    // compiler-visible reads (h2_segment_g<..., false>): with two batches pinned in flight it spills 125-196 VGPRs and loses what it gains
+    h2_segment_g<NOB, NK, K0, H2_FRAG_GROUP, true>(acc, src, st, lane, hook);
 }
 
 
