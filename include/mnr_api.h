@@ -133,6 +133,11 @@ typedef struct mnr_mlp_io {
                                                      at out[r] (per-cell evaluation under the MegaNeRF router) */
 } mnr_mlp_io;
 
+/* Register-chained evaluation of nerf.py:115-160.  Kernel families behind it (all exact fp32 MFMA, same packed image): layer_dim <= 256:
+ * one wavefront owns 16 samples x all features, two workgroups per CU (csrc/mlp_fwd_kernels.h); layer_dim 512 with the default
+ * encodings (README "Larger models", Building): a wavefront PAIR owns the 16 samples and splits every layer's output features, two
+ * wavefronts per SIMD (csrc/mlp_fwd_pair.hip: whole render at 0.82 of the fp32-MFMA peak; MNR_NO_PAIR_KERNEL=1 selects the
+ * one-wavefront-per-SIMD instantiation for comparison).  MNR_E_UNSUPPORTED: no instantiation -- use the per-layer entry points below. */
 int mnr_mlp_forward(const void *packed_dev, const mnr_model_desc *desc, const mnr_mlp_io *io, void *stream);
 /* All cells of a routed MegaNeRF evaluation in ONE launch (the per-cell launches of mega_nerf.py:28-49 are individually
  * too small to fill 256 CUs).  cells_dev: DEVICE array; every cell shares the architecture of `desc` (its weight pointers
