@@ -264,6 +264,8 @@ class LayerwiseTape:
         use_jobs = self.tiled and B % 32 == 0
         ws = N.wgrad_workspace(dev) if use_jobs else None
 
+        held: list = []                        # gradient buffers that queued jobs still read
+
         def flush():
             if jobs:
                 arr = (N.WgradJob * len(jobs))(*jobs)
@@ -385,8 +387,7 @@ class LayerwiseTape:
             else:
                 dgrad(d_h.data_ptr(), W, d_f.data_ptr(), W, W, m.xyz_encoding_final, 0, W)
                 dgrad(d_h.data_ptr(), W, g_sig.data_ptr(), 1, 1, m.sigma, 0, W, accumulate=1)
-            flush()                            # the jobs read d_f
-            del d_f
+            held.append(d_f)                   # pending jobs read d_f: kept alive until they are flushed
         else:
             d_h = d_src
             g_sig = torch.empty(B, 1, device=dev)
@@ -395,7 +396,6 @@ class LayerwiseTape:
             bgrad('sigma.bias', g_sig.data_ptr(), 1, 1)
             dgrad(d_h.data_ptr(), W, g_sig.data_ptr(), 1, 1, m.sigma, 0, W, accumulate=1)
         # trunk
-        spare = None
         for i in range(m.layers - 1, -1, -1):
             name = 'xyz_encodings.%d.0' % i
             enc = m.xyz_encodings[i][0]
@@ -410,11 +410,15 @@ class LayerwiseTape:
                     wgrad(name + '.weight', E if has_emb else 0, d_h.data_ptr(), W, W, self.hs[i - 1].data_ptr(), W, W)
                 bgrad(name + '.bias', d_h.data_ptr(), W, W)
             if i > 0:
-                flush()                        # pending jobs may still read the buffer that is recycled next
-                nxt = spare if spare is not None else torch.empty(B, W, device=dev)
+                # every layer's dZ gets its own buffer (288 GB of HBM: ten of them are 4 GB at the benchmark's 196 608 rows), so the
+                # weight-gradient jobs of several layers go out as ONE launch (24 jobs per table) instead of one launch + reduction per
+                # layer -- recycling two buffers meant flushing the job table before each reuse
+                held.append(d_h)
+                nxt = torch.empty(B, W, device=dev)
                 wt, col0 = (self.wp[name], Ep) if name in self.wp else (enc.weight.detach(), E if has_emb else 0)
                 gated = dgrad_t(nxt, d_h, W, wt, col0, W, gate=self.hs[i - 1])
                 if not gated:
                     dgrad(nxt.data_ptr(), W, d_h.data_ptr(), W, W, enc, E if has_emb else 0, W)
-                spare, d_h = d_h, nxt
+                d_h = nxt
         flush()
+        del held[:]
