@@ -1515,7 +1515,24 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         seg[0].packed_dev = r->fg_packed; seg[0].desc = r->fg; seg[0].io = &io[0];
         seg[1].packed_dev = r->bg_packed; seg[1].desc = r->bg; seg[1].io = &io[1];
         const int first = branch == 2 ? 1 : 0, n = branch == 0 ? 2 : 1;
-        return r->split_precision ? mnr_mlp_forward_multi_h2(seg + first, n, st) : mlp_forward_multi_impl(seg + first, n, nullptr, st);
+        if (r->split_precision) return mnr_mlp_forward_multi_h2(seg + first, n, st);
+        if (r->fg->layer_dim == 512 || r->bg->layer_dim == 512) {
+            // 512-wide models (Building): one launch per model -- the wavefront-pair kernel for a 512-wide one, the two-model kernel
+            // (with one segment) for a 256-wide background
+            for (int i = first; i < first + n; ++i) {
+                int rc2;
+                if (seg[i].desc->layer_dim == 512) {
+                    ModelLayout ml;
+                    if ((rc2 = layout_from_desc(seg[i].desc, ml)) != MNR_OK) return rc2;
+                    rc2 = mlp_forward_pair_dispatch(ml, seg[i].packed_dev, seg[i].desc, seg[i].io, st, nullptr, 0, nullptr, 0, 0);
+                } else {
+                    rc2 = mlp_forward_multi_impl(seg + i, 1, nullptr, st);
+                }
+                if (rc2 != MNR_OK) return rc2;
+            }
+            return MNR_OK;
+        }
+        return mlp_forward_multi_impl(seg + first, n, nullptr, st);
     };
     auto mid = [&](long unit0, long unit1, hipStream_t st) -> int {
         MidArgs a{};

@@ -18,6 +18,9 @@ struct CellTable {
 };
 
 int mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
+// 512-wide default architectures (csrc/mlp_fwd_pair.hip); MNR_E_UNSUPPORTED for anything else
+int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                              const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0);
 int mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
 // split-precision forms (csrc/mlp_fwd_h2.hip, csrc/mlp_bwd_h2.hip): packed pointers = the (hi, lo) f16 images
 int h2_layout(const mnr_model_desc *d, ModelLayout &m);

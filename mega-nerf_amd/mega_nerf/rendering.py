@@ -398,7 +398,11 @@ def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_d
     if sh and (hparams.sh_deg != 2 or SPLIT_PRECISION):
         return False
     for m in (nerf, bg_nerf):
-        if not isinstance(m, NeRF) or m.training or not (m.is_sh2_arch() if sh else m.is_default_arch()):
+        if not isinstance(m, NeRF) or m.training:
+            return False
+        # default 8 x 256, its sh_deg 2 form, or (fp32 kernels only) the 512-wide Building shape on the wavefront-pair kernel
+        wide = m.is_wide_default_arch() and not sh and not SPLIT_PRECISION and os.environ.get('MNR_NO_PAIR_KERNEL') is None
+        if not ((m.is_sh2_arch() if sh else m.is_default_arch()) or wide):
             return False
     return nerf.xyz_dim == 3 and bg_nerf.xyz_dim == 4
 

@@ -187,7 +187,7 @@ def test_generated_random_numbers_are_uniform_and_keyed():
 
 
 @pytest.mark.parametrize('name,split', [('render_fgbg_eval', False), ('render_fgbg_eval', True), ('render_default_samples_eval', False),
-                                        ('render_default_samples_eval', True), ('render_sh2_eval', False)])
+                                        ('render_default_samples_eval', True), ('render_sh2_eval', False), ('render_w512_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches) against the stage-by-stage render -- identical outputs, bit for bit, for the fp32 kernels --
     and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
