@@ -34,7 +34,8 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
     // Experiment (round 4, -DMNR_EXPERIMENT_8WAVES + MNR_FWD_8WAVES=1): eight wavefronts per workgroup share one weight stream (128 rows
     // per pass, one workgroup per CU: half the stream traffic and half the barriers per CU).  Measured on the benchmark step: eval 2.08 ->
     // 2.38 ms, training forward 0.84 + 1.45 -> 1.02 + 1.73 ms, the 8-cell set 47.5 -> 49.4 ms: two independent four-wavefront workgroups
-    // per CU, whose chunk barriers interleave, beat one barrier domain of eight.  Not instantiated by default.
+    // per CU, whose chunk barriers interleave, beat one barrier domain of eight -- also after the asm fragment reads of run_segment removed
+    // the per-chunk vmcnt(0) wait (re-measured: eval 2.04 vs 2.34 ms, training forward 0.81 + 1.42 vs 0.97 + 1.60 ms).  Not instantiated by default.
     if (pair == 1 && getenv("MNR_FWD_8WAVES")) {
         bool ok = true;
         for (int i = 0; i < n_segs; ++i) ok = ok && (!cells || cells[i].cell_rows % 128 == 0);
