@@ -206,7 +206,11 @@ __device__ __forceinline__ void init_acc(AccT (&acc)[NOB], const float *bias_par
     for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
         for (int q = 0; q < RPB / 4; ++q) {
+#ifdef MNR_EXPERIMENT_NO_BIAS          // timing experiment only (results invalid): what do the per-layer bias loads cost?
+            const float4 v = make_float4(0.f, 0.f, 0.f, 0.f); (void)bias_part;
+#else
             const float4 v = *reinterpret_cast<const float4 *>(bias_part + ob * RPB + 4 * q);
+#endif
             acc[ob][4 * q + 0] = v.x; acc[ob][4 * q + 1] = v.y; acc[ob][4 * q + 2] = v.z; acc[ob][4 * q + 3] = v.w;
         }
     }
