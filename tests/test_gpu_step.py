@@ -602,3 +602,40 @@ def test_gathered_batch_equals_the_materialised_batch():
     for k in out[0][2]:
         sc_ = max(float(np.abs(out[1][2][k]).max()), 1e-30)
         assert float(np.abs(out[0][2][k] - out[1][2][k]).max()) / sc_ < 2e-5, k
+
+
+def test_sticky_health_bits_raise_what_the_reference_raises():
+    """The trainer checks its steps' health every k iterations instead of synchronising every iteration (runner.py:260-261 checks every
+    metric every step; rendering.py:412-414 raises inside render_rays): mnr_train_step ORs 'loss not finite' / 'camera outside the unit
+    ellipsoid' into words that survive the per-step memset, CellTrainer.health() turns them into the reference's exceptions -- also when
+    the offending step is followed by healthy ones."""
+    from mega_nerf import _native as N
+    from mega_nerf.training import CellTrainer
+    g = load('render_fgbg_train')
+    s = common.SCENE
+    rays, idx, tgt = T(g['rays']), T(g['idx'].astype(np.int32)), T(g['target'])
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+
+    def trainer():
+        hp, nerf, bg_nerf = native_models('render_fgbg_train')
+        return CellTrainer(nerf, bg_nerf, Namespace(**vars(hp)), sc, sr, seed=1)
+    tr = trainer()
+    tr.step(rays, idx, tgt)
+    tr.health()                                                   # nothing to report
+    assert int(tr.fused.sticky.max()) == 0
+    bad = rays.clone()
+    bad[3, :3] *= 40                                              # one camera far outside the ellipsoid
+    tr.step(bad, idx, tgt)
+    tr.step(rays, idx, tgt)                                       # a healthy step afterwards must not clear the flag
+    assert int(tr.fused.sticky[0]) & N.MNR_STEP_STICKY_OUTSIDE
+    with pytest.raises(Exception, match='Not all your cameras are bounded by the unit sphere'):
+        tr.health()
+    assert int(tr.fused.sticky.max()) == 0                        # reported once, then cleared
+    tr2 = trainer()
+    nan_t = tgt.clone()
+    nan_t[5, 1] = float('nan')
+    tr2.step(rays, idx, nan_t)
+    tr2.step(rays, idx, tgt)
+    assert int(tr2.fused.sticky[0]) & N.MNR_STEP_STICKY_NONFINITE
+    with pytest.raises(Exception, match='Train metrics not finite'):
+        tr2.health()
