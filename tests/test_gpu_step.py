@@ -639,3 +639,42 @@ def test_sticky_health_bits_raise_what_the_reference_raises():
     assert int(tr2.fused.sticky[0]) & N.MNR_STEP_STICKY_NONFINITE
     with pytest.raises(Exception, match='Train metrics not finite'):
         tr2.health()
+
+
+def test_gathered_batches_in_a_multi_cell_plan():
+    """Two cells in one plan, each fed by row selections of its own resident training set (one GatheredBatch per cell, one cell's
+    colours as bytes and the other's batch materialised): per-cell loss and colours equal the all-materialised call."""
+    from mega_nerf.datasets.memory_dataset import unit_rgb, unit_table
+    from mega_nerf.training import FusedTrainStep, GatheredBatch
+    s = common.SCENE
+    sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
+    n = 128
+    rng = np.random.default_rng(9)
+
+    def source(cell):
+        rays, idx, _ = cell[3]
+        P = 3 * n
+        pos = rng.permutation(P)[:n]
+        ra = rays.repeat(3, 1).clone()
+        ra[:, :3] += 1e-3 * torch.randn(P, 3, device=ra.device)
+        ra[T(pos.astype(np.int64))] = rays
+        ia = torch.randint(0, s['appearance_count'], (P,), device=ra.device, dtype=torch.int32)
+        ia[T(pos.astype(np.int64))] = idx
+        ca = torch.randint(0, 256, (P, 3), device=ra.device, dtype=torch.uint8)
+        return ra.contiguous(), ia.contiguous(), ca.contiguous(), T(pos.astype(np.int64))
+    out = []
+    for gathered in (True, False):
+        rng = np.random.default_rng(9)
+        torch.manual_seed(4)
+        cells = [_cell(sd, n) for sd in (21, 22)]
+        srcs = [source(c) for c in cells]
+        hpn = Namespace(**vars(cells[0][0]))
+        step = FusedTrainStep([(c[1], c[2]) for c in cells], hpn, sc, sr, n, seed=5)
+        mat = [(sr_[0][sr_[3]], sr_[1][sr_[3]], unit_rgb(sr_[2][sr_[3]])) for sr_ in srcs]
+        batches = [GatheredBatch(srcs[0][0], srcs[0][1], srcs[0][2], srcs[0][3], unit_table(DEV)), mat[1]] if gathered else mat
+        loss, n_bg, err = step(batches, optimize=False)
+        torch.cuda.synchronize()
+        assert int(err.max()) == 0
+        out.append((loss.cpu().numpy().copy(), step.rgb.cpu().numpy().copy()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
+    np.testing.assert_array_equal(out[0][1], out[1][1])
