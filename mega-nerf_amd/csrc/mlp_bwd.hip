@@ -768,6 +768,8 @@ extern "C" int mnr_mlp_backward_data(const void *packed_fwd_dev, const void *pac
     MNR_TRY_B(4, 12, 4, 0, 256, 8, 16, 3, 16)
     MNR_TRY_B(3, 12, 0, 48, 256, 8, 16, 27, 16)       // configs/mega-nerf-sh-3
     MNR_TRY_B(4, 12, 0, 48, 256, 8, 16, 27, 16)
+    MNR_TRY_B(3, 12, 0, 48, 256, 8, 16, 48, 16)       // sh_deg 3
+    MNR_TRY_B(4, 12, 0, 48, 256, 8, 16, 48, 16)
 #endif
 #undef MNR_TRY_B
     if (rc == MNR_E_UNSUPPORTED) return set_err(rc, "no backward kernel for this architecture (training supports the "

@@ -145,6 +145,9 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
     // configs/mega-nerf-sh-3 (sh_deg 2, pos_dir_dim 0)
     MNR_TRY(3, 12, 0, 48, 256, 8, 16, 27)
     MNR_TRY(4, 12, 0, 48, 256, 8, 16, 27)
+    // sh_deg 3 (BASELINE.json's wording of configs[4]): 48 colour coefficients
+    MNR_TRY(3, 12, 0, 48, 256, 8, 16, 48)
+    MNR_TRY(4, 12, 0, 48, 256, 8, 16, 48)
     // small-width models used by the cascade tests
     MNR_TRY(3, 12, 4, 0, 64, 8, 16, 3)
     MNR_TRY(3, 12, 4, 48, 64, 8, 16, 3)

@@ -17,6 +17,8 @@ int mlp_forward_train_dispatch(const ModelLayout &m, const void *packed_dev, con
     MNR_TRY_TRAIN(4, 12, 4, 0, 256, 8, 16, 3, 16)
     MNR_TRY_TRAIN(3, 12, 0, 48, 256, 8, 16, 27, 16)   // configs/mega-nerf-sh-3 (colour epilogue + rgb layer adjoint: caller)
     MNR_TRY_TRAIN(4, 12, 0, 48, 256, 8, 16, 27, 16)
+    MNR_TRY_TRAIN(3, 12, 0, 48, 256, 8, 16, 48, 16)   // sh_deg 3
+    MNR_TRY_TRAIN(4, 12, 0, 48, 256, 8, 16, 48, 16)
 #endif
 #undef MNR_TRY_TRAIN
     return set_err(MNR_E_UNSUPPORTED,
