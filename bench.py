@@ -363,9 +363,9 @@ SWEEP = [
     ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), train', ['--sh-deg', '2', '--mode', 'train']),
     ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), eval', ['--sh-deg', '2', '--mode', 'eval']),
     # BASELINE.json words configs[4] as "SH-degree-3"; the reference's config files say sh_deg 2.  Degree 3 (48 colour
-    # coefficients) runs on the register-chained kernels sequenced stage by stage (no one-call step / render for this head)
-    ('configs[4] as worded in BASELINE.json: sh_deg 3 (stage-by-stage sequencing), train', ['--sh-deg', '3', '--mode', 'train']),
-    ('configs[4] as worded in BASELINE.json: sh_deg 3 (stage-by-stage sequencing), eval', ['--sh-deg', '3', '--mode', 'eval']),
+    # coefficients) has its own pair of the one-call step / render
+    ('configs[4] as worded in BASELINE.json: sh_deg 3, train', ['--sh-deg', '3', '--mode', 'train']),
+    ('configs[4] as worded in BASELINE.json: sh_deg 3, eval', ['--sh-deg', '3', '--mode', 'eval']),
 ]
 
 
@@ -838,7 +838,7 @@ def run_config(args, rank, world, dev, dist):
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
                     'kernel': ('whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages' if args.mode == 'train' and args.sh_deg is None
-                               else 'whole step (one-call step / render of the SH pair), wall clock incl. render stages' if args.sh_deg == 2
+                               else 'whole step (one-call step / render of the SH pair), wall clock incl. render stages' if args.sh_deg in (2, 3)
                                else 'whole step (register-chained kernels + stand-alone SH adjoint kernels, sequenced stage by stage), wall clock incl. render stages' if args.sh_deg is not None
                                else 'whole step (k_mlp_fwd_pair: 512-wide foreground, two wavefronts per SIMD; k_mlp_fwd background), wall clock incl. render stages'),
                     'algorithmic_gflop_per_step': round(fl * len(work) / 1e9, 1)}

@@ -614,9 +614,12 @@ __global__ __launch_bounds__(256 * HG_GROUPS) void k_head_grads_jobs(HeadJobs js
 // registers for the block's whole row range, d_coef is wave-uniform; a block's four wavefronts meet in LDS and add their sums with
 // one set of atomics.  HBM: 1 KB per row (a in, dd out) -- ~0.2 GB per benchmark step; few long blocks like k_head_grads.
 struct ShHeadJobs { ShHeadJob job[SH_HEAD_MAX_JOBS]; };
-template <int NB>
+// CPP: colour channels per pass over the block's rows.  The per-lane state is 5 x CPP x NB registers (two weight columns, two
+// weight-gradient columns, the bias sum): 3 x 9 coefficients fit in one pass, 3 x 16 (sh_deg 3) take one pass per channel -- the rows'
+// inputs are read again (1 KB per row and pass) and the data gradient dd accumulates over the passes (each row is written by one lane pair).
+template <int NB, int CPP>
 __global__ __launch_bounds__(256) void k_sh_head_bwd(ShHeadJobs js) {
-    constexpr int NC = 3 * NB, H2 = 128;
+    constexpr int NC = CPP * NB, H2 = 128;
     const ShHeadJob &j = js.job[blockIdx.y];
     if ((int)blockIdx.x >= j.n_blocks) return;
     const long n = j.n_units_dev ? (long)(*j.n_units_dev) * j.rows_per_unit : j.n_rows;
@@ -624,65 +627,72 @@ __global__ __launch_bounds__(256) void k_sh_head_bwd(ShHeadJobs js) {
     const long rb = (long)blockIdx.x * per, re = min(n, rb + per);
     if (rb >= re) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float w0[NC], w1[NC], a0[NC], a1[NC], bsum[NC];
+    __shared__ float acc[4][H2];
+    for (int c0 = 0; c0 < 3; c0 += CPP) {
+        float w0[NC], w1[NC], a0[NC], a1[NC], bsum[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        w0[c] = j.rgb_w[c * H2 + lane]; w1[c] = j.rgb_w[c * H2 + 64 + lane];
-        a0[c] = 0.f; a1[c] = 0.f; bsum[c] = 0.f;
-    }
-    // U rows per wavefront and iteration: all their loads are requested before the first product (the loop is latency-bound otherwise:
-    // one row at a time measured 0.30 ms per benchmark step)
-    constexpr int U = 4;
-    for (long r0 = rb + wave * U; r0 < re; r0 += 4 * U) {
-        float4 go[U], o[U];
-        float x0[U], x1[U], dx[U], dy[U], dz[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ok[u] = r0 + u < re;
-            const long r = ok[u] ? r0 + u : re - 1, ro = j.out_row0 + r, rt = j.tape_row0 + r;
-            go[u] = *reinterpret_cast<const float4 *>(j.d_out + ro * 4);
-            o[u] = *reinterpret_cast<const float4 *>(j.out + ro * 4);
-            const float *dv = j.dirs + (ro / j.rows_per_ray) * j.dir_stride;
-            dx[u] = dv[0]; dy[u] = dv[1]; dz[u] = dv[2];
-            x0[u] = j.dact[rt * H2 + lane]; x1[u] = j.dact[rt * H2 + 64 + lane];
+        for (int c = 0; c < NC; ++c) {
+            w0[c] = j.rgb_w[(c0 * NB + c) * H2 + lane]; w1[c] = j.rgb_w[(c0 * NB + c) * H2 + 64 + lane];
+            a0[c] = 0.f; a1[c] = 0.f; bsum[c] = 0.f;
         }
+        // U rows per wavefront and iteration: all their loads are requested before the first product (the loop is latency-bound otherwise:
+        // one row at a time measured 0.30 ms per benchmark step)
+        constexpr int U = 4;
+        for (long r0 = rb + wave * U; r0 < re; r0 += 4 * U) {
+            float4 go[U], o[U];
+            float x0[U], x1[U], dx[U], dy[U], dz[U], p0[U], p1[U];
+            bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float b[25];
-            sh_basis(j.sh_deg, dx[u], dy[u], dz[u], b);
-            const float m = ok[u] ? 1.f : 0.f;
-            const float g[3] = {m * go[u].x * (o[u].x * (1.f - o[u].x)), m * go[u].y * (o[u].y * (1.f - o[u].y)), m * go[u].z * (o[u].z * (1.f - o[u].z))};
-            float d0 = 0.f, d1 = 0.f;
+            for (int u = 0; u < U; ++u) {
+                ok[u] = r0 + u < re;
+                const long r = ok[u] ? r0 + u : re - 1, ro = j.out_row0 + r, rt = j.tape_row0 + r;
+                go[u] = *reinterpret_cast<const float4 *>(j.d_out + ro * 4);
+                o[u] = *reinterpret_cast<const float4 *>(j.out + ro * 4);
+                const float *dv = j.dirs + (ro / j.rows_per_ray) * j.dir_stride;
+                dx[u] = dv[0]; dy[u] = dv[1]; dz[u] = dv[2];
+                x0[u] = j.dact[rt * H2 + lane]; x1[u] = j.dact[rt * H2 + 64 + lane];
+                p0[u] = 0.f; p1[u] = 0.f;
+                if (CPP < 3 && c0 > 0) { p0[u] = j.dd[ro * H2 + lane]; p1[u] = j.dd[ro * H2 + 64 + lane]; }
+            }
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int u = 0; u < U; ++u) {
+                float b[25];
+                sh_basis(j.sh_deg, dx[u], dy[u], dz[u], b);
+                const float m = ok[u] ? 1.f : 0.f;
+                const float g[3] = {m * go[u].x * (o[u].x * (1.f - o[u].x)), m * go[u].y * (o[u].y * (1.f - o[u].y)), m * go[u].z * (o[u].z * (1.f - o[u].z))};
+                float d0 = p0[u], d1 = p1[u];
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    const float dc = g[c] * b[k];
-                    d0 = fmaf(dc, w0[c * NB + k], d0); d1 = fmaf(dc, w1[c * NB + k], d1);
-                    a0[c * NB + k] = fmaf(dc, x0[u], a0[c * NB + k]); a1[c * NB + k] = fmaf(dc, x1[u], a1[c * NB + k]);
-                    bsum[c * NB + k] += dc;
+                for (int c = 0; c < CPP; ++c) {
+                    const float gc = CPP == 3 ? g[c] : (c0 == 0 ? g[0] : (c0 == 1 ? g[1] : g[2]));
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        const float dc = gc * b[k];
+                        d0 = fmaf(dc, w0[c * NB + k], d0); d1 = fmaf(dc, w1[c * NB + k], d1);
+                        a0[c * NB + k] = fmaf(dc, x0[u], a0[c * NB + k]); a1[c * NB + k] = fmaf(dc, x1[u], a1[c * NB + k]);
+                        bsum[c * NB + k] += dc;
+                    }
                 }
-            if (ok[u]) {
-                const long ro = j.out_row0 + r0 + u;
-                j.dd[ro * H2 + lane] = d0; j.dd[ro * H2 + 64 + lane] = d1;
+                if (ok[u]) {
+                    const long ro = j.out_row0 + r0 + u;
+                    j.dd[ro * H2 + lane] = d0; j.dd[ro * H2 + 64 + lane] = d1;
+                }
             }
         }
-    }
-    // combine the four wavefronts: NC x 128 sums in passes of one coefficient row (128 floats per wavefront) to stay inside 64 KB of LDS
-    __shared__ float acc[4][H2];
+        // combine the four wavefronts: NC x 128 sums in passes of one coefficient row (128 floats per wavefront) to stay inside 64 KB of LDS
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        acc[wave][lane] = a0[c]; acc[wave][64 + lane] = a1[c];
-        __syncthreads();
-        if (threadIdx.x < H2) atomicAdd(j.d_rgb_w + c * H2 + threadIdx.x, acc[0][threadIdx.x] + acc[1][threadIdx.x] + acc[2][threadIdx.x] + acc[3][threadIdx.x]);
-        __syncthreads();
-    }
-    // bias sums are wave-uniform: lane c of every wavefront carries coefficient c
-    float mine = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            acc[wave][lane] = a0[c]; acc[wave][64 + lane] = a1[c];
+            __syncthreads();
+            if (threadIdx.x < H2)
+                atomicAdd(j.d_rgb_w + (c0 * NB + c) * H2 + threadIdx.x, acc[0][threadIdx.x] + acc[1][threadIdx.x] + acc[2][threadIdx.x] + acc[3][threadIdx.x]);
+            __syncthreads();
+        }
+        // bias sums are wave-uniform: lane c of every wavefront carries coefficient c
+        float mine = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) mine = lane == c ? bsum[c] : mine;
-    if (lane < NC) atomicAdd(j.d_rgb_b + lane, mine);
+        for (int c = 0; c < NC; ++c) mine = lane == c ? bsum[c] : mine;
+        if (lane < NC) atomicAdd(j.d_rgb_b + c0 * NB + lane, mine);
+    }
 }
 
 }  // namespace mnr
@@ -720,8 +730,9 @@ int mnr::sh_head_bwd_jobs(const ShHeadJob *jobs, int n_jobs, hipStream_t s) {
     }
     const dim3 grid((unsigned)max_blocks, (unsigned)n_jobs);
     switch (jobs[0].sh_deg) {
-        case 2: hipLaunchKernelGGL(k_sh_head_bwd<9>, grid, dim3(256), 0, s, js); break;
-        default: return set_err(MNR_E_UNSUPPORTED, "the fused colour-head adjoint is instantiated for sh_deg 2 (configs/mega-nerf-sh-3)");
+        case 2: hipLaunchKernelGGL((k_sh_head_bwd<9, 3>), grid, dim3(256), 0, s, js); break;
+        case 3: hipLaunchKernelGGL((k_sh_head_bwd<16, 1>), grid, dim3(256), 0, s, js); break;
+        default: return set_err(MNR_E_UNSUPPORTED, "the fused colour-head adjoint is instantiated for sh_deg 2 (configs/mega-nerf-sh-3) and 3");
     }
     return check_launch("k_sh_head_bwd");
 }
@@ -830,14 +841,16 @@ int mnr::mlp_backward_chain_multi_impl(const mnr_mlp_grad_launch *segs, int n_se
         const mnr_model_desc *d = segs[i].desc;
         const bool trunk = (d->xyz_dim == 3 || d->xyz_dim == 4) && d->pos_xyz_dim == 12 && d->appearance_dim == 48 && d->layer_dim == 256 &&
                            d->layers == 8 && d->skip_mask == 16 && (d->mfma_tile == 0 || d->mfma_tile == 16);
-        const int p = !trunk ? 0 : (d->pos_dir_dim == 4 && d->rgb_dim == 3 ? 1 : (d->pos_dir_dim == 0 && d->rgb_dim == 27 ? 2 : 0));
+        const int p = !trunk ? 0 : (d->pos_dir_dim == 4 && d->rgb_dim == 3 ? 1 : (d->pos_dir_dim == 0 && d->rgb_dim == 27 ? 2 : (d->pos_dir_dim == 0 && d->rgb_dim == 48 ? 3 : 0)));
         if (p == 0 || (pair >= 0 && p != pair))
-            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_backward_data_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2) form");
+            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_backward_data_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2 / 3) forms");
         pair = p;
     }
     if (pair == 1)
         return mlp_backward_chain_multi_pair<MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>, MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>>(segs, n_segs, cells, s);
 #ifdef MNR_ALL_VARIANTS
+    if (pair == 3)
+        return mlp_backward_chain_multi_pair<MlpCfg<3, 12, 0, 48, 256, 8, 16, 48, 16>, MlpCfg<4, 12, 0, 48, 256, 8, 16, 48, 16>>(segs, n_segs, cells, s);
     return mlp_backward_chain_multi_pair<MlpCfg<3, 12, 0, 48, 256, 8, 16, 27, 16>, MlpCfg<4, 12, 0, 48, 256, 8, 16, 27, 16>>(segs, n_segs, cells, s);
 #else
     return set_err(MNR_E_UNSUPPORTED, "built without MNR_ALL_VARIANTS: no spherical-harmonics multi-segment kernels");

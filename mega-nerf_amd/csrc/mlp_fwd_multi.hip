@@ -10,13 +10,14 @@ using namespace mnr;
 using CfgFG = MlpCfg<3, 12, 4, 48, 256, 8, 16, 3, 16>;
 using CfgBG = MlpCfg<4, 12, 4, 48, 256, 8, 16, 3, 16>;
 
-// 0: not a multi-launch architecture; 1: the default pair; 2: the spherical-harmonics pair (sh_deg 2: rgb_dim 27, no direction encoding)
+// 0: not a multi-launch architecture; 1: the default pair; 2 / 3: the spherical-harmonics pair of that degree (rgb_dim 27 / 48, no direction encoding)
 static int pair_of(const mnr_model_desc *d) {
     const bool trunk = (d->xyz_dim == 3 || d->xyz_dim == 4) && d->pos_xyz_dim == 12 && d->appearance_dim == 48 && d->layer_dim == 256 &&
                        d->layers == 8 && d->skip_mask == 16 && (d->mfma_tile == 0 || d->mfma_tile == 16);
     if (!trunk) return 0;
     if (d->pos_dir_dim == 4 && d->rgb_dim == 3) return 1;
     if (d->pos_dir_dim == 0 && d->rgb_dim == 27) return 2;
+    if (d->pos_dir_dim == 0 && d->rgb_dim == 48) return 3;
     return 0;
 }
 
@@ -27,7 +28,7 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
         MNR_REQUIRE(segs[i].desc, "segment %d: NULL pointer argument", i);
         const int p = pair_of(segs[i].desc);
         if (p == 0 || (pair >= 0 && p != pair))
-            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_forward_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2) form");
+            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_forward_multi covers the default 8x256 fg / bg models and their spherical-harmonics (sh_deg 2 / 3) forms");
         pair = p;
     }
 #ifdef MNR_EXPERIMENT_8WAVES
@@ -42,7 +43,7 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
         if (ok) return mlp_forward_multi_pair<CfgFG, CfgBG, 8>(segs, n_segs, cells, s);
     }
 #endif
-    return pair == 1 ? mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s) : mlp_forward_multi_sh(segs, n_segs, cells, s);
+    return pair == 1 ? mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s) : mlp_forward_multi_sh(segs, n_segs, cells, pair, s);
 }
 
 extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {

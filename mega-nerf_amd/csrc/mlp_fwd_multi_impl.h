@@ -57,7 +57,7 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
     return check_launch("k_mlp_fwd_multi");
 }
 
-// the pair of the spherical-harmonics configuration (mlp_fwd_multi_sh.hip)
-int mlp_forward_multi_sh(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s);
+// the pairs of the spherical-harmonics configurations, sh_deg 2 or 3 (mlp_fwd_multi_sh.hip)
+int mlp_forward_multi_sh(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, int sh_deg, hipStream_t s);
 
 }  // namespace mnr

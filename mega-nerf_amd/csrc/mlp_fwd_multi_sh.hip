@@ -5,8 +5,10 @@
 
 using namespace mnr;
 
-int mnr::mlp_forward_multi_sh(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
+int mnr::mlp_forward_multi_sh(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, int sh_deg, hipStream_t s) {
 #ifdef MNR_ALL_VARIANTS
+    if (sh_deg == 3)      // 48 coefficients: the degree BASELINE.json's configs[4] words (the shipped yaml files say 2)
+        return mlp_forward_multi_pair<MlpCfg<3, 12, 0, 48, 256, 8, 16, 48, 16>, MlpCfg<4, 12, 0, 48, 256, 8, 16, 48, 16>>(segs, n_segs, cells, s);
     using CfgFG = MlpCfg<3, 12, 0, 48, 256, 8, 16, 27, 16>;
     using CfgBG = MlpCfg<4, 12, 0, 48, 256, 8, 16, 27, 16>;
     return mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s);

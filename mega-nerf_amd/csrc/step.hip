@@ -137,11 +137,12 @@ static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mn
                        (bg->mfma_tile == 0 || bg->mfma_tile == 16);
     const bool plain = fg->pos_dir_dim == 4 && bg->pos_dir_dim == 4 && fg->rgb_dim == 3 && bg->rgb_dim == 3;
     // configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0 -> 27 colour coefficients, dir_a_encoding over [features | appearance]
-    const bool sh2 = fg->pos_dir_dim == 0 && bg->pos_dir_dim == 0 && fg->rgb_dim == 27 && bg->rgb_dim == 27;
-    if (!trunk || !(plain || sh2))
-        return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models and their sh_deg 2 form");
-    if (sh2 && cfg->split_precision) return set_err(MNR_E_UNSUPPORTED, "no split-precision kernels for the spherical-harmonics colour head");
-    D.sh_deg = sh2 ? 2 : -1;
+    // (48 coefficients: sh_deg 3, the degree BASELINE.json's configs[4] words)
+    const bool sh = fg->pos_dir_dim == 0 && bg->pos_dir_dim == 0 && fg->rgb_dim == bg->rgb_dim && (fg->rgb_dim == 27 || fg->rgb_dim == 48);
+    if (!trunk || !(plain || sh))
+        return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models and their sh_deg 2 / 3 forms");
+    if (sh && cfg->split_precision) return set_err(MNR_E_UNSUPPORTED, "no split-precision kernels for the spherical-harmonics colour head");
+    D.sh_deg = !sh ? -1 : (fg->rgb_dim == 27 ? 2 : 3);
     return MNR_OK;
 }
 
@@ -1472,7 +1473,7 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
     int rc = render_dims_ok(N, Nc, Nf);
     if (rc != MNR_OK) return rc;
     // spherical-harmonics models (rgb_dim = 3 (deg + 1)^2 coefficients, configs/mega-nerf-sh-3: deg 2): colour epilogue inside the MLP launches
-    const int sh_deg = r->fg->rgb_dim == 27 && r->bg->rgb_dim == 27 ? 2 : -1;
+    const int sh_deg = r->fg->rgb_dim == 27 && r->bg->rgb_dim == 27 ? 2 : (r->fg->rgb_dim == 48 && r->bg->rgb_dim == 48 ? 3 : -1);
     MNR_REQUIRE(sh_deg < 0 || !r->split_precision, "no split-precision kernels for the spherical-harmonics colour head");
     RenderWs L;
     render_layout(N, Nc, Nf, L);

@@ -331,12 +331,16 @@ class NeRF(nn.Module):
                 list(self.skip_layers) == [4] and self.layer_dim == 512 and self.appearance_dim == 48 and self.rgb_dim == 3 and
                 self.embedding_a is not None and self.affine is None and self.mfma_tile in (0, 16))
 
-    def is_sh2_arch(self) -> bool:
+    def is_sh_arch(self, sh_deg: int = 2) -> bool:
         """True for the default architectures in their spherical-harmonics form (configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0
-        -- 27 colour coefficients, no direction encoding): the second pair the multi-segment launches are instantiated for."""
-        return (self.xyz_dim in (3, 4) and self.pos_xyz_dim == 12 and self.pos_dir_dim == 0 and self.layers == 8 and
-                list(self.skip_layers) == [4] and self.layer_dim == 256 and self.appearance_dim == 48 and self.rgb_dim == 27 and
+        -- 27 colour coefficients, no direction encoding; sh_deg 3 -- 48 coefficients -- is the degree BASELINE.json words): the further
+        pairs the multi-segment launches are instantiated for."""
+        return (sh_deg in (2, 3) and self.xyz_dim in (3, 4) and self.pos_xyz_dim == 12 and self.pos_dir_dim == 0 and self.layers == 8 and
+                list(self.skip_layers) == [4] and self.layer_dim == 256 and self.appearance_dim == 48 and self.rgb_dim == 3 * (sh_deg + 1) ** 2 and
                 self.embedding_a is not None and self.affine is None and self.mfma_tile in (0, 16))
+
+    def is_sh2_arch(self) -> bool:
+        return self.is_sh_arch(2)
 
     def fused_train_supported(self) -> bool:
         """True if the fused training kernels (activation tape + hand-written backward) cover this architecture."""

@@ -393,16 +393,16 @@ def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_d
         return False
     if (hparams.coarse_samples, hparams.fine_samples) not in ((64, 128), (256, 512)):
         return False
-    # the default models, or their spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; fp32 kernels only)
+    # the default models, or their spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; also sh_deg 3; fp32 kernels only)
     sh = hparams.sh_deg is not None and hparams.pos_dir_dim == 0
-    if sh and (hparams.sh_deg != 2 or SPLIT_PRECISION):
+    if sh and (hparams.sh_deg not in (2, 3) or SPLIT_PRECISION):
         return False
     for m in (nerf, bg_nerf):
         if not isinstance(m, NeRF) or m.training:
             return False
         # default 8 x 256, its sh_deg 2 form, or (fp32 kernels only) the 512-wide Building shape on the wavefront-pair kernel
         wide = m.is_wide_default_arch() and not sh and not SPLIT_PRECISION and os.environ.get('MNR_NO_PAIR_KERNEL') is None
-        if not ((m.is_sh2_arch() if sh else m.is_default_arch()) or wide):
+        if not ((m.is_sh_arch(hparams.sh_deg) if sh else m.is_default_arch()) or wide):
             return False
     return nerf.xyz_dim == 3 and bg_nerf.xyz_dim == 4
 

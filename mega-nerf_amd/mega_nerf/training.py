@@ -717,7 +717,7 @@ def render_rays_train(nerf: nn.Module, bg_nerf: Optional[nn.Module], rays: torch
 
 def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int, split_precision: bool = False) -> bool:
     """True if mnr_train_step (csrc/step.hip) covers this configuration: the default foreground / background architectures or their
-    spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; fp32 kernels only), no cascade, 64 + 128 or 256 + 512
+    spherical-harmonics form (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0; also sh_deg 3; fp32 kernels only), no cascade, 64 + 128 or 256 + 512
     samples per ray, background rows of a batch filling whole 64-row tiles."""
     import os
     from mega_nerf.models.nerf import NeRF
@@ -727,7 +727,7 @@ def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int, split_precision: b
         return False
     sh = hparams.sh_deg is not None and hparams.pos_dir_dim == 0
     if sh:
-        if hparams.sh_deg != 2 or split_precision or not (nerf.is_sh2_arch() and bg_nerf.is_sh2_arch()):
+        if hparams.sh_deg not in (2, 3) or split_precision or not (nerf.is_sh_arch(hparams.sh_deg) and bg_nerf.is_sh_arch(hparams.sh_deg)):
             return False
     elif hparams.sh_deg is not None or not (_fast_path_ok(nerf, bg_nerf, hparams) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
         return False

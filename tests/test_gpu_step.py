@@ -23,9 +23,10 @@ def _grads(models):
     return {'%s.%s' % (t, k): p.grad.detach().cpu().numpy().copy() for t, m in models for k, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize('name', ['render_fgbg_train', 'render_sh2_256_train'])
+@pytest.mark.parametrize('name', ['render_fgbg_train', 'render_sh2_256_train', 'render_sh3_256_train'])
 def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
-    """render_fgbg_train / render_sh2_256_train (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0 -- the colour head's adjoint runs in
+    """render_fgbg_train / render_sh2_256_train / render_sh3_256_train (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0, and the
+    degree-3 head BASELINE.json words -- the colour head's adjoint runs in
     k_sh_head_bwd inside the step) on the reference's captured random draws: loss, rgb_fine, depth variance, bg_lambda and every parameter
     gradient of ONE mnr_train_step call against (i) the stage-by-stage path on the same random numbers -- same kernels for the
     MLP, restated kernels for the ray stages: equal up to the summation order of the atomically accumulated head / embedding
@@ -65,11 +66,12 @@ def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
 
 
 def _cell(seed, n_rays, sh=False):
-    """A cell of the benchmark's kind: default fg + bg models (``sh``: their sh_deg 2 form) with their own weights, their own batch."""
+    """A cell of the benchmark's kind: default fg + bg models (``sh``: their spherical-harmonics form of that degree; True = 2) with their
+    own weights, their own batch."""
     from oracle import nerf_oracle as O
     from test_gpu_parity import native_nerf
     s = common.SCENE
-    hp = O.make_hparams(coarse_samples=64, fine_samples=128, **(dict(sh_deg=2, pos_dir_dim=0) if sh else {}))
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, **(dict(sh_deg=2 if sh is True else int(sh), pos_dir_dim=0) if sh else {}))
     fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
     fg = native_nerf(fcfg, common.make_weights(fcfg, s['appearance_count'], seed)).train()
     bg = native_nerf(bcfg, common.make_weights(bcfg, s['appearance_count'], seed + 500)).train()
@@ -80,7 +82,7 @@ def _cell(seed, n_rays, sh=False):
     return hp, fg, bg, (T(rays), T(idx.astype(np.int32)), T(tgt))
 
 
-@pytest.mark.parametrize('split,sh', [(False, False), (True, False), (False, True)], ids=['f32', 'split', 'f32-sh2'])
+@pytest.mark.parametrize('split,sh', [(False, False), (True, False), (False, True), (False, 3)], ids=['f32', 'split', 'f32-sh2', 'f32-sh3'])
 def test_cells_sharing_a_step_are_independent(split, sh):
     """Three cells (own weights, own batches, own optimiser moments) stepped by ONE plan -- their rows side by side in every MLP
     launch -- against the same cells stepped one plan each (cell c of a plan draws its random numbers with key seed + c, so a
@@ -187,7 +189,8 @@ def test_generated_random_numbers_are_uniform_and_keyed():
 
 
 @pytest.mark.parametrize('name,split', [('render_fgbg_eval', False), ('render_fgbg_eval', True), ('render_default_samples_eval', False),
-                                        ('render_default_samples_eval', True), ('render_sh2_eval', False), ('render_w512_eval', False)])
+                                        ('render_default_samples_eval', True), ('render_sh2_eval', False), ('render_sh3_eval', False),
+                                        ('render_w512_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches) against the stage-by-stage render -- identical outputs, bit for bit, for the fp32 kernels --
     and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
