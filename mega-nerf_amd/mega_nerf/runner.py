@@ -417,6 +417,36 @@ class Runner:
                              md['intrinsics'] / scale_factor, image_index,
                              None if (is_val and self.hparams.all_val) else mask_path, is_val)
 
+    # anchor colours of the depth ramp (dark violet -> magenta -> orange -> pale yellow, 0 = dark); the reference maps through OpenCV's
+    # COLORMAP_INFERNO table (runner.py:610) -- OpenCV is not part of this image, so the ramp is piecewise linear through these anchors:
+    # same ordering and endpoints, colours differ by a few counts in between (visualisation only, nothing reads these images back)
+    _RAMP = np.array([[0, 0, 4], [40, 11, 84], [101, 21, 110], [159, 42, 99], [212, 72, 66], [245, 125, 21], [250, 193, 39], [252, 255, 164]],
+                     dtype=np.float32)
+
+    @staticmethod
+    def visualize_scalars(scalar_tensor: torch.Tensor) -> np.ndarray:
+        """(H, W) scalars -> (H, W, 3) uint8 heat map: normalised between the 5 % and 95 % quantiles, inverted (near = bright), as
+        runner.py:598-610 does for the depth panels."""
+        to_use = scalar_tensor.reshape(-1).float()
+        while to_use.shape[0] > 2 ** 24:
+            to_use = to_use[::2]
+        mi, ma = torch.quantile(to_use, 0.05), torch.quantile(to_use, 0.95)
+        t = ((scalar_tensor.float() - mi) / max(float(ma - mi), 1e-8)).clamp(0, 1)
+        level = ((1 - t) * 255).byte().cpu().numpy().astype(np.float32) / 255.0
+        ramp = Runner._RAMP
+        x = level * (len(ramp) - 1)
+        i0 = np.minimum(x.astype(np.int64), len(ramp) - 2)
+        f = (x - i0)[..., None]
+        return (ramp[i0] * (1 - f) + ramp[i0 + 1] * f + 0.5).astype(np.uint8)
+
+    @staticmethod
+    def _create_result_image(rgbs: torch.Tensor, result_rgbs: torch.Tensor, result_depths: torch.Tensor):
+        """ground truth | render | log-depth heat map side by side (runner.py:591-595)."""
+        from PIL import Image
+        depth_vis = Runner.visualize_scalars(torch.log(result_depths + 1e-8).view(rgbs.shape[0], rgbs.shape[1]).cpu())
+        images = ((rgbs * 255).cpu().numpy(), (result_rgbs * 255).cpu().numpy(), depth_vis)
+        return Image.fromarray(np.concatenate(images, 1).astype(np.uint8))
+
     def _get_experiment_path(self) -> Path:
         exp_dir = Path(self.hparams.exp_name)
         exp_dir.mkdir(parents=True, exist_ok=True)

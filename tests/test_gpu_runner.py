@@ -159,3 +159,60 @@ def test_sh_config_trains_through_the_fused_step_and_evaluates(tmp_path):
         return float([ln for ln in text.splitlines() if ln.startswith('Average ' + key)][0].split(':')[1])
     a, b = metric(m_train, 'val/psnr'), metric(m_eval, 'val/psnr')
     assert abs(a - b) < 0.05 and a > 5.0, (a, b)
+
+
+def test_render_images_script_writes_the_reference_tree(tmp_path):
+    """scripts/render_images.py (reference scripts/render_images.py:19-144): poses / intrinsics / embeddings text files in, rgbs / depths /
+    cells (+ depths_npz) out; the rgb files are the Runner.render_image colours of the same pose (up to JPEG), --resume skips finished poses."""
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    from mega_nerf import train as tr
+    from mega_nerf.image_metadata import ImageMetadata
+    from mega_nerf.runner import Runner
+    data = _dataset(tmp_path)
+    exp = tmp_path / 'exp'
+    tr.main(_hparams(data, exp, ['--train_iterations', '10', '--ckpt_interval', '10']))
+    ckpt = exp / '0' / 'models' / '10.pt'
+    inp = tmp_path / 'poses'
+    inp.mkdir()
+    mds = [torch.load(p, map_location='cpu', weights_only=False) for p in sorted((data / 'val' / 'metadata').iterdir())]
+    (inp / 'poses.txt').write_text('\n'.join(' '.join('%.9g' % float(x) for x in md['c2w'].reshape(-1)) for md in mds) + '\n')
+    (inp / 'intrinsics.txt').write_text('\n'.join('%d %d ' % (md['W'], md['H']) + ' '.join('%.9g' % float(x) for x in md['intrinsics']) for md in mds) + '\n')
+    (inp / 'embeddings.txt').write_text('\n'.join(str(3 * k) for k in range(len(mds))) + '\n')
+    cen = tmp_path / 'params.pt'
+    torch.save({'centroids': torch.tensor([[0., -0.3, -0.3], [0., 0.3, -0.3], [0., -0.3, 0.3], [0., 0.3, 0.3]])}, cen)
+    spec = importlib.util.spec_from_file_location('render_images', ROOT / 'mega-nerf_amd' / 'scripts' / 'render_images.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / 'renders'
+    argv = ['--dataset_path', str(data), '--coarse_samples', '64', '--fine_samples', '128', '--near', '0.01', '--ray_altitude_range', '-0.5', '0.2',
+            '--val_scale_factor', '1', '--ckpt_path', str(ckpt), '--input', str(inp), '--output', str(out), '--centroids_path', str(cen),
+            '--save_depth_npz']
+    mod.main(mod._get_render_opts(argv))
+    n = len(mds)
+    for sub, ext in (('rgbs', 'jpg'), ('depths', 'jpg'), ('cells', 'jpg'), ('depths_npz', 'npy')):
+        assert sorted(p.name for p in (out / sub).iterdir()) == ['%06d.%s' % (i, ext) for i in range(n)], sub
+    # the written colours are the renderer's
+    hp = mod._get_render_opts(argv)
+    r = Runner(hp, False)
+    r.nerf.eval(), r.bg_nerf.eval()
+    md = mds[1]
+    with torch.inference_mode():
+        res, _ = r.render_image(ImageMetadata(Path(''), md['c2w'], md['W'], md['H'], md['intrinsics'], 3, None, False))
+    want = (res['rgb_fine'].view(md['H'], md['W'], 3) * 255).byte().cpu().numpy().astype(np.float64)
+    got = np.array(Image.open(out / 'rgbs' / '000001.jpg')).astype(np.float64)
+    assert got.shape == want.shape
+    assert 10 * np.log10(255.0 ** 2 / np.mean((got - want) ** 2)) > 28.0           # JPEG quality 75 of a smooth 32 x 32 render
+    depth = np.load(out / 'depths_npz' / '000001.npy')
+    np.testing.assert_allclose(depth, torch.nan_to_num(res['depth_fine']).view(md['H'], md['W']).cpu().numpy() * r.pose_scale_factor, rtol=1e-5)
+    vis = np.array(Image.open(out / 'cells' / '000000.jpg'))
+    assert vis.shape == (md['H'], md['W'], 3)
+    # --resume: finished poses are skipped (their files keep their timestamps), a missing one is rendered again
+    stamp = (out / 'rgbs' / '000000.jpg').stat().st_mtime_ns
+    (out / 'cells' / '000001.jpg').unlink()
+    mod.main(mod._get_render_opts(argv + ['--resume']))
+    assert (out / 'rgbs' / '000000.jpg').stat().st_mtime_ns == stamp and (out / 'cells' / '000001.jpg').exists()
+    # without --resume an existing output tree is refused, as the reference's mkdir(exist_ok=False) does
+    with pytest.raises(FileExistsError):
+        mod.main(mod._get_render_opts(argv))
