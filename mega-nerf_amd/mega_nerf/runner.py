@@ -338,6 +338,7 @@ class Runner:
                 sums['val/psnr'] += val_psnr
                 sums['val/ssim'] += val_ssim
                 count += 1
+                self._save_validation_images(train_index, i, gt, results, typ)
             self.nerf.train(was_training)
             if self.bg_nerf is not None:
                 self.bg_nerf.train(bg_was)
@@ -345,6 +346,31 @@ class Runner:
         sums.setdefault('val/ssim', 0.0)
         total, _ = mdist.all_reduce_metrics(dict(sums), count, self.device)
         return total
+
+    def _save_validation_images(self, train_index: int, i: int, gt: torch.Tensor, results: Dict[str, torch.Tensor], typ: str) -> None:
+        """ground truth | render | log-depth panels of validation image ``i`` (+ the background / foreground panels), the images the
+        reference hands to its TensorBoard writer (runner.py:452-491); there is no TensorBoard here, so the rank that owns the experiment
+        directory writes them to <experiment>/val_images/<iteration>/.  MNR_NO_VAL_IMAGES=1 skips it."""
+        path = getattr(self, 'experiment_path', None)
+        if path is None or os.environ.get('MNR_NO_VAL_IMAGES'):
+            return
+        out = path / 'val_images' / str(train_index)
+        out.mkdir(parents=True, exist_ok=True)
+        H, W = gt.shape[0], gt.shape[1]
+
+        def panel(rgb_key: str, depth_key: str, clamp_to: Optional[str], name: str) -> None:
+            depth = torch.nan_to_num(results[depth_key]).view(-1)
+            if clamp_to is not None and clamp_to in results:      # background depths are inverse-sphere quantities (quirk Q2): clamp for display
+                to_use = torch.nan_to_num(results[clamp_to]).view(-1)
+                while to_use.shape[0] > 2 ** 24:
+                    to_use = to_use[::2]
+                depth = depth.clamp_max(torch.quantile(to_use, 0.95))
+            Runner._create_result_image(gt, results[rgb_key].view(H, W, 3), depth).save(str(out / name))
+
+        panel(f'rgb_{typ}', f'depth_{typ}', f'fg_depth_{typ}', '{}.jpg'.format(i))
+        if self.hparams.bg_nerf and f'bg_rgb_{typ}' in results:
+            panel(f'bg_rgb_{typ}', f'bg_depth_{typ}', None, '{}_bg.jpg'.format(i))
+            panel(f'fg_rgb_{typ}', f'fg_depth_{typ}', None, '{}_fg.jpg'.format(i))
 
     def _save_checkpoint(self, optimizers: Dict[str, any], scaler, train_index: int, dataset_index: int,
                          dataset_state: Optional[str], epoch: int = 0) -> None:

@@ -41,6 +41,10 @@ def test_train_then_eval_entry_points(tmp_path):
     assert 'Average val/psnr' in m_train
     for f in ('hparams.txt', 'command.txt', 'image_indices.txt'):
         assert (run0 / f).exists()
+    # the validation panels the reference hands to TensorBoard (runner.py:452-491): ground truth | render | depth, + bg / fg panels
+    from PIL import Image
+    for name in ('0.jpg', '1.jpg', '0_bg.jpg', '0_fg.jpg'):
+        assert Image.open(run0 / 'val_images' / '40' / name).size == (3 * 32, 32), name
     # evaluation of the checkpoint through eval.py reproduces the validation PSNR written after training
     ev.main(parse(['--exp_name', str(exp), '--ckpt_path', str(run0 / 'models' / '40.pt')]))
     m_eval = (exp / '1' / 'metrics.txt').read_text()
