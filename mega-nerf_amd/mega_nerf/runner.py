@@ -196,8 +196,8 @@ class Runner:
             # the one-call step gathers its batch itself from the resident arrays (training.GatheredBatch): the loop then enqueues NO torch
             # kernel per iteration; every other path gets materialised batches
             source = dataset.gather_source() if trainer is not None else None
-            feed = dataset.index_batches(hp.batch_size, gen) if trainer is not None else dataset.batches(hp.batch_size, gen)
-            for dataset_index, item in enumerate(feed):
+            # the epoch as row selections: a rank materialises (gathers) only the batches it trains on
+            for dataset_index, item in enumerate(dataset.index_batches(hp.batch_size, gen)):
                 if dataset_index < discard or dataset_index >= usable or dataset_index % world != rank:
                     continue
                 if trainer is not None:
@@ -222,6 +222,7 @@ class Runner:
                     if last:
                         break
                     continue
+                item = dataset[item]
                 image_indices = item['img_indices'] if hp.appearance_dim > 0 else None
                 metrics, bg_present = self._training_step(item['rgbs'], item['rays'], image_indices)
                 for key, val in metrics.items():
