@@ -49,7 +49,7 @@ def _rows(path: Path):
 
 def _hue_wheel(h: torch.Tensor) -> torch.Tensor:
     """hue in [0, 1) -> fully saturated RGB in [0, 255] (..., 3)."""
-    k = (h.unsqueeze(-1) * 6 + torch.tensor([0., 4., 2.], device=h.device)) % 6
+    k = (h.unsqueeze(-1) * 6 + torch.tensor([5., 3., 1.], device=h.device)) % 6
     return (1 - torch.clamp(torch.minimum(k, 4 - k), 0, 1)) * 255
 
 

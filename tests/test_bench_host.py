@@ -143,6 +143,34 @@ def test_flag_set_is_the_reference_flag_set():
     assert (hp.lr, hp.lr_decay_factor, hp.train_iterations, hp.random_seed, hp.perturb) == (5e-4, 0.1, 500000, 42, 1.0)
 
 
+def test_script_flags_and_depth_ramp():
+    """scripts/render_images.py takes the reference script's flags on top of the base set (scripts/render_images.py:19-29 of the
+    reference), and Runner.visualize_scalars maps near -> bright, far -> dark between the 5 % / 95 % quantiles (runner.py:598-610)."""
+    import importlib.util
+    import numpy as np
+    import torch
+    from pathlib import Path
+    from mega_nerf.runner import Runner
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location('render_images', root / 'mega-nerf_amd' / 'scripts' / 'render_images.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hp = mod._get_render_opts(['--input', 'i', '--output', 'o', '--dataset_path', 'd', '--centroids_path', 'c'])
+    assert (hp.input, hp.output, hp.dataset_path, hp.centroids_path, hp.save_depth_npz, hp.resume) == ('i', 'o', 'd', 'c', False, False)
+    import pytest
+    with pytest.raises(SystemExit):
+        mod._get_render_opts(['--input', 'i'])                         # the other three are required, as in the reference
+    with pytest.raises(AssertionError):
+        mod.main(hp)                                                   # neither --ckpt_path nor --container_path (:137)
+    v = Runner.visualize_scalars(torch.linspace(0, 1, 40 * 50).view(40, 50))
+    assert v.shape == (40, 50, 3) and v.dtype == np.uint8
+    lum = v.astype(np.float64).sum(-1).reshape(-1)
+    assert (np.diff(lum) <= 0).all() and lum[0] > 600 and lum[-1] < 10             # monotone ramp, inverted
+    assert (v.reshape(-1, 3)[:100] == v[0, 0]).all() and (v.reshape(-1, 3)[-100:] == v[-1, -1]).all()   # clamped outside the quantiles
+    hue = mod._hue_wheel(torch.tensor([0.0, 1 / 3, 2 / 3]))
+    np.testing.assert_allclose(hue.numpy(), [[255, 0, 0], [0, 255, 0], [0, 0, 255]], atol=1e-3)
+
+
 def test_filesystem_dataset_refuses_a_cpu_device(tmp_path):
     import pytest
     import torch
