@@ -96,6 +96,9 @@ def main():
             e['parked_fraction_of_wave_cycles'] = round(med(r['SQ_WAIT_ANY'] / r['SQ_WAVE_CYCLES'] for r in rows if r.get('SQ_WAVE_CYCLES')), 4)
             e['valu_per_mfma_instruction'] = round(med(r['SQ_INSTS_VALU'] / r['SQ_INSTS_MFMA'] for r in rows if r.get('SQ_INSTS_MFMA')), 3) if any(r.get('SQ_INSTS_MFMA') for r in rows) else None
             e['cycles_per_xcd'] = int(med(r['GRBM_GUI_ACTIVE'] / 8 for r in rows))
+            # clock the kernel ran at (the fp32-MFMA peak is priced at 2.4 GHz: frac of peak ~ mfma_busy x clock / 2.4)
+            if e.get('median_duration_us_under_pmc'):
+                e['approx_clock_ghz'] = round(e['cycles_per_xcd'] / e['median_duration_us_under_pmc'] / 1e3, 3)
         out[key] = e
     try:
         sha = subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent)).stdout.strip()
