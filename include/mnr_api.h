@@ -264,6 +264,18 @@ typedef struct mnr_mlp_launch {
     int64_t tape_rows, tape_row0;
 } mnr_mlp_launch;
 int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream);
+/* Routed evaluations of SEVERAL merged models in one launch (mega_nerf.py:28-49 for the foreground container and the background
+ * container of one render pass, rendering.py:275-331): segment s = mnr_mlp_forward_cells(desc, cells_dev, n_cells, io) of one
+ * container.  The background's routed rows alone fill a fraction of the chip; side by side with the foreground's they only lengthen
+ * its tail.  Inference, the default 8x256 foreground / background architectures (MNR_E_UNSUPPORTED otherwise: one
+ * mnr_mlp_forward_cells per container). */
+typedef struct mnr_mlp_cells_launch {
+    const mnr_model_desc *desc;      /* architecture shared by the container's cells */
+    const mnr_mlp_cell *cells_dev;   /* device array [n_cells] */
+    int32_t n_cells;                 /* 1 .. 64 */
+    const mnr_mlp_io *io;            /* as for mnr_mlp_forward_cells */
+} mnr_mlp_cells_launch;
+int mnr_mlp_forward_cells_multi(const mnr_mlp_cells_launch *segs, int n_segs, void *stream);
 
 /* ---- opt-in split-precision inference (csrc/mlp_fwd_h2.hip) ------------------------------------------------
  * Same contract as mnr_mlp_forward_multi (inference segments only, default 8 x 256 fg / bg architectures), computed on the

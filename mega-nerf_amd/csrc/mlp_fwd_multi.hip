@@ -49,3 +49,19 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
 extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {
     return mlp_forward_multi_impl(segs, n_segs, nullptr, as_stream(stream));
 }
+
+// Routed evaluations of several merged models in one launch: segment = one container's cells (mnr_mlp_forward_cells semantics)
+extern "C" int mnr_mlp_forward_cells_multi(const mnr_mlp_cells_launch *segs, int n_segs, void *stream) {
+    MNR_REQUIRE(segs && n_segs >= 1 && n_segs <= MLP_MAX_SEGS, "1..%d segments per launch", MLP_MAX_SEGS);
+    mnr_mlp_launch L[MLP_MAX_SEGS] = {};
+    RoutedSeg R[MLP_MAX_SEGS];
+    for (int i = 0; i < n_segs; ++i) {
+        MNR_REQUIRE(segs[i].desc && segs[i].cells_dev && segs[i].io, "segment %d: NULL pointer argument", i);
+        if (pair_of(segs[i].desc) != 1)
+            return set_err(MNR_E_UNSUPPORTED, "mnr_mlp_forward_cells_multi covers containers of the default 8x256 fg / bg models");
+        L[i].desc = segs[i].desc;
+        L[i].io = segs[i].io;
+        R[i] = RoutedSeg{segs[i].cells_dev, segs[i].n_cells};
+    }
+    return mlp_forward_multi_pair<CfgFG, CfgBG>(L, n_segs, nullptr, as_stream(stream), R);
+}

@@ -9,15 +9,19 @@ namespace mnr {
 
 static inline long n_cells_of(const mnr_mlp_launch &L, const CellTable &c) { return c.cell_rows > 0 ? L.io->n_rows / c.cell_rows : 0; }
 
+// routed: per segment the device table of a merged container's cells (mnr_mlp_forward_cells_multi), else NULL
+struct RoutedSeg { const mnr_mlp_cell *cells; int n_cells; };
+
 template <class CfgFG, class CfgBG, int NW = 4>
-static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s) {
+static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s, const RoutedSeg *routed = nullptr) {
     constexpr int ROWS_WG = NW * CfgFG::TILE;
     MlpFwdMulti mm{};
     const bool train = segs[0].tape_dev != nullptr;
     long wg = 0;
     for (int i = 0; i < n_segs; ++i) {
         const mnr_mlp_launch &L = segs[i];
-        MNR_REQUIRE(L.packed_dev && L.desc && L.io && L.io->xyz && L.io->out, "segment %d: NULL pointer argument", i);
+        MNR_REQUIRE(L.desc && L.io && L.io->xyz && (routed || (L.packed_dev && L.io->out)), "segment %d: NULL pointer argument", i);
+        if (routed) MNR_REQUIRE(routed[i].cells && routed[i].n_cells >= 1 && routed[i].n_cells <= 64 && !cells && !train, "segment %d: bad cell table", i);
         MNR_REQUIRE((L.tape_dev != nullptr) == train, "segments must be all training or all inference launches");
         MNR_REQUIRE(!L.io->row_index && !L.io->sigma_only, "segment %d: gather / sigma_only are single-launch features", i);
         // spherical-harmonics pair: the colour epilogue (eval_sh + sigmoid) must be ON -- a multi-segment launch writes 4 floats per row
@@ -29,8 +33,10 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
         int rc = layout_from_desc(L.desc, m);
         if (rc != MNR_OK) return rc;
         const bool is_bg = L.desc->xyz_dim == 4;
-        rc = !is_bg ? fill_fwd_args<CfgFG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0)
-                    : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, nullptr, 0);
+        const mnr_mlp_cell *rcells = routed ? routed[i].cells : nullptr;
+        const int rn = routed ? routed[i].n_cells : 0;
+        rc = !is_bg ? fill_fwd_args<CfgFG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, rcells, rn)
+                    : fill_fwd_args<CfgBG>(mm.seg[i], m, L.packed_dev, L.desc, L.io, L.tape_dev, (long)L.tape_rows, (long)L.tape_row0, rcells, rn);
         if (rc != MNR_OK) return rc;
         if (cells && cells[i].dcells) {
             MNR_REQUIRE(cells[i].cell_rows > 0 && cells[i].cell_rows % ROWS_WG == 0 && L.io->n_rows % cells[i].cell_rows == 0,
@@ -45,7 +51,8 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
                         "multi-cell launch: every segment needs a cell table over the same number of cells");
             wg += cells[i].cell_rows / ROWS_WG;
         } else
-        wg += (L.io->n_rows + ROWS_WG - 1) / ROWS_WG;
+        // (routed: the worst case -- every row routed to every cell; workgroups past the device-side counts exit at once)
+        wg += (L.io->n_rows + ROWS_WG - 1) / ROWS_WG * (routed ? routed[i].n_cells : 1);
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;

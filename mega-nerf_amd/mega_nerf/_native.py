@@ -85,6 +85,11 @@ class MlpLaunch(C.Structure):
                 ('tape_rows', C.c_int64), ('tape_row0', C.c_int64)]
 
 
+class MlpCellsLaunch(C.Structure):
+    """struct mnr_mlp_cells_launch"""
+    _fields_ = [('desc', C.POINTER(ModelDesc)), ('cells_dev', C.c_void_p), ('n_cells', C.c_int32), ('io', C.POINTER(MlpIO))]
+
+
 class MlpGradLaunch(C.Structure):
     """struct mnr_mlp_grad_launch"""
     _fields_ = [('packed_fwd_dev', C.c_void_p), ('packed_bwd_dev', C.c_void_p), ('desc', C.POINTER(ModelDesc)),
@@ -192,7 +197,7 @@ EXPORTS = [
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
-    'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy',
+    'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy', 'mnr_mlp_forward_cells_multi',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -278,6 +283,7 @@ def lib() -> C.CDLL:
                                            C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.mnr_mlp_forward_cells.argtypes = [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.POINTER(MlpIO), C.c_void_p]
         _lib.mnr_mlp_forward_cells_h2.argtypes = [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.POINTER(MlpIO), C.c_void_p]
+        _lib.mnr_mlp_forward_cells_multi.argtypes = [C.POINTER(MlpCellsLaunch), C.c_int, C.c_void_p]
         _lib.mnr_fused_train_supported.argtypes = [C.POINTER(ModelDesc)]
         _lib.mnr_embed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]
         _lib.mnr_gather_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int,

@@ -34,6 +34,9 @@ KERNEL_EVENTS = None
 # (csrc/mlp_fwd_h2.hip: fp32-class accuracy -- 4.6e-7 per layer against fp64 -- at ~2.5x the speed).  The fp32 kernels are the
 # default and what every headline number is measured with.
 SPLIT_PRECISION = False
+# Merged containers: the foreground and the background container's routed evaluations of a pass share ONE launch
+# (mnr_mlp_forward_cells_multi); False = one launch per container (tests compare the two)
+MERGE_ROUTED = True
 
 _tables: Dict[Tuple[int, str], torch.Tensor] = {}
 _host_cache: Dict[int, tuple] = {}          # id(tensor) -> (weakref to it, version, host list)
@@ -177,6 +180,22 @@ def _serve(reqs) -> list:
             b.record()
             KERNEL_EVENTS.append(('fwd_%s' % reqs[0].typ, a, b))
         return outs
+    if len(reqs) > 1 and not split and MERGE_ROUTED:
+        # merged containers (foreground and background): both routed evaluations of the pass in ONE gather-mode launch
+        from mega_nerf.models.mega_nerf import MegaNeRF, evaluate_routed_together
+        if all(isinstance(q.nerf, MegaNeRF) for q in reqs):
+            outs = [_f(q.xyz.shape[0], q.S, 4, device=q.xyz.device) for q in reqs]
+            a = b = None
+            if KERNEL_EVENTS is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            hp = reqs[0].hparams
+            sh_deg = hp.sh_deg if (hp.pos_dir_dim == 0 and hp.sh_deg is not None) else -1
+            if evaluate_routed_together([(q.nerf, q.xyz, q.part, q.S, o, q.noise, sh_deg) for q, o in zip(reqs, outs)]):
+                if a is not None:
+                    b.record()
+                    KERNEL_EVENTS.append(('fwd_%s' % reqs[0].typ, a, b))
+                return outs
     return [_model_eval(q.nerf, q.typ, q.hparams, q.xyz, q.part, q.S, q.noise) for q in reqs]
 
 

@@ -79,6 +79,45 @@ def test_new_render_goldens(name):
         np.testing.assert_allclose(a, b, err_msg=k, **tol)
 
 
+def test_containers_of_a_pass_share_one_launch():
+    """render_container8_eval with the foreground and the background container's routed evaluations in ONE launch per pass
+    (mnr_mlp_forward_cells_multi, the default) against one launch per container: the same kernel bodies over the same rows -- every
+    output bit-identical; and the merged launch is what the default takes (checked through the C entry point's call count)."""
+    from mega_nerf import _native as N
+    from mega_nerf import rendering as R
+    g = load('render_container8_eval')
+    hp, nerf, bg_nerf = native_models('render_container8_eval')
+    s = common.SCENE
+    idx = T(g['idx'].astype(f32))
+    flags = [bool(v) for v in g['flags']]
+    calls = {'n': 0}
+    real = N.lib().mnr_mlp_forward_cells_multi
+
+    class Counting:
+        def __call__(self, *a):
+            calls['n'] += 1
+            return real(*a)
+
+    def render():
+        with torch.no_grad():
+            return R.render_rays(nerf, bg_nerf, T(g['rays']), idx, Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']), *flags)[0]
+
+    lib = N.lib()
+    try:
+        lib.mnr_mlp_forward_cells_multi = Counting()
+        merged = {k: v.cpu().numpy().copy() for k, v in render().items()}
+        assert calls['n'] == 2                       # coarse pass + fine pass
+        R.MERGE_ROUTED = False
+        single = {k: v.cpu().numpy().copy() for k, v in render().items()}
+        assert calls['n'] == 2
+    finally:
+        R.MERGE_ROUTED = True
+        lib.mnr_mlp_forward_cells_multi = real
+    assert merged.keys() == single.keys()
+    for k in merged:
+        np.testing.assert_array_equal(merged[k], single[k], err_msg=k)
+
+
 def all_ray_violations(res, ores, rnd, dbg, keys, rtol=1e-4, atol=2e-5):
     """Rays of a render that miss ``|a - b| <= atol + rtol |b|`` (the north-star 1e-4 relative bound) in any of ``keys``, with
     what is needed to explain them: the largest relative move of one of the ray's fine samples against the oracle's."""

@@ -85,7 +85,7 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
     if shutil.which('gcc') is None:
         pytest.skip('no C compiler')
     names = {'mnr_model_desc': N.ModelDesc, 'mnr_mlp_io': N.MlpIO, 'mnr_composite_io': N.CompositeIO, 'mnr_model_grads': N.ModelGrads,
-             'mnr_mlp_grad_io': N.MlpGradIO, 'mnr_composite_grad_io': N.CompositeGradIO, 'mnr_mlp_launch': N.MlpLaunch,
+             'mnr_mlp_grad_io': N.MlpGradIO, 'mnr_composite_grad_io': N.CompositeGradIO, 'mnr_mlp_launch': N.MlpLaunch, 'mnr_mlp_cells_launch': N.MlpCellsLaunch,
              'mnr_mlp_grad_launch': N.MlpGradLaunch, 'mnr_wgrad_region': N.WgradRegion, 'mnr_step_model': N.StepModel,
              'mnr_step_cfg': N.StepCfg, 'mnr_step_layout': N.StepLayout, 'mnr_step_batch': N.StepBatch, 'mnr_step_randoms': N.StepRandoms, 'mnr_render_io': N.RenderIO}
     src = tmp_path / 'sizes.c'
