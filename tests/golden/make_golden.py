@@ -513,6 +513,8 @@ def main(only=None):
     # round 4: the overfit regime (sampling decided by rounding), fp32 and fp64 runs of the reference on the same weights
     # ... and training gradients of the sh_deg 3 head (the degree BASELINE.json's configs[4] words) at the default width
     case('render_sh3_256_train', dict(base, sh_deg=3, pos_dir_dim=0), 32, 26, TR, fg_train=True, bg_train=True, with_grad=True)
+    # ... and at the reference's default sample counts (opts.py:32-35: 256 + 512 -- the other instantiation of the ray-stage kernels)
+    case('render_default_samples_train', dict(), 8, 27, TR, fg_train=True, bg_train=True, with_grad=True)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

@@ -135,6 +135,7 @@ RENDER_CASES = {
     'render_noapp256_train': dict(hp=dict(appearance_dim=0), seed=16, fg_train=True, bg_train=True),
     'render_sh3_eval': dict(hp=dict(sh_deg=3, pos_dir_dim=0), seed=21),
     'render_sh3_256_train': dict(hp=dict(sh_deg=3, pos_dir_dim=0), seed=26, fg_train=True, bg_train=True),
+    'render_default_samples_train': dict(hp=dict(coarse_samples=256, fine_samples=512), seed=27, fg_train=True, bg_train=True),
     'render_container8_eval': dict(hp=dict(container_path='dummy'), seed=22, container=8),
     'render_container_w512_eval': dict(hp=dict(container_path='dummy', layer_dim=512, bg_layer_dim=512), seed=23, container=4),
     'render_joint_train': dict(hp=dict(train_mega_nerf='dummy', layer_dim=64, bg_layer_dim=64), seed=17, container=4, joint=True,
