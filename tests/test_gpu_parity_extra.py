@@ -118,6 +118,36 @@ def test_containers_of_a_pass_share_one_launch():
         np.testing.assert_array_equal(merged[k], single[k], err_msg=k)
 
 
+def test_container_render_edge_batches():
+    """Merged containers on the batches the routed launches size worst: no ray of the batch reaches the background (the background
+    container's row lists are all empty: every workgroup of its segment exits on the device-side counts), one ray, and an empty batch
+    -- against the oracle's routed render (mega_nerf.py:19-61 over rendering.py:33-45)."""
+    from mega_nerf.rendering import render_rays
+    from test_oracle_golden import build_case
+    from oracle import nerf_oracle as O
+    name = 'render_container8_eval'
+    g = load(name)
+    hp, nerf, bg_nerf = native_models(name)
+    hpn = Namespace(**vars(hp))
+    s = common.SCENE
+    ohp, onerf, obg = build_case(name)
+    rays = g['rays'].copy()
+    rays[:, 7] = np.minimum(rays[:, 7], 0.3)              # far well inside the ellipsoid for every ray
+    idx = g['idx'].astype(f32)
+    for sel in (slice(None), slice(0, 1)):
+        want, present = O.render_rays(onerf, obg, rays[sel], idx[sel], ohp, s['sphere_center'], s['sphere_radius'], True, False, True)
+        assert not present
+        with torch.no_grad():
+            res, got_present = render_rays(nerf, bg_nerf, T(rays[sel]), T(idx[sel]), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+        assert got_present is False and sorted(res) == sorted(want)
+        for k in want:
+            np.testing.assert_allclose(res[k].cpu().numpy(), want[k], rtol=2e-4, atol=2e-5, err_msg=k)
+        assert float(res['bg_rgb_fine'].abs().max()) == 0.0
+    with torch.no_grad():
+        res0, p0 = render_rays(nerf, bg_nerf, T(rays[:0]), T(idx[:0]), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+    assert p0 is False and res0['rgb_fine'].shape == (0, 3)
+
+
 def all_ray_violations(res, ores, rnd, dbg, keys, rtol=1e-4, atol=2e-5):
     """Rays of a render that miss ``|a - b| <= atol + rtol |b|`` (the north-star 1e-4 relative bound) in any of ``keys``, with
     what is needed to explain them: the largest relative move of one of the ray's fine samples against the oracle's."""
