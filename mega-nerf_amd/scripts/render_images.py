@@ -1,27 +1,30 @@
-"""Render a list of poses with a trained model (checkpoint or merged container): same flags, input files and output tree as the
-reference's scripts/render_images.py (:19-144) --
+"""Render a list of camera poses with a trained model (a checkpoint or a merged container).
 
-    <input>/poses.txt        one c2w per line, 12 floats (3 x 4, row-major)
-    <input>/intrinsics.txt   W H fx fy cx cy per line (divided by --val_scale_factor)
-    <input>/embeddings.txt   appearance index per line
-    <output>/rgbs/%06d.jpg, depths/%06d.jpg (log-depth heat map), cells/%06d.jpg (render tinted by the nearest centroid of every
-    pixel's surface point), depths_npz/%06d.npy (metric depth, with --save_depth_npz)
+Drop-in for the reference's scripts/render_images.py (:19-144): same command line, same input files, same output tree --
 
-Every image is one ``Runner.render_image`` call = ray generation + render_rays on the device (csrc/raygen.hip, csrc/step.hip); poses are
-striped over the ranks (pose i -> rank i % world, :81).  The surface points and their nearest centroids stay on the device (the reference
-moves rays and depth to the host and runs cdist there, :125-129).  Colour maps: OpenCV is not part of this image; the depth ramp is
-``Runner.visualize_scalars`` and the cell tint is the plain hue wheel (hue = cell / n_cells), where the reference uses OpenCV's
-COLORMAP_INFERNO / COLORMAP_HSV tables.
+    <input>/poses.txt        one camera-to-world matrix per line: 12 floats, 3 x 4 row-major
+    <input>/intrinsics.txt   "W H fx fy cx cy" per line (every number is divided by --val_scale_factor)
+    <input>/embeddings.txt   one appearance index per line
+    <output>/rgbs/NNNNNN.jpg        the render
+    <output>/depths/NNNNNN.jpg      heat map of log depth (background depths clamped to the foreground's 95 % quantile)
+    <output>/cells/NNNNNN.jpg       the render tinted by the centroid nearest to every pixel's surface point
+    <output>/depths_npz/NNNNNN.npy  depth in scene units (--save_depth_npz)
+
+What happens per pose is ONE ``Runner.render_image`` call: ray generation (csrc/raygen.hip) and render_rays (csrc/step.hip) on the
+device.  Surface points and the nearest-centroid search stay on the device as well (the reference moves rays and depth to the host
+for them, :125-129).  Poses are striped over the ranks of a multi-process launch (pose i belongs to rank i mod world, :81).
+OpenCV is not part of this image: the depth heat map is ``Runner.visualize_scalars`` and the cell tint a plain hue wheel
+(hue = cell / number of cells) where the reference goes through OpenCV's COLORMAP_INFERNO / COLORMAP_HSV tables.
 """
 import os
 import sys
 import traceback
 from argparse import Namespace
 from pathlib import Path
+from typing import List, NamedTuple
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
@@ -30,92 +33,132 @@ from mega_nerf.misc_utils import main_tqdm           # noqa: E402
 from mega_nerf.opts import get_opts_base             # noqa: E402
 from mega_nerf.runner import Runner                  # noqa: E402
 
+# the script's own flags on top of the base set: (name, is a switch)
+_FLAGS = (('input', False), ('output', False), ('dataset_path', False), ('centroids_path', False), ('save_depth_npz', True), ('resume', True))
+_SUBDIRS = ('rgbs', 'depths', 'cells')
+
 
 def _get_render_opts(argv=None) -> Namespace:
-    parser = get_opts_base()
-    parser.add_argument('--input', type=str, required=True)
-    parser.add_argument('--output', type=str, required=True)
-    parser.add_argument('--dataset_path', type=str, required=True)
-    parser.add_argument('--centroids_path', type=str, required=True)
-    parser.add_argument('--save_depth_npz', default=False, action='store_true')
-    parser.add_argument('--resume', default=False, action='store_true')
-    return parser.parse_args(argv)
+    p = get_opts_base()
+    for name, switch in _FLAGS:
+        if switch:
+            p.add_argument('--' + name, default=False, action='store_true')
+        else:
+            p.add_argument('--' + name, type=str, required=True)
+    return p.parse_args(argv)
 
 
-def _rows(path: Path):
-    with path.open() as f:
-        return [line.strip().split() for line in f if line.strip()]
+class Pose(NamedTuple):
+    c2w: torch.Tensor          # (3, 4)
+    width: int
+    height: int
+    pinhole: torch.Tensor      # fx, fy, cx, cy
+    appearance: int
 
 
-def _hue_wheel(h: torch.Tensor) -> torch.Tensor:
-    """hue in [0, 1) -> fully saturated RGB in [0, 255] (..., 3)."""
-    k = (h.unsqueeze(-1) * 6 + torch.tensor([5., 3., 1.], device=h.device)) % 6
+def read_poses(folder: Path, scale: float) -> List[Pose]:
+    """The three text files of a pose list, line k of each describing pose k."""
+    def table(name):
+        return [ln.split() for ln in (folder / name).read_text().splitlines() if ln.strip()]
+
+    cams, pins, apps = table('poses.txt'), table('intrinsics.txt'), table('embeddings.txt')
+    if not (len(cams) == len(pins) == len(apps)):
+        raise ValueError('poses.txt, intrinsics.txt and embeddings.txt of {} disagree in length: {} / {} / {}'.format(
+            folder, len(cams), len(pins), len(apps)))
+    poses = []
+    for cam, pin, app in zip(cams, pins, apps):
+        vals = [float(v) / scale for v in pin]
+        poses.append(Pose(torch.tensor([float(v) for v in cam]).view(3, 4), int(vals[0]), int(vals[1]), torch.tensor(vals[2:6]), int(app[0])))
+    return poses
+
+
+def hue_wheel(hue: torch.Tensor) -> torch.Tensor:
+    """Fully saturated colours of hue in [0, 1): (..., 3) floats in [0, 255]."""
+    k = (hue.unsqueeze(-1) * 6 + torch.tensor([5., 3., 1.], device=hue.device)) % 6
     return (1 - torch.clamp(torch.minimum(k, 4 - k), 0, 1)) * 255
 
 
-@torch.inference_mode()
-def _render_images(hparams: Namespace) -> None:
+_hue_wheel = hue_wheel
+
+
+def _finished(marker: Path) -> bool:
+    """--resume: the cell overlay is the last file written for a pose, so a readable one means the pose is complete."""
     from PIL import Image
+    if not marker.exists():
+        return False
+    try:
+        np.asarray(Image.open(marker))
+        return True
+    except Exception:
+        traceback.print_exc()
+        return False
+
+
+def _write_pose(k: int, pose: Pose, out_dir: Path, runner: Runner, centroids: torch.Tensor, save_npz: bool) -> None:
+    from PIL import Image
+    stem = '{0:06d}'.format(k)
+    meta = ImageMetadata(Path(''), pose.c2w, pose.width, pose.height, pose.pinhole, pose.appearance, None, False)
+    out, rays = runner.render_image(meta)
+    level = 'fine' if 'rgb_fine' in out else 'coarse'
+    H, W = pose.height, pose.width
+
+    colour = (out['rgb_' + level].view(H, W, 3) * 255).byte()
+    Image.fromarray(colour.cpu().numpy()).save(out_dir / 'rgbs' / (stem + '.jpg'))
+
+    depth = torch.nan_to_num(out['depth_' + level]).view(H, W)
+    if save_npz:
+        np.save(str(out_dir / 'depths_npz' / (stem + '.npy')), (depth * runner.pose_scale_factor).cpu().numpy())
+    if 'bg_depth_' + level in out:
+        # background depths are inverse-sphere quantities of size 1e7 - 1e8 (SURVEY quirk Q2): clamp them for display and for the
+        # surface points below, as the reference does, to the 95 % quantile of the foreground depths (subsampled to 2^24 values)
+        fg = torch.nan_to_num(out['fg_depth_' + level]).reshape(-1)
+        halvings = 0
+        while (fg.numel() + (1 << halvings) - 1) >> halvings > 2 ** 24:
+            halvings += 1
+        fg = fg[::1 << halvings]
+        depth = depth.clamp_max(torch.quantile(fg, 0.95))
+    Image.fromarray(Runner.visualize_scalars(torch.log(depth + 1e-8))).save(out_dir / 'depths' / (stem + '.jpg'))
+
+    grid = rays.view(H, W, -1)
+    surface = torch.addcmul(grid[..., 0:3], grid[..., 3:6], depth.unsqueeze(-1))
+    nearest = torch.cdist(surface.reshape(-1, 3), centroids).argmin(dim=1).view(H, W)
+    share = ((nearest.float() / centroids.shape[0]) * 255).byte().float() / 256.0          # 8-bit cell level, as the reference quantises it
+    overlay = (colour.float() * 0.7 + hue_wheel(share) * 0.3 + 0.5).clamp(0, 255).byte()
+    Image.fromarray(overlay.cpu().numpy()).save(out_dir / 'cells' / (stem + '.jpg'))
+
+
+def render_pose_list(hparams: Namespace) -> None:
     runner = Runner(hparams, False)
-    inp, output = Path(hparams.input), Path(hparams.output)
+    out_dir = Path(hparams.output)
+    poses = read_poses(Path(hparams.input), float(hparams.val_scale_factor))
     centroids = torch.load(hparams.centroids_path, map_location='cpu', weights_only=False)['centroids'].float().to(runner.device)
-    c2ws = [torch.tensor([float(x) for x in row]).view(3, 4) for row in _rows(inp / 'poses.txt')]
-    intrinsics = [[float(x) / hparams.val_scale_factor for x in row] for row in _rows(inp / 'intrinsics.txt')]
-    embeddings = [int(row[0]) for row in _rows(inp / 'embeddings.txt')]
 
-    rank = int(os.environ.get('RANK', '0'))
+    rank, world = int(os.environ.get('RANK', '0')), 1
     if rank == 0:
-        for sub in ('rgbs', 'depths', 'cells') + (('depths_npz',) if hparams.save_depth_npz else ()):
-            (output / sub).mkdir(parents=True, exist_ok=hparams.resume)
-    world_size = 1
+        for sub in _SUBDIRS + (('depths_npz',) if hparams.save_depth_npz else ()):
+            (out_dir / sub).mkdir(parents=True, exist_ok=hparams.resume)       # an existing tree is refused unless --resume
     if runner.distributed:
-        dist.barrier()
-        world_size = int(os.environ['WORLD_SIZE'])
+        torch.distributed.barrier()
+        world = int(os.environ['WORLD_SIZE'])
 
-    runner.nerf.eval()
-    if runner.bg_nerf is not None:
-        runner.bg_nerf.eval()
-
-    for i in main_tqdm(np.arange(rank, len(c2ws), world_size)):
-        cell_path = output / 'cells' / '{0:06d}.jpg'.format(i)
-        if hparams.resume and cell_path.exists():
-            try:
-                np.array(Image.open(cell_path))          # the last file written for a pose: readable = the pose is complete
+    for m in (runner.nerf, runner.bg_nerf):
+        if m is not None:
+            m.eval()                                                           # deterministic renders of BOTH models (:73-75)
+    with torch.inference_mode():
+        for k in main_tqdm(range(rank, len(poses), world)):
+            if hparams.resume and _finished(out_dir / 'cells' / '{0:06d}.jpg'.format(k)):
                 continue
-            except Exception:
-                traceback.print_exc()
-        W, H = int(intrinsics[i][0]), int(intrinsics[i][1])
-        results, rays = runner.render_image(ImageMetadata(Path(''), c2ws[i], W, H, torch.tensor(intrinsics[i][2:]), embeddings[i], None, False))
-        typ = 'fine' if 'rgb_fine' in results else 'coarse'
-        rgbs = (results[f'rgb_{typ}'].view(H, W, 3) * 255).byte()
-        Image.fromarray(rgbs.cpu().numpy()).save(output / 'rgbs' / '{0:06d}.jpg'.format(i))
-
-        depth = torch.nan_to_num(results[f'depth_{typ}']).view(H, W)
-        if hparams.save_depth_npz:
-            np.save(str(output / 'depths_npz' / '{0:06d}.npy'.format(i)), (depth * runner.pose_scale_factor).cpu().numpy())
-        if f'bg_depth_{typ}' in results:
-            # background depths are inverse-sphere quantities of size 1e7-1e8 (SURVEY quirk Q2): clamp to the foreground's 95 % quantile
-            to_use = torch.nan_to_num(results[f'fg_depth_{typ}']).view(-1)
-            while to_use.shape[0] > 2 ** 24:
-                to_use = to_use[::2]
-            depth = depth.clamp_max(torch.quantile(to_use, 0.95))
-        Image.fromarray(Runner.visualize_scalars(torch.log(depth + 1e-8))).save(output / 'depths' / '{0:06d}.jpg'.format(i))
-
-        rays = rays.view(H, W, -1)
-        locations = rays[..., :3] + rays[..., 3:6] * depth.unsqueeze(-1)
-        cells = torch.cdist(locations.view(-1, 3), centroids).argmin(dim=1).view(H, W).float() / len(centroids)
-        tint = _hue_wheel((cells * 255).byte().float() / 256.0)
-        blend = (rgbs.float() * 0.7 + tint * 0.3 + 0.5).clamp(0, 255).byte()
-        Image.fromarray(blend.cpu().numpy()).save(cell_path)
+            _write_pose(k, poses[k], out_dir, runner, centroids, hparams.save_depth_npz)
 
 
 def main(hparams: Namespace) -> None:
-    assert hparams.ckpt_path is not None or hparams.container_path is not None
+    if hparams.ckpt_path is None and hparams.container_path is None:
+        raise AssertionError('render_images needs --ckpt_path or --container_path')
     if hparams.detect_anomalies:
         with torch.autograd.detect_anomaly():
-            _render_images(hparams)
-    else:
-        _render_images(hparams)
+            render_pose_list(hparams)
+        return
+    render_pose_list(hparams)
 
 
 if __name__ == '__main__':
