@@ -248,7 +248,8 @@ def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode
     n = int(max(32, min(n_sample, (5.0 / max(probe / 32, 1e-9)) // 32 * 32)))
     best = probe if n == 32 else min(run(n) for _ in range(2))
     out = {'value': n / best, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-           'sample': 'torch-CPU restatement of the reference (%s), first %d rays x (%d+%d) samples of the same batch, '
+           'sample': 'torch-CPU port of the reference %s, first %d rays of the batch, %d threads' % ('train step' if mode == 'train' else 'eval render', n, cores),
+           'sample_detail': 'torch-CPU restatement of the reference (%s), first %d rays x (%d+%d) samples of the same batch, '
                      '%d threads, best of 2 after a 32-ray warm-up; the port runs at %s the speed of the REAL reference on this workload '
                      '(8 threads, build container: profiles/r03_cpu_port_vs_reference.json)' % (
                          'fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n, hp.coarse_samples, hp.fine_samples, cores,
@@ -285,7 +286,8 @@ def cpu_baseline_container(hp, rays_np, idx_np, cells):
     n = int(max(16, min(rays_np.shape[0], 16 * 10.0 / max(t_probe, 1e-3))))          # ~10 s of host work
     dt = run(n)
     return {'value': n / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': 'numpy restatement of the reference (render_rays through the routed %d-cell container, eval flags), first %d rays '
+            'sample': 'numpy port of the reference routed-container render, first %d rays of the batch' % n,
+            'sample_detail': 'numpy restatement of the reference (render_rays through the routed %d-cell container, eval flags), first %d rays '
                       'x (%d+%d) samples of the same batch, one run after a 16-ray probe' % (len(cells['fg']), n, hp.coarse_samples, hp.fine_samples)}
 
 
@@ -344,6 +346,12 @@ def main():
     if rank == 0 and headline and not args.no_extras and not args.no_config_sweep:
         t0 = time.perf_counter()
         line['baseline_configs'] = config_sweep(args, dev)
+        set8 = next((v for k, v in line['baseline_configs'].items() if k.startswith('configs[2] Rubble 8 submodules')), None)
+        if set8 and 'error' not in set8:
+            # the N = 1 point of the STRONG-scaling curve BASELINE.json's metric is quoted on ("Rubble 8-submodule"): the fixed 8-cell set on one
+            # GPU (`--gpus N --submodules 8` deals the same set to N ranks; there is no exchange, so N = 8 is one cell's step)
+            line['strong_scaling_n1'] = {'flags': '--submodules 8', 'submodules': 8, 'ms_per_step_of_the_set': set8['ms_per_step'],
+                                         'rays_per_sec': set8['rays_per_sec'], 'frac_of_f32_mfma_peak': set8['frac'], 'steps': set8['steps']}
         line['runner_loop'] = runner_loop(args, dev, line['value'])
         line['baseline_configs']['_seconds'] = round(time.perf_counter() - t0, 1)
     if rank == 0:
@@ -354,26 +362,27 @@ def main():
 
 # BASELINE.json `configs` beyond the headline one (configs[1]), each as a compact line of the default run: same code path as the
 # flag combination named in `flags`, short timed region, no CPU baseline, no side measurements
+# (third field: timed steps -- every entry times >= 0.3 s)
 SWEEP = [
-    ('configs[2] Rubble 8 submodules, ONE GPU trains the whole set (one mnr_train_step call per iteration)', ['--submodules', '8', '--mode', 'train']),
-    ('configs[2] Rubble merged 8-cell container, routed eval', ['--container', '8', '--mode', 'eval']),
-    ('configs[3] Building-shaped cell (fg 8x512), train', ['--layer-dim', '512', '--mode', 'train']),
-    ('configs[3] Building-shaped cell (fg 8x512), eval', ['--layer-dim', '512', '--mode', 'eval']),
-    ('configs[3] Building merged 25-cell container of 512-wide cells, routed eval', ['--layer-dim', '512', '--container', '25', '--mode', 'eval']),
-    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), train', ['--sh-deg', '2', '--mode', 'train']),
-    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), eval', ['--sh-deg', '2', '--mode', 'eval']),
+    ('configs[2] Rubble 8 submodules, ONE GPU trains the whole set (one mnr_train_step call per iteration)', ['--submodules', '8', '--mode', 'train'], 10),
+    ('configs[2] Rubble merged 8-cell container, routed eval', ['--container', '8', '--mode', 'eval'], 90),
+    ('configs[3] Building-shaped cell (fg 8x512), train', ['--layer-dim', '512', '--mode', 'train'], 15),
+    ('configs[3] Building-shaped cell (fg 8x512), eval', ['--layer-dim', '512', '--mode', 'eval'], 50),
+    ('configs[3] Building merged 25-cell container of 512-wide cells, routed eval', ['--layer-dim', '512', '--container', '25', '--mode', 'eval'], 30),
+    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), train', ['--sh-deg', '2', '--mode', 'train'], 50),
+    ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), eval', ['--sh-deg', '2', '--mode', 'eval'], 150),
     # BASELINE.json words configs[4] as "SH-degree-3"; the reference's config files say sh_deg 2.  Degree 3 (48 colour
     # coefficients) has its own pair of the one-call step / render
-    ('configs[4] as worded in BASELINE.json: sh_deg 3, train', ['--sh-deg', '3', '--mode', 'train']),
-    ('configs[4] as worded in BASELINE.json: sh_deg 3, eval', ['--sh-deg', '3', '--mode', 'eval']),
+    ('configs[4] as worded in BASELINE.json: sh_deg 3, train', ['--sh-deg', '3', '--mode', 'train'], 50),
+    ('configs[4] as worded in BASELINE.json: sh_deg 3, eval', ['--sh-deg', '3', '--mode', 'eval'], 150),
 ]
 
 
 def config_sweep(args, dev):
     import gc
     out = {}
-    for name, flags in SWEEP:
-        a = parse_args(flags + ['--steps', '10', '--warmup', '3', '--no-cpu-baseline', '--no-extras', '--rays', str(args.rays), '--samples', args.samples])
+    for name, flags, steps in SWEEP:
+        a = parse_args(flags + ['--steps', str(steps), '--warmup', '3', '--no-cpu-baseline', '--no-extras', '--rays', str(args.rays), '--samples', args.samples])
         t0 = time.perf_counter()
         try:
             ln = run_config(a, 0, 1, dev, None)
@@ -391,7 +400,65 @@ def config_sweep(args, dev):
             out[name] = {'flags': ' '.join(flags), 'error': '%s: %s' % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
+    for mode in ('train', 'eval'):
+        name = 'configs[0] configs/nerf-shaped model (cascade, layer_dim 2048, no appearance, no background), %s' % mode
+        try:
+            out[name] = config0_line(args, dev, mode)
+        except Exception as e:
+            out[name] = {'flags': 'configs/nerf/*.yaml', 'error': '%s: %s' % (type(e).__name__, e)}
+        gc.collect()
+        torch.cuda.empty_cache()
     return out
+
+
+def config0_line(args, dev, mode):
+    """BASELINE.json configs[0] on the MI355X: `configs/nerf/*.yaml` (use_cascade, layer_dim 2048, appearance_dim 0, no_bg_nerf; /root/reference's
+    configs/nerf/rubble.yaml:1-4) at the benchmark's 1024 rays x (64 + 128) samples.  A cascade evaluates the coarse model on Nc samples and
+    the fine model on the sorted Nc + Nf: 64 + 192 = 256 MLP rows per ray.  2048-wide layers run on the tiled per-layer GEMMs
+    (k_tgemm / k_wgrad2 jobs); whole-step figure (wall clock incl. the render stages) against the fp32-MFMA peak."""
+    import synthetic_scene as S
+    from mega_nerf import ray_utils
+    from mega_nerf.models.model_utils import get_nerf
+    from mega_nerf.opts import get_opts_base
+    from mega_nerf.rendering import render_rays_async
+    from mega_nerf.training import TrainStep
+    Nc, Nf = [int(v) for v in args.samples.split(',')]
+    hp = get_opts_base().parse_args(['--coarse_samples', str(Nc), '--fine_samples', str(Nf), '--layer_dim', '2048', '--appearance_dim', '0',
+                                     '--use_cascade', '--no_bg_nerf'])
+    torch.manual_seed(7)
+    nerf = get_nerf(hp, 0).to(dev)
+    s = S.SCENE
+    d = ray_utils.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True, dev)
+    all_rays = ray_utils.get_rays(d, torch.from_numpy(s['c2w']).to(dev), s['near'], 2.0, s['ray_altitude_range']).view(-1, 8)     # no background: far = 2 (runner.py:81-82)
+    g = torch.Generator(device='cpu').manual_seed(42)
+    rays = all_rays[torch.randperm(all_rays.shape[0], generator=g)[:args.rays].to(dev)].contiguous()
+    target = torch.rand(args.rays, 3, generator=g).to(dev)
+    mac = sum(p.numel() for k_, p in nerf.fine.named_parameters() if k_.endswith('weight'))
+    steps = 6 if mode == 'train' else 20
+    if mode == 'train':
+        nerf.train()
+        ts = TrainStep(nerf, None, hp, None, None)
+        fn = lambda: ts(rays, None, target)                                                           # noqa: E731
+    else:
+        nerf.eval()
+
+        def fn():
+            with torch.no_grad():
+                render_rays_async(nerf, None, rays, None, hp, None, None, True, False, True)
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = 2.0 * mac * args.rays * (Nc + Nc + Nf) * (3 if mode == 'train' else 1)
+    return {'flags': 'configs/nerf/*.yaml: use_cascade, layer_dim 2048, appearance_dim 0, no_bg_nerf', 'ms_per_step': round(dt * 1e3, 4),
+            'rays_per_sec': round(args.rays / dt, 1), 'steps': steps, 'frac': round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            'frac_of': 'whole step (k_tgemm / k_wgrad2 jobs + render stages), wall clock', 'peak_tflops': PEAK_F32_MFMA_TFLOPS,
+            'achieved_tflops': round(fl / dt / 1e12, 2), 'algorithmic_gflop_per_step': round(fl / 1e9, 1),
+            'workload': 'cascade of two 8x2048 NeRFs, %d rays x (%d coarse + %d fine-model) rows, fg only' % (args.rays, Nc, Nc + Nf)}
 
 
 def runner_loop(args, dev, value):
@@ -810,7 +877,7 @@ def run_config(args, rank, world, dev, dist):
                     'mfma_busy': p.get('mfma_busy'),
                     # traffic / mfma_busy are PMC figures from the committed summary (separate --pmc passes), NOT from this run:
                     'pmc_source': {'file': str(PMC_FILE.relative_to(ROOT)), 'git_head_when_summarised': pmc.get('_meta', {}).get('git_head_when_summarised')},
-                    'kernel': kernel, 'avg_launch_ms': round(avg * 1e3, 4),
+                    'kernel': kernel.split(' (')[0], 'kernel_detail': kernel, 'avg_launch_ms': round(avg * 1e3, 4),
                     'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
         mlp = lambda nf_, nb_: nf_ * FG_FLOP_PER_SAMPLE + nb_ * BG_FLOP_PER_SAMPLE                      # noqa: E731
@@ -825,7 +892,8 @@ def run_config(args, rank, world, dev, dist):
             ach = fl / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'kernel': 'whole step (k_mlp_fwd%s gather mode: all cells of a pass in one launch; k_route, k_route_combine, render stages), wall clock' % ('_pair' if args.layer_dim == 512 else ''),
+                    'kernel': 'whole step, wall clock',
+                    'kernel_detail': 'whole step (k_mlp_fwd%s gather mode: all cells of a pass in one launch; k_route, k_route_combine, render stages), wall clock' % ('_pair' if args.layer_dim == 512 else ''),
                     'routed_rows_per_step': {'fg': r_fg // args.steps, 'bg': r_bg // args.steps,
                                              'unrouted': {'fg': args.rays * (Nc + Nf), 'bg': max(n_bg, 0) * (Nc // 2 + Nf // 2)}},
                     'algorithmic_gflop_per_step': round(fl / 1e9, 1)}
@@ -837,7 +905,8 @@ def run_config(args, rank, world, dev, dist):
             ach = fl * len(work) / (dt / args.steps) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                    'kernel': ('whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages' if args.mode == 'train' and args.sh_deg is None
+                    'kernel': 'whole step, wall clock',
+                    'kernel_detail': ('whole step (k_tgemm forward / data-gradient launches + k_wgrad2<1>), wall clock incl. render stages' if args.mode == 'train' and args.sh_deg is None
                                else 'whole step (one-call step / render of the SH pair), wall clock incl. render stages' if args.sh_deg in (2, 3)
                                else 'whole step (register-chained kernels + stand-alone SH adjoint kernels, sequenced stage by stage), wall clock incl. render stages' if args.sh_deg is not None
                                else 'whole step (k_mlp_fwd_pair: 512-wide foreground, two wavefronts per SIMD; k_mlp_fwd background), wall clock incl. render stages'),
@@ -900,7 +969,13 @@ def run_config(args, rank, world, dev, dist):
             'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.submodules else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('configs/mega-nerf-sh-3 Sci-Art-shaped fg+bg NeRF (sh_deg %d, pos_dir_dim 0, fg 8x%d, bg 8x%d, 12 freqs, 48-d appearance), ' % (
+            'config': {'workload': '%s cell, fg 8x%d + bg 8x%d, %d rays x (%d+%d) samples, %s' % (
+                           'configs[4] Sci-Art-shaped sh_deg %d' % args.sh_deg if args.sh_deg is not None else 'configs[3] Building-shaped' if wide
+                           else 'configs[1] Rubble-shaped' if not (args.submodules or args.container) else 'configs[2] Rubble-shaped',
+                           args.layer_dim, hp.bg_layer_dim, args.rays, Nc, Nf,
+                           '%d-cell container' % args.container if args.container else '%d submodules on %d GPU(s)' % (args.submodules, world) if args.submodules
+                           else 'one submodule per GPU'),
+                       'workload_detail': ('configs/mega-nerf-sh-3 Sci-Art-shaped fg+bg NeRF (sh_deg %d, pos_dir_dim 0, fg 8x%d, bg 8x%d, 12 freqs, 48-d appearance), ' % (
                                         args.sh_deg, args.layer_dim, hp.bg_layer_dim) if args.sh_deg is not None else
                                     'configs/mega-nerf %s-shaped fg+bg NeRF (fg 8x%d, bg 8x%d, 12/4 freqs, 48-d appearance), ' % (
                                         'Building' if wide else 'Rubble', args.layer_dim, hp.bg_layer_dim)) +

@@ -6,6 +6,13 @@
 #include "common.h"
 #include "mlp_layout.h"
 
+#ifndef MNR_FRAG_DEPTH
+#define MNR_FRAG_DEPTH 2
+#endif
+#ifndef MNR_FRAG_WEAVE
+#define MNR_FRAG_WEAVE 1
+#endif
+
 namespace mnr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -120,6 +127,23 @@ struct WStreamT {
         cur ^= 1;
         issue();
     }
+    // the same in pieces, for callers that weave the DMA requests into their MFMA stream: publish() = barrier + flip, then
+    // issue_piece<0 .. PIECES - 1>() (any order, each once), then issued()
+    static constexpr int PIECES = CHUNK_F4 / NT;
+    __device__ __forceinline__ void publish() {
+        __syncthreads();
+        cur ^= 1;
+    }
+    template <int I>
+    __device__ __forceinline__ void issue_piece() {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        float4 *dst = lds + (cur ^ 1) * CHUNK_F4 + wave * 64;
+        unsigned lo = threadIdx.x * 16u;
+        asm("" : "+v"(lo));
+        __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(g + I * NT)) + lo),
+                                         (lds_void_t *)(dst + I * NT), 16, 0, 0);
+    }
+    __device__ __forceinline__ void issued() { g += CHUNK_F4; }
 };
 using WStream = WStreamT<256>;
 
@@ -144,16 +168,80 @@ __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0
 __device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(floatx4 &x) { asm volatile("" : "+v"(x)); }
 
+// Static schedule of a K segment's fragment batches (TILE = 16): batch t = (group G0 + t / NBATCH, blocks (t % NBATCH) * OBB ..).  A "run" is
+// a stretch of batches inside one weight chunk; its fragment reads are software-pipelined two batches deep and restart behind the
+// chunk barrier that publishes the next chunk.
+template <int NBATCH, int GPC, int G0, int T>
+struct SegSched {
+    static constexpr bool chunk_start(int t) { return t % NBATCH == 0 && (G0 + t / NBATCH) % GPC == 0 && (G0 + t / NBATCH) > 0; }
+    static constexpr int run_start(int t) { int r = t; while (r > 0 && !chunk_start(r)) --r; return r; }
+    static constexpr int run_end(int t) { int r = t + 1; while (r < T && !chunk_start(r)) ++r; return r; }    // one past the run's last batch
+};
+// the OBB A fragments of batch (group slot GS of the chunk, first block O0): asm reads at immediate offsets from the lane's chunk address
+template <int GS, int O0, int NOB, int OBB>
+__device__ __forceinline__ void frag_load(floatx4 (&a)[OBB], unsigned addr) {
+    static_for<0, OBB>([&](auto oc) { a[decltype(oc)::value] = lds_ld4<(GS * NOB + O0 + decltype(oc)::value) * 1024>(addr); });
+}
+// ... and their 4 x OBB MFMAs.  The empty asm behind them "redefines" every accumulator block the batch wrote: volatile asm statements
+// keep their program order, so the fragment reads that follow in the source cannot be scheduled above these MFMAs.  Without it the MFMAs
+// -- pure values to the compiler -- sink below the asm reads of the following batches and groups, each of which then gets fresh
+// registers: in the dir_a layer 45 ds_read_b128 (180 registers) were in flight at once and 51-63 registers went to scratch (rounds 3-4).
+template <int O0, int OBB, int NOB>
+__device__ __forceinline__ void frag_mfmas(floatx4 (&acc)[NOB], floatx4 (&a)[OBB], float b0, float b1, float b2, float b3) {
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) pin(a[ob]);
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][0], b0, acc[O0 + ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][1], b1, acc[O0 + ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][2], b2, acc[O0 + ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][3], b3, acc[O0 + ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) pin(acc[O0 + ob]);
+}
+
+// The same batch with the fragment reads of a LATER batch (group slot GS, first block O0N) woven in: one ds_read_b128 behind each K step's
+// OBB MFMAs, into a third buffer.  A burst of four reads behind sixteen MFMAs holds the wavefront's issue port long enough to open a gap
+// in the matrix pipe (measured: the strictly ordered burst form ran the forward 1.5 % and the data-gradient chain 3 % slower than the
+// schedule hipcc had found on its own); one read per four MFMAs disappears in their issue shadow.  The pins behind every K step keep
+// MFMAs and reads in exactly this order.
+template <int O0, int GS, int O0N, int NOBF, bool LOAD, bool DMA, int OBB, int NOB, class Stream>
+__device__ __forceinline__ void frag_mfmas_weave(floatx4 (&acc)[NOB], floatx4 (&a)[OBB], floatx4 (&an)[OBB], unsigned addr, Stream &st, float b0,
+                                                 float b1, float b2, float b3) {
+    static_assert(OBB == 4, "one read per K step: four blocks per batch");
+#pragma unroll
+    for (int ob = 0; ob < OBB; ++ob) pin(a[ob]);
+    const float bk[4] = {b0, b1, b2, b3};
+    static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], bk[k], acc[O0 + ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < OBB; ++ob) pin(acc[O0 + ob]);
+        if constexpr (DMA) {                      // the next-but-one chunk's DMA requests, a quarter behind each K step
+            constexpr int PP = (Stream::PIECES + 3) / 4;
+            static_for<0, PP>([&](auto pc) {
+                constexpr int piece = k * PP + decltype(pc)::value;
+                if constexpr (piece < Stream::PIECES) st.template issue_piece<piece>();
+            });
+            if constexpr (k == 3) st.issued();
+        }
+        if constexpr (LOAD) an[k] = lds_ld4<(GS * NOBF + O0N + k) * 1024>(addr);
+    });
+}
+
 // One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
 // G0 = index of the segment's first group inside the layer (chunk boundaries are static).
 template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB, class Stream>
 __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], Stream &st, int lane) {
     static_assert(NB >= 4 * NG, "B register array too small");
-    static_for<0, NG>([&](auto gi) {
-        constexpr int g = G0 + decltype(gi)::value;
-        constexpr int gl = decltype(gi)::value;
-        if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
-        if constexpr (TILE == 32) {
+    if constexpr (TILE == 32) {
+        static_for<0, NG>([&](auto gi) {
+            constexpr int g = G0 + decltype(gi)::value;
+            constexpr int gl = decltype(gi)::value;
+            if constexpr (g % GPC == 0 && g > 0) st.next_chunk();
             const float4 *p = st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane;
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
@@ -163,41 +251,71 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
                 acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * gl + 2], acc[ob], 0, 0, 0);
                 acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * gl + 3], acc[ob], 0, 0, 0);
             }
-        } else {
-            // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk a batch of OBB blocks per k step.  The A fragments of two
-            // batches are in flight (asm reads, hand-counted waits): batch i + 2 is requested as soon as the MFMAs of batch i are issued.
-            constexpr int OBB = NOB < 4 ? NOB : 4, NBATCH = NOB / OBB;
-            static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
-            const unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + (g % GPC) * NOB * 64 + lane);
-            floatx4 a0[OBB], a1[OBB];
-            auto load = [&](floatx4 (&a)[OBB], auto batch) {
-                constexpr int o0 = decltype(batch)::value * OBB;
-                static_for<0, OBB>([&](auto oc) { a[decltype(oc)::value] = lds_ld4<(o0 + decltype(oc)::value) * 1024>(addr); });
-            };
-            auto mfmas = [&](floatx4 (&a)[OBB], auto batch) {
-                constexpr int o0 = decltype(batch)::value * OBB;
-#pragma unroll
-                for (int ob = 0; ob < OBB; ++ob) pin(a[ob]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int ob = 0; ob < OBB; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], b[4 * gl + k], acc[o0 + ob], 0, 0, 0);
-            };
-            load(a0, std::integral_constant<int, 0>{});
-            if constexpr (NBATCH > 1) load(a1, std::integral_constant<int, 1>{});
-            static_for<0, NBATCH>([&](auto bc) {
-                constexpr int bi = decltype(bc)::value;
-                if constexpr (bi + 1 < NBATCH) wait_lgkm<OBB>(); else wait_lgkm<0>();
-                if constexpr (bi % 2 == 0) {
-                    mfmas(a0, bc);
-                    if constexpr (bi + 2 < NBATCH) load(a0, std::integral_constant<int, bi + 2>{});
+        });
+    } else {
+        // 16x16x4: 32-cycle issue / 40-cycle dependent latency -> walk a batch of OBB blocks per k step.  The A fragments of MNR_FRAG_DEPTH
+        // batches are in flight (asm reads at immediate offsets, hand-counted waits): batch t + 2 is requested as soon as the MFMAs of
+        // batch t are issued -- across the groups of a chunk (SegSched), so only a chunk barrier restarts the pipeline.
+        constexpr int OBB = NOB < 4 ? NOB : 4, NBATCH = NOB / OBB, T = NG * NBATCH;
+        static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
+        static_assert(GPC * NOB * 1024 <= 65536, "fragment offsets must fit the ds_read immediate");
+        using S = SegSched<NBATCH, GPC, G0, T>;
+        unsigned addr = 0;
+        // (a segment whose SECOND batch opens a chunk -- 64-wide test models only -- takes the restartable form below)
+        if constexpr (MNR_FRAG_WEAVE && OBB == 4 && !(T > 1 && S::chunk_start(1))) {
+            // ONE software pipeline over the whole segment.  Three fragment buffers: batch t computes from one, batch t + 1 is in flight in
+            // the second, batch t + 2 is requested -- one read behind each K step of batch t -- into the third (released by batch t - 1).
+            // Chunk boundaries do not restart it: when batch t + 2 opens a new weight chunk, the chunk barrier is taken at the START of
+            // batch t -- all that has to be true there is that the fragment reads of the old chunk (batches t, t + 1) have landed
+            // (lgkmcnt(0)): the DMA the barrier releases may then overwrite the old buffer while the 32 MFMAs of t and t + 1 still run from
+            // registers.  A wavefront therefore waits at the barrier with two batches of matrix work in hand instead of none, the DMA
+            // requests of the next-but-one chunk are woven into batch t, and the first reads of the new chunk into batches t and t + 1
+            // (hipcc's own schedule sank some MFMAs below the barrier the same way -- that is what round 4's kernels lived on).
+            static_assert(GPC * NBATCH >= 2, "a chunk holds at least two batches");
+            floatx4 a[3][OBB];
+            if constexpr (S::chunk_start(0)) st.next_chunk();
+            addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
+            frag_load<G0 % GPC, 0, NOB>(a[0], addr);
+            if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * OBB, NOB>(a[1], addr);
+            static_for<0, T>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, u = t + 2;
+                constexpr int gl = t / NBATCH;
+                constexpr bool early = u < T && S::chunk_start(u);
+                if constexpr (early) {
+                    wait_lgkm<0>();
+                    st.publish();
+                    addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
+                } else if constexpr (t + 1 < T) {
+                    // (behind an early barrier at t - 1 everything has landed already; the count is an upper bound either way)
+                    wait_lgkm<OBB>();
                 } else {
-                    mfmas(a1, bc);
-                    if constexpr (bi + 2 < NBATCH) load(a1, std::integral_constant<int, bi + 2>{});
+                    wait_lgkm<0>();
                 }
+                frag_mfmas_weave<(t % NBATCH) * OBB, (G0 + u / NBATCH) % GPC, (u % NBATCH) * OBB, NOB, (u < T), early>(
+                    acc, a[t % 3], a[u % 3], addr, st, b[4 * gl], b[4 * gl + 1], b[4 * gl + 2], b[4 * gl + 3]);
+            });
+        } else {
+            constexpr int D = MNR_FRAG_DEPTH;                  // fragment batches in flight
+            static_assert(OBB * (D - 1) <= 15, "lgkmcnt is a 4-bit counter");
+            floatx4 a[D][OBB];
+            static_for<0, T>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, t0 = S::run_start(t), t1 = S::run_end(t);
+                constexpr int gl = t / NBATCH;
+                if constexpr (t == t0) {
+                    if constexpr (S::chunk_start(t)) st.next_chunk();
+                    addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
+                    static_for<0, D>([&](auto dc) {
+                        constexpr int u = t + decltype(dc)::value;
+                        if constexpr (u < t1) frag_load<(G0 + u / NBATCH) % GPC, (u % NBATCH) * OBB, NOB>(a[decltype(dc)::value], addr);
+                    });
+                }
+                constexpr int newer = (t1 - 1 - t) < (D - 1) ? (t1 - 1 - t) : (D - 1);         // batches requested after this one, still in flight
+                wait_lgkm<OBB * newer>();
+                frag_mfmas<(t % NBATCH) * OBB>(acc, a[(t - t0) % D], b[4 * gl], b[4 * gl + 1], b[4 * gl + 2], b[4 * gl + 3]);
+                if constexpr (t + D < t1) frag_load<(G0 + (t + D) / NBATCH) % GPC, ((t + D) % NBATCH) * OBB, NOB>(a[(t - t0) % D], addr);
             });
         }
-    });
+    }
 }
 
 template <int NOB, int RPB, class AccT>

@@ -105,6 +105,23 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
     }
 }
 
+// Direction-encoding stash.  `embed` is sincosf -- its large-argument path alone wants ~40 registers -- and the dir_a layer, where the
+// encoding is consumed, is where a lane holds the 64 feature registers, 32 accumulators and 32 fragment registers in flight: evaluated
+// there it pushed 51-63 registers to scratch (rounds 1-4; the spherical-harmonics pairs, which have no direction encoding, never
+// spilled).  It is evaluated at the start of the kernel instead, next to the position encoding where nothing else is live, parked in
+// a lane-private LDS slot behind the weight ring (ED floats per lane; slot i of thread t at (i * NT + t) * 4: conflict-free) and read
+// back in front of its K segment.  asm on both sides: a compiler-visible access to the ring's array would get a vmcnt(0) (mlp_device.h).
+template <class C, int NW>
+constexpr size_t fwd_lds_bytes() { return (size_t)2 * CHUNK_BYTES + (size_t)C::ED * 64 * NW * 4; }
+template <int I, int NT>
+__device__ __forceinline__ void stash_put(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(I * NT * 4) : "memory"); }
+template <int I, int NT>
+__device__ __forceinline__ float stash_get(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(I * NT * 4) : "memory");
+    return v;
+}
+
 // NW = wavefronts per workgroup sharing one weight stream (4: two workgroups per CU; 8: one -- half the stream traffic and barriers per CU)
 template <class C, bool TRAIN, int NW = 4>
 __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int cidx = 0) {
@@ -186,6 +203,21 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         if (valid) tape_store_emb<C::XYZ, C::LX, P>(a.tape + a.tl.embx_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.embx_w, ex, part);
     }
 
+    if constexpr (C::ED > 0) {
+        if (!io.sigma_only) {                                // (a density-only launch has no directions: io.dir may be NULL)
+            float dv[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
+            float ed[C::ED];
+            embed<3, C::LD, P>(ed, dv, part);
+            if constexpr (TRAIN) {
+                if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.embd_w, ed, part);
+            }
+            const unsigned sa = lds_addr(lds_ring + 2 * CHUNK_F4) + threadIdx.x * 4u;
+            static_for<0, C::ED>([&](auto ic) { stash_put<decltype(ic)::value, 64 * NW>(sa, ed[decltype(ic)::value]); });
+        }
+    }
+
     float h[H];
     AccT acc[NOB];
     int li = 0;   // MFMA layer counter (compile-time after unrolling)
@@ -260,14 +292,13 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         }
         run_segment<TILE, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane);
         if constexpr (C::ED > 0) {
-            float dv[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
             float ed[C::ED];
-            embed<3, C::LD, P>(ed, dv, part);
-            if constexpr (TRAIN) {
-                if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, tape_row<TILE>(trow0), a.tl.embd_w, ed, part);
-            }
+            unsigned sa = lds_addr(lds_ring + 2 * CHUNK_F4) + threadIdx.x * 4u;
+            asm volatile("" : "+v"(sa));        // formed here, not kept in a register since the start of the kernel
+            static_for<0, C::ED>([&](auto ic) { ed[decltype(ic)::value] = stash_get<decltype(ic)::value, 64 * NW>(sa); });
+            wait_lgkm<0>();
+#pragma unroll
+            for (int i = 0; i < C::ED; ++i) pin(ed[i]);
             run_segment<TILE, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane);
         }
         if constexpr (C::AP > 0) {
@@ -363,6 +394,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_mlp_fwd_multi(MlpF
     else mlp_fwd_body<CA, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
 }
 
+// dynamic LDS beyond 64 KiB has to be granted per kernel function (once per process and function: `done` is the call site's flag)
+static inline int allow_lds(const void *fn, size_t bytes) {
+    if (bytes <= 65536) return MNR_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return set_err(MNR_E_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %zu): %s", bytes, hipGetErrorString(e));
+    return MNR_OK;
+}
+
 template <class C>
 static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
                          float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells, int n_cells) {
@@ -406,7 +445,10 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
     if (nwg > 0x7fffffffL) return set_err(MNR_E_INVALID, "too many rows for one MLP launch");
-    hipLaunchKernelGGL((k_mlp_fwd<C, TRAIN>), dim3((unsigned)nwg), dim3(256), 2 * CHUNK_BYTES, stream, a);
+    constexpr size_t LDS = fwd_lds_bytes<C, 4>();
+    const int lrc = allow_lds(reinterpret_cast<const void *>(k_mlp_fwd<C, TRAIN>), LDS);
+    if (lrc != MNR_OK) return lrc;
+    hipLaunchKernelGGL((k_mlp_fwd<C, TRAIN>), dim3((unsigned)nwg), dim3(256), LDS, stream, a);
     return check_launch("k_mlp_fwd");
 }
 

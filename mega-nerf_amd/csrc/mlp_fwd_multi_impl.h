@@ -59,8 +59,12 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
     mm.nseg = n_segs;
     if (wg == 0) return MNR_OK;
     const unsigned ny = cells ? (unsigned)n_cells_of(segs[0], cells[0]) : 1u;
-    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), 2 * CHUNK_BYTES, s, mm);
-    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), 2 * CHUNK_BYTES, s, mm);
+    constexpr size_t LDS = fwd_lds_bytes<CfgFG, NW>() > fwd_lds_bytes<CfgBG, NW>() ? fwd_lds_bytes<CfgFG, NW>() : fwd_lds_bytes<CfgBG, NW>();
+    const int lrc = allow_lds(train ? reinterpret_cast<const void *>(k_mlp_fwd_multi<CfgFG, CfgBG, true, NW>)
+                                    : reinterpret_cast<const void *>(k_mlp_fwd_multi<CfgFG, CfgBG, false, NW>), LDS);
+    if (lrc != MNR_OK) return lrc;
+    if (train) hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, true, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), LDS, s, mm);
+    else hipLaunchKernelGGL((k_mlp_fwd_multi<CfgFG, CfgBG, false, NW>), dim3((unsigned)wg, ny), dim3(64 * NW), LDS, s, mm);
     return check_launch("k_mlp_fwd_multi");
 }
 

@@ -51,41 +51,66 @@ struct WStream8 {      // WStream (mlp_device.h) for a 512-thread workgroup
 // 31-78 spilled VGPRs), and scheduling fences / group barriers either spilled more or did not finish compiling.
 struct NoHook { template <class G> __device__ __forceinline__ void operator()(G) const {} };
 
-template <int NOBH, int NOB_FULL, int NG, int GPC, int G0, int NB, class Hook = NoHook>
-__device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const float (&b)[NB], WStream8 &st, int lane, int ob0, Hook hook = Hook()) {
-    static_assert(NB >= 4 * NG, "B register array too small");
+// BSTASH: the B operands (a positional encoding) are not a register array but sit in LDS, one float4 per K group and lane at
+// bst + g * BST_STRIDE bytes (this wavefront's slice of the exchange buffer), and are fetched group by group: four registers live instead
+// of 20-28 next to the 128 input + 64 accumulator + 32 fragment registers of the skip layer (which is where rounds 3-4 spilled).
+constexpr int BST_STRIDE = 512 * 16;
+template <int NOBH, int NOB_FULL, int NG, int GPC, int G0, int NB, class Hook = NoHook, bool BSTASH = false>
+__device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const float (&b)[NB], WStream8 &st, int lane, int ob0, Hook hook = Hook(),
+                                                 unsigned bst = 0) {
+    static_assert(BSTASH || NB >= 4 * NG, "B register array too small");
     static_assert(NOBH % 8 == 0, "blocks per half: whole pairs of four-block batches");
-    static_for<0, NG>([&](auto gi) {
-        constexpr int g = G0 + decltype(gi)::value;
-        constexpr int gl = decltype(gi)::value;
-        if constexpr (g % GPC == 0 && g > 0) { st.next_chunk(); hook(std::integral_constant<int, g>{}); }      // (hook: right behind a chunk barrier)
-        const unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ((g % GPC) * NOB_FULL + ob0) * 64 + lane);
-        floatx4 a0[4], a1[4];
-        auto load = [&](floatx4 (&a)[4], auto batch) {
-            constexpr int o0 = decltype(batch)::value * 4;
-            a[0] = lds_ld4<(o0 + 0) * 1024>(addr); a[1] = lds_ld4<(o0 + 1) * 1024>(addr);
-            a[2] = lds_ld4<(o0 + 2) * 1024>(addr); a[3] = lds_ld4<(o0 + 3) * 1024>(addr);
-        };
-        auto mfmas = [&](floatx4 (&a)[4], auto batch) {
-            constexpr int o0 = decltype(batch)::value * 4;
-            pin(a[0]); pin(a[1]); pin(a[2]); pin(a[3]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc[o0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], b[4 * gl + k], acc[o0 + ob], 0, 0, 0);
-        };
-        constexpr int NBATCH = NOBH / 4;
-        load(a0, std::integral_constant<int, 0>{});
-        load(a1, std::integral_constant<int, 1>{});
-        static_for<0, NBATCH / 2>([&](auto pc) {
-            constexpr int bp = decltype(pc)::value * 2;                 // batches bp (in a0) and bp + 1 (in a1)
+    // ONE two-deep pipeline over the segment's batches (mlp_device.h: SegSched, frag_load, frag_mfmas -- the accumulator pins behind every
+    // batch keep the MFMAs above the reads that follow them).  A chunk boundary does not restart it: when batch t + 2 opens a new weight
+    // chunk, the barrier is taken at the START of batch t, as soon as the reads of the old chunk (batches t, t + 1) have landed; the
+    // wavefront then stands at the barrier with 32 MFMAs in hand, the DMA it releases overwrites a buffer nobody reads any more, and
+    // the first reads of the new chunk go out behind batch t.  (W = 512: a chunk is ONE group = four batches -- a restart per chunk
+    // left the matrix pipe idle for an LDS round trip every 64 MFMAs.)
+    constexpr int NBATCH = NOBH / 4, T = NG * NBATCH;
+    static_assert(GPC * NOB_FULL * 1024 <= 65536, "fragment offsets must fit the ds_read immediate");
+    static_assert(GPC * NBATCH >= 2, "a chunk holds at least two batches");
+    using S = SegSched<NBATCH, GPC, G0, T>;
+    floatx4 a0[4], a1[4], bq = floatx4(0.f);
+    if constexpr (S::chunk_start(0)) { st.next_chunk(); hook(std::integral_constant<int, G0>{}); }      // (hook: right behind a chunk barrier)
+    unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + lane);
+    frag_load<G0 % GPC, 0, NOB_FULL>(a0, addr);
+    if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * 4, NOB_FULL>(a1, addr);
+    static_for<0, T>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, u = t + 2, gl = t / NBATCH;
+        constexpr bool early = u < T && S::chunk_start(u), group_start = BSTASH && t % NBATCH == 0;
+        if constexpr (group_start) bq = lds_ld4<gl * BST_STRIDE>(bst);
+        if constexpr (early) {
+            wait_lgkm<0>();
+            st.next_chunk();
+            hook(std::integral_constant<int, G0 + u / NBATCH>{});
+            addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + lane);
+        } else if constexpr (group_start || t + 1 >= T) {
+            wait_lgkm<0>();
+        } else {
             wait_lgkm<4>();
-            mfmas(a0, std::integral_constant<int, bp>{});
-            if constexpr (bp + 2 < NBATCH) { load(a0, std::integral_constant<int, bp + 2>{}); wait_lgkm<4>(); }
-            else wait_lgkm<0>();
-            mfmas(a1, std::integral_constant<int, bp + 1>{});
-            if constexpr (bp + 3 < NBATCH) load(a1, std::integral_constant<int, bp + 3>{});
-        });
+        }
+        float b0, b1, b2, b3;
+        if constexpr (BSTASH) { pin(bq); b0 = bq[0]; b1 = bq[1]; b2 = bq[2]; b3 = bq[3]; }
+        else { b0 = b[4 * gl]; b1 = b[4 * gl + 1]; b2 = b[4 * gl + 2]; b3 = b[4 * gl + 3]; }
+        if constexpr (t % 2 == 0) {
+            frag_mfmas<(t % NBATCH) * 4>(acc, a0, b0, b1, b2, b3);
+            if constexpr (u < T) frag_load<(G0 + u / NBATCH) % GPC, (u % NBATCH) * 4, NOB_FULL>(a0, addr);
+        } else {
+            frag_mfmas<(t % NBATCH) * 4>(acc, a1, b0, b1, b2, b3);
+            if constexpr (u < T) frag_load<(G0 + u / NBATCH) % GPC, (u % NBATCH) * 4, NOB_FULL>(a1, addr);
+        }
+    });
+}
+
+// a positional encoding -> this wavefront's slice of the exchange buffer, one float4 per K group (BSTASH above)
+template <int OFF>
+__device__ __forceinline__ void lds_st4(unsigned addr, floatx4 v) { asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+template <int NE>
+__device__ __forceinline__ void stash_encoding(unsigned bst, const float (&e)[NE]) {
+    static_assert(NE % 4 == 0 && (NE / 4) * BST_STRIDE <= PAIR_XBUF_F4 * 16, "encoding groups must fit the exchange buffer");
+    static_for<0, NE / 4>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        lds_st4<g * BST_STRIDE>(bst, floatx4{e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]});
     });
 }
 
@@ -169,19 +194,36 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         n_rows = io.n_units_dev ? (long)(*io.n_units_dev) * io.rows_per_unit : (long)io.n_rows;
         if (blk * C::ROWS_PER_WG >= n_rows) return;
     }
+    // Everything uniform goes to SGPRs, everything per-row is RE-DERIVED where it is used (the row from a fresh lane id, the gathered source
+    // row by re-reading the index list): with 128 input + 64 accumulator + 32 fragment registers a lane has ~30 registers for all the
+    // rest, and whatever stays live from here to the epilogue is parked in scratch (rounds 3-4: 30 dwords spilled at the top of the kernel).
     aux = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(aux)));
+    emb_a = reinterpret_cast<const float *>(uniform_ptr(reinterpret_cast<const char *>(emb_a)));
+    outp = reinterpret_cast<float *>(const_cast<char *>(uniform_ptr(reinterpret_cast<const char *>(outp))));
+    row_index = reinterpret_cast<const int32_t *>(uniform_ptr(reinterpret_cast<const char *>(row_index)));
+    n_rows = uniform_long(n_rows);
+    blk = uniform_long(blk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave & 3, half = wave >> 2;            // waves w and w + 4 share their 16 rows
     const int part = lane / 16;
-    const long lrow = (blk * 4 + pair) * 16 + (lane % 16);
-    const bool valid = lrow < n_rows;
-    const long rc = valid ? lrow : n_rows - 1;
-    const long src = row_index ? (long)row_index[rc] : rc;
-    const long ray = src / io.rows_per_ray;
+    auto row_of = [&]() -> long {                            // this lane's row inside the launch (the cell's list)
+        unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return (blk * 4 + pair) * 16 + (long)(l & 15u);
+    };
+    auto src_of = [&](long lrow_) -> long {                  // ... and the row of the input arrays it evaluates (gathered launches)
+        const long rc = lrow_ < n_rows ? lrow_ : n_rows - 1;
+        return row_index ? (long)row_index[rc] : rc;
+    };
+    const bool valid = row_of() < n_rows;
     // training: byte offset of this lane's first own column inside a 512-wide (256-wide) plane row
-    const unsigned trow = (unsigned)((blk * 4 + pair) * 16 + (lane % 16) + a.tape_row0);
-    const unsigned off512 = (trow * 512u + 4u * (unsigned)part) * 4u + 1024u * (unsigned)half;
-    const unsigned off256 = (trow * 256u + 4u * (unsigned)part) * 4u + 512u * (unsigned)half;
+    // (re-derived at every store site, like the row: one VGPR while it lives instead of two for the whole kernel)
+    auto off_of = [&](unsigned width) -> unsigned {
+        unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        const unsigned trow = (unsigned)((blk * 4 + pair) * 16 + a.tape_row0) + (l & 15u);
+        return (trow * width + 4u * (l >> 4)) * 4u + 2u * width * (unsigned)half;
+    };
     const bool upper = half != 0;
 
     WStream8 st;
@@ -196,31 +238,44 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     // ---- trunk -------------------------------------------------------------------------------------
     static_for<0, C::NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        init_acc<NOBH, 4>(acc, aux + a.bias_off[l] + part * H + half * HH);
+        constexpr bool ENC = l == 0 || ((C::SKIP >> l) & 1);
+        const float *bias = aux + a.bias_off[l] + part * H + half * HH;
+        const unsigned bst = lds_addr(xb + wave * 64 + lane);
+        if constexpr (ENC) {
+            // The positional encoding is evaluated where it is consumed (layer 0 and the skip layer) -- BEFORE this layer's accumulators
+            // exist (sincosf wants ~40 registers of its own) -- and parked in this wavefront's slice of the exchange buffer, which is idle
+            // between two layers' exchanges; the K segment then fetches it group by group (run_segment_half BSTASH).
+            float x[C::XYZ];
+            const long src = src_of(row_of());
+#pragma unroll
+            for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
+            float ex[C::EX];
+            embed<C::XYZ, C::LX, P>(ex, x, part);
+            stash_encoding(bst, ex);
+            asm volatile("" : "+v"(bias));            // the bias loads below stay below (they would hold 64 registers across the sincosf code)
+        }
+        init_acc<NOBH, 4>(acc, bias);
         st.next_chunk();
         // deferred tape stores of layer l - 1 (its output = this layer's input registers): pieces behind chunk barriers 0 .. 3
         auto hook = [&](auto gc) {
             if constexpr (TRAIN && l > 0) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, off512, h, upper); }
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, off_of(512u), h, upper); }
             }
         };
         hook(std::integral_constant<int, 0>{});
-        if constexpr (l == 0 || ((C::SKIP >> l) & 1)) {
-            // the positional encoding is evaluated where it is consumed (layer 0 and the skip layer) instead of living in 20 registers
-            // across the layers in between: the kernel sits at its 256-register budget
-            float x[C::XYZ];
-#pragma unroll
-            for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
-            float ex[C::EX];
-            embed<C::XYZ, C::LX, P>(ex, x, part);
-            run_segment_half<NOBH, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane, ob0, hook);
+        if constexpr (ENC) {
+            const float none[4] = {0.f, 0.f, 0.f, 0.f};
+            run_segment_half<NOBH, NOB, C::EX / 4, C::GPC, 0, 4, decltype(hook), true>(acc, none, st, lane, ob0, hook, bst);
             if constexpr (l > 0) run_segment_half<NOBH, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane, ob0, hook);
         } else {
             run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0, hook);
         }
         float o[HH];
         acc_to_regs<NOBH, 4, true>(o, acc);
+        // layer 0 ends in its encoding segment: a wavefront that is done must not start writing exchange data over the slice another one
+        // still fetches its last encoding group from (in the skip layer the hidden-state segment's chunk barriers lie in between)
+        if constexpr (l == 0) __syncthreads();
         pair_exchange<HH>(h, o, xb, wave, lane, upper);
     });
 
@@ -236,11 +291,11 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
             s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);
         }
         s = reduce_parts<P>(s) + ws[P * H];
-        if (io.sigma_noise) s += io.sigma_noise[src];
+        if (io.sigma_noise) s += io.sigma_noise[src_of(row_of())];
         sigma = a.sigma_act ? softplus_shifted(s) : fmaxf(s, 0.f);
     }
     if (io.sigma_only) {
-        if (valid && part == 0 && half == 0) outp[lrow * io.out_stride] = sigma;
+        if (valid && part == 0 && half == 0) outp[row_of() * io.out_stride] = sigma;
         return;
     }
 
@@ -251,7 +306,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         auto hook = [&](auto gc) {
             if constexpr (TRAIN) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, off512, h, upper); }
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, off_of(512u), h, upper); }
             }
         };
         hook(std::integral_constant<int, 0>{});
@@ -268,20 +323,22 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     auto hook_fin = [&](auto gc) {              // (two groups per chunk here: a barrier every other group)
         if constexpr (TRAIN) {
             constexpr int g = decltype(gc)::value;
-            if constexpr (g % 2 == 0 && g < 8) { if (valid) pair_store_own<2 * g, 4>(a.tape + a.tl.fin_off * a.tape_rows, off512, h, upper); }
+            if constexpr (g % 2 == 0 && g < 8) { if (valid) pair_store_own<2 * g, 4>(a.tape + a.tl.fin_off * a.tape_rows, off_of(512u), h, upper); }
         }
     };
     hook_fin(std::integral_constant<int, 0>{});
     run_segment_half<NOB2H, NOB2, H / 4, C::GPC2, 0>(acc2, h, st, lane, half * NOB2H, hook_fin);
     if constexpr (C::ED > 0) {
         float dv[3];
+        const long ray_d = src_of(row_of()) / io.rows_per_ray;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray * io.dir_stride + d];
+        for (int d = 0; d < 3; ++d) dv[d] = io.dir[ray_d * io.dir_stride + d];
         float ed[C::ED];
         embed<3, C::LD, P>(ed, dv, part);
         run_segment_half<NOB2H, NOB2, C::ED / 4, C::GPC2, H / 4>(acc2, ed, st, lane, half * NOB2H);
     }
     if constexpr (C::AP > 0) {
+        const long ray = src_of(row_of()) / io.rows_per_ray;
         long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
                                    : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
         idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);
@@ -295,9 +352,10 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     acc_to_regs<NOB2H, 4, true>(dreg, acc2);
     if constexpr (TRAIN) {
         if (valid) {
+            const unsigned o256 = off_of(256u);
             static_for<0, H2H / 4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                gstore4<64 * q>(a.tape + a.tl.dact_off * a.tape_rows, off256, make_float4(dreg[4 * q], dreg[4 * q + 1], dreg[4 * q + 2], dreg[4 * q + 3]));
+                gstore4<64 * q>(a.tape + a.tl.dact_off * a.tape_rows, o256, make_float4(dreg[4 * q], dreg[4 * q + 1], dreg[4 * q + 2], dreg[4 * q + 3]));
             });
         }
     }
@@ -320,7 +378,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     if (half == 1 && part == 0) { rs[0] = rgbp[0]; rs[1] = rgbp[1]; rs[2] = rgbp[2]; }
     __syncthreads();
     if (!(valid && part == 0 && half == 0)) return;
-    float *o = outp + lrow * io.out_stride;
+    float *o = outp + row_of() * io.out_stride;
     o[0] = sigmoidf_(rgbp[0] + rs[0] + wr[3 * P * H2 + 0]);
     o[1] = sigmoidf_(rgbp[1] + rs[1] + wr[3 * P * H2 + 1]);
     o[2] = sigmoidf_(rgbp[2] + rs[2] + wr[3 * P * H2 + 2]);

@@ -740,30 +740,45 @@ __global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, lo
     const int lane = threadIdx.x & 63;
     float p[3] = {0.f, 0.f, 0.f};
     if (valid) { p[0] = pos[row * pos_stride]; p[1] = pos[row * pos_stride + 1]; p[2] = pos[row * pos_stride + 2]; }
-    // distances (torch.cdist, p = 2) over the clustered dimensions
+    // distances: torch.cdist(x[:, d0:3], centroids[:, d0:]) (mega_nerf.py:22,31).  ATen takes its MATMUL formulation whenever either side
+    // has more than 25 rows (cdist mode "use_mm_for_euclid_dist_if_necessary"; _euclidean_dist): [-2x, |x|^2, 1] . [c, 1, |c|^2] as one
+    // sgemm -- an fma chain in column order (checked against torch / MKL: oracle/nerf_oracle.py cdist_mm) --, clamp_min(0), sqrt.  The two
+    // formulations agree to rounding near the scene, but not for the background's routing points under cluster_2d (rendering.py:459-461:
+    // o + d * depth_real with depth_real up to 1e8, quirk Q2): there |x|^2 swallows the centroid terms, every cell is equally far, hard
+    // routing picks cell 0 and the blend weighs all cells alike.  That is what the reference computes, so it is what is computed here.
+    const bool mm = n > 25 || cen.n > 25;
+    float xn = 0.f;
+    for (int k = d0; k < 3; ++k) xn = k == d0 ? p[k] * p[k] : xn + p[k] * p[k];
+    auto dist = [&](int i) {
+        if (!mm) {
+            float s = 0.f;
+            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
+            return sqrtf(s);
+        }
+        float cn = 0.f, acc = 0.f;
+        for (int k = d0; k < 3; ++k) cn = k == d0 ? cen.c[i][k] * cen.c[i][k] : cn + cen.c[i][k] * cen.c[i][k];
+        for (int k = d0; k < 3; ++k) acc = k == d0 ? (-2.f * p[k]) * cen.c[i][k] : fmaf(-2.f * p[k], cen.c[i][k], acc);
+        acc = fmaf(xn, 1.f, acc);
+        acc = fmaf(1.f, cn, acc);
+        return sqrtf(fmaxf(acc, 0.f));
+    };
     float dmin = INFINITY;
     int amin = 0;
     for (int i = 0; i < cen.n; ++i) {
-        float s = 0.f;
-        for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
-        const float d = sqrtf(s);
+        const float d = dist(i);
         if (d < dmin) { dmin = d; amin = i; }
     }
     float wsum = 0.f;
     if (margin > 1.f) {
         for (int i = 0; i < cen.n; ++i) {
-            float s = 0.f;
-            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
-            const float d = sqrtf(s);
+            const float d = dist(i);
             wsum += d > margin * dmin ? 0.f : 1.f / (d + 1e-8f);
         }
     }
     for (int i = 0; i < cen.n; ++i) {
         float w;
         if (margin > 1.f) {
-            float s = 0.f;
-            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
-            const float d = sqrtf(s);
+            const float d = dist(i);
             w = d > margin * dmin ? 0.f : (1.f / (d + 1e-8f)) / wsum;
         } else {
             w = i == amin ? 1.f : 0.f;

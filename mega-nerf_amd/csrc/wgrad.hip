@@ -182,7 +182,12 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
     constexpr int M = S::M, MBW = S::MBW, NBW = S::NBW, KS = S::KS;
     const WJob &J = a.job[j];
     const WRegion &R = a.region[J.region];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the thread index is made opaque once per episode: everything derived from it (fragment / flush addresses) is then formed here,
+    // inside the episode loop.  Left visible, those expressions are loop-invariant, get hoisted to the top of the kernel and -- with
+    // 128 accumulators + the fragment registers live in the episodes -- are parked in scratch until each flush (11-16 spilled VGPRs).
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int ks = wave / (S::GM * S::GN), wq = wave % (S::GM * S::GN);
     const int wr = wq / S::GN, wc = wq % S::GN;
     const int i32 = lane & 31, kk = lane >> 5;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
         constexpr int p = decltype(pc)::value;
         constexpr int F0 = W2_KT * M / 4, F1 = S::SEG_OFF[1] / 4, F2 = S::SEG_OFF[2] / 4;     // float4 boundaries of the segments
         constexpr int lo = p * W2_THREADS, hi = lo + W2_THREADS;
-        const int t = lo + threadIdx.x;
+        const int t = lo + (int)tid;
         if (hi <= S::TILE_F4 || t < S::TILE_F4) {
             const float *src;
             // 256-wide operands with a run-time pitch: 64 float4 per row, so piece p = rows 8 p .. 8 p + 7 (one per wave)
@@ -267,7 +272,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
     int t = item * tpi, t_end = min(t + tpi, tiles_all);
     int pend = 0, slot = 0, next_item = 0, pulled = 0;
     auto start_pull = [&]() {
-        if (threadIdx.x == 0) pulled = atomic_inc_async(a.counters + j);
+        if (tid == 0) pulled = atomic_inc_async(a.counters + j);
         pend = 1;
     };
     start_pull();
@@ -282,7 +287,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
         const long long c0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
         wait_vm0();
         const long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-        if (pend && threadIdx.x == 0) lds_st_i(ctl + 4 * (WCtl::MAILBOX + slot), pulled);
+        if (pend && tid == 0) lds_st_i(ctl + 4 * (WCtl::MAILBOX + slot), pulled);
         __builtin_amdgcn_s_barrier();
         const long long c2 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
         if (pend) { next_item = lds_ld_u(ctl + 4 * (WCtl::MAILBOX + slot)); slot ^= 1; pend = 0; }

@@ -249,7 +249,7 @@ def gen_mlp():
 
 
 def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train=False, cascade=False,
-               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256, joint=False):
+               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256, joint=False, cluster_2d=False):
     s = common.SCENE
     hp = Namespace(**vars(make_hparams(layer_dim=layer_dim, bg_layer_dim=bg_layer_dim, **hp_kw)))
     rays, idx = common.pick_rays(all_rays, N, seed)
@@ -271,12 +271,14 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
             cent_t = T(cent).to(torch.get_default_dtype())
             subs = [ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + i), A) for i in range(n_sub)]
             bsubs = [ref_model(hp, bcfg, common.make_weights(bcfg, A, seed * 1000 + 500 + i), A) for i in range(n_sub)]
+            # cluster_2d (configs/mega-nerf/quad.yaml:5): distances over dims 1:3 only (mega_nerf.py:16,22), and the background's
+            # routing point becomes the true far-away point o + d * depth_real, per SAMPLE (rendering.py:457-461)
             if joint:        # --train_mega_nerf: model_utils.py:37-42 (hard routing, joint_training flag)
-                nerf = MegaNeRF(subs, cent_t, 1, False, False, True)
-                bg_nerf = MegaNeRF(bsubs, cent_t, 1, True, False, True)
+                nerf = MegaNeRF(subs, cent_t, 1, False, cluster_2d, True)
+                bg_nerf = MegaNeRF(bsubs, cent_t, 1, True, cluster_2d, True)
             else:
-                nerf = MegaNeRF(subs, cent_t, hp.boundary_margin, False, False)
-                bg_nerf = MegaNeRF(bsubs, cent_t, hp.boundary_margin, True, False)
+                nerf = MegaNeRF(subs, cent_t, hp.boundary_margin, False, cluster_2d)
+                bg_nerf = MegaNeRF(bsubs, cent_t, hp.boundary_margin, True, cluster_2d)
         elif cascade:
             nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
                            ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
@@ -515,6 +517,11 @@ def main(only=None):
     case('render_sh3_256_train', dict(base, sh_deg=3, pos_dir_dim=0), 32, 26, TR, fg_train=True, bg_train=True, with_grad=True)
     # ... and at the reference's default sample counts (opts.py:32-35: 256 + 512 -- the other instantiation of the ray-stage kernels)
     case('render_default_samples_train', dict(), 8, 27, TR, fg_train=True, bg_train=True, with_grad=True)
+    # round 5: cluster_2d (the Quad configs) -- the routed render whose BACKGROUND is routed per sample on the true far-away point
+    # (margin 1.15, soft blend) and a hard-routed jointly trained case with the reference's gradients
+    case('render_container_2d_eval', dict(base, container_path='dummy', cluster_2d=True), 48, 28, E, container=4, cluster_2d=True)
+    case('render_joint_2d_train', dict(base, train_mega_nerf='dummy', cluster_2d=True), 64, 29, TR, container=4, joint=True, cluster_2d=True,
+         fg_train=True, bg_train=True, with_grad=True, layer_dim=64, bg_layer_dim=64)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

@@ -15,7 +15,7 @@ import torch
 
 import common
 from oracle import nerf_oracle as O
-from test_oracle_golden import MLP_VARIANTS, RENDER_CASES, build_case, load, mlp_variant  # noqa: F401
+from test_oracle_golden import MLP_VARIANTS, RENDER_CASES, build_case, check_index_agreement, load, mlp_variant  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -358,14 +358,10 @@ def test_render_rays_matches_reference(name):
             np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(b).max())), err_msg=k)
         else:
             np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5, err_msg=k)   # north star: 1e-4 rel on rgb/depth
-    # end-to-end sample-index agreement with the reference (upstream GEMM rounding differs by ~1e-6, so a
-    # handful of u values straddling a cdf entry may move by one bin)
+    # end-to-end sample-index agreement with the reference: measured and explained per fixture (test_oracle_golden.check_index_agreement)
     for part in ('fg', 'bg'):
         if 'inds_' + part in g and '_inds_' + part in rnd:
-            ref = g['inds_' + part].astype(np.int64)
-            got = rnd['_inds_' + part].cpu().numpy()[:ref.shape[0]]
-            mism = float((got != ref).mean())
-            assert mism < (5e-3 if part == 'fg' else 3e-2), (part, mism)
+            check_index_agreement(name, part, rnd['_inds_' + part].cpu().numpy(), g['inds_' + part])
 
 
 def test_render_rays_raises_when_camera_outside_sphere():
@@ -705,27 +701,43 @@ def test_train_step_equals_a_plain_adam_loop():
     assert runs[1][-1] < runs[1][0] and runs[0][-1] < runs[0][0], runs
 
 
-def test_meganerf_router_forward_matches_oracle():
-    """MegaNeRF.forward (device routing + gathered per-cell launches) vs the numpy oracle, hard and blended."""
+@pytest.mark.parametrize('cluster_2d', [False, True])
+@pytest.mark.parametrize('xyz_real', [False, True])
+def test_meganerf_router_forward_matches_oracle(cluster_2d, xyz_real):
+    """MegaNeRF.forward (device routing + gathered per-cell launches; mega_nerf.py:19-61) vs the numpy oracle: hard and blended routing,
+    3-D and `cluster_2d` distances, foreground rows and background rows that carry their routing point in front (`xyz_real`, Q15).
+    Every row must agree to 1e-4 unless its ROUTING sits on a rounding edge -- counted and explained, not budgeted: blended, a cell
+    whose distance ratio is within 1e-5 of the margin (it is in or out of the blend); hard, two nearest centroids within 1e-6."""
     from mega_nerf.models.mega_nerf import MegaNeRF
-    hp, cfg, _ = mlp_variant('fg')
+    hp, cfg, _ = mlp_variant('bg' if xyz_real else 'fg')
     rng = np.random.default_rng(4)
     cent = np.array([[0, -.4, -.4], [0, -.4, .4], [0, .4, -.4], [0, .4, .4]], f32)
     subs_w = [common.make_weights(cfg, 100, 300 + i, sharpen=False) for i in range(4)]
     B = 1000
-    x = np.concatenate([rng.uniform(-.8, .8, (B, 3)), rng.standard_normal((B, 3)), rng.integers(0, 100, (B, 1))], 1).astype(f32)
+    pos = rng.uniform(-.8, .8, (B, cfg.xyz_dim))
+    x = np.concatenate([pos, rng.standard_normal((B, 3)), rng.integers(0, 100, (B, 1))], 1).astype(f32)
+    if xyz_real:                              # [xyz_real(3) | p_sphere(3) inv_depth(1) | dir(3) | idx(1)]: routed on the first three columns
+        x = np.concatenate([rng.uniform(-.8, .8, (B, 3)).astype(f32), x], 1)
+    c0 = 1 if cluster_2d else 0
+    d = np.sqrt(((x[:, None, c0:3].astype(np.float64) - cent[None, :, c0:].astype(np.float64)) ** 2).sum(-1))
+    ds = np.sort(d, 1)
     for margin in (1.0, 1.15):
-        m = MegaNeRF([native_nerf(cfg, w) for w in subs_w], torch.from_numpy(cent), margin, False, False).to(DEV).eval()
+        m = MegaNeRF([native_nerf(cfg, w) for w in subs_w], torch.from_numpy(cent), margin, xyz_real, cluster_2d).to(DEV).eval()
         with torch.no_grad():
             got = m(T(x)).cpu().numpy()
-            got_s = m(T(x[:, :3]), sigma_only=True).cpu().numpy()
-        exp = O.mega_nerf_forward(subs_w, cfg, cent, margin, False, False, x)
-        exp_s = O.mega_nerf_forward(subs_w, cfg, cent, margin, False, False, x[:, :3], sigma_only=True)
-        # a sample whose distance ratio sits within rounding of the margin may be blended differently: allow a few
-        bad = np.abs(got - exp).max(-1) > 1e-4 * (1 + np.abs(exp).max(-1))
-        assert bad.mean() < 5e-3, (margin, bad.mean())
-        bad = np.abs(got_s - exp_s).max(-1) > 1e-4 * (1 + np.abs(exp_s).max(-1))
-        assert bad.mean() < 5e-3, (margin, bad.mean())
+            got_s = m(T(np.ascontiguousarray(x[:, :(3 if xyz_real else 0) + cfg.xyz_dim])), sigma_only=True).cpu().numpy()
+        exp = O.mega_nerf_forward(subs_w, cfg, cent, margin, xyz_real, cluster_2d, x)
+        exp_s = O.mega_nerf_forward(subs_w, cfg, cent, margin, xyz_real, cluster_2d, x[:, :(3 if xyz_real else 0) + cfg.xyz_dim], sigma_only=True)
+        if margin > 1:
+            edge = (np.abs(d / ds[:, :1] - margin) < 1e-5).any(1)
+        else:
+            edge = (ds[:, 1] - ds[:, 0]) < 1e-6 * ds[:, 1]
+        for a, b in ((got, exp), (got_s, exp_s)):
+            bad = np.abs(a - b).max(-1) > 1e-4 * (1 + np.abs(b).max(-1))
+            print('margin %.2f cluster_2d %s xyz_real %s: rows beyond 1e-4: %d of %d, of which on a routing edge: %d'
+                  % (margin, cluster_2d, xyz_real, bad.sum(), B, (bad & edge).sum()))
+            assert not (bad & ~edge).any(), (margin, np.flatnonzero(bad & ~edge)[:8])
+            assert bad.sum() <= 2                  # (measured: 0)
 
 
 def test_psnr_within_0p05_db_of_reference():

@@ -12,7 +12,7 @@ import torch
 import common
 import fp64_ref
 from oracle import nerf_oracle as O
-from test_oracle_golden import OVERFIT_KEYS, build_case, load, mlp_variant, overfit_case, rays_beyond_bound
+from test_oracle_golden import OVERFIT_KEYS, build_case, check_index_agreement, load, mlp_variant, overfit_case, rays_beyond_bound
 from test_gpu_parity import DEV, T, close, native_models, native_nerf
 
 pytestmark = pytest.mark.gpu
@@ -61,7 +61,8 @@ def test_remaining_mlp_variants(name):
         close(m(x[:, :cfg.xyz_dim].contiguous(), sigma_only=True), g[name + '_sigma_only'], 1e-4, 2e-6)
 
 
-@pytest.mark.parametrize('name', ['render_sh3_eval', 'render_container8_eval', 'render_container_w512_eval', 'render_container25_eval'])
+@pytest.mark.parametrize('name', ['render_sh3_eval', 'render_container8_eval', 'render_container_w512_eval', 'render_container25_eval',
+                                  'render_container_2d_eval'])
 def test_new_render_goldens(name):
     from mega_nerf.rendering import render_rays
     g = load(name)
@@ -69,14 +70,19 @@ def test_new_render_goldens(name):
     s = common.SCENE
     idx = T(g['idx'].astype(f32))
     flags = [bool(v) for v in g['flags']]
+    rnd = {'_want_inds': True}
     with torch.no_grad():
-        res, present = render_rays(nerf, bg_nerf, T(g['rays']), idx, Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']), *flags)
+        res, present = render_rays(nerf, bg_nerf, T(g['rays']), idx, Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']), *flags,
+                                   _randoms=rnd)
     ref_keys = sorted(k[4:] for k in g if k.startswith('res_'))
     assert sorted(res.keys()) == ref_keys and present == bool(g['present'])
     for k in ref_keys:
         a, b = res[k].cpu().numpy(), g['res_' + k]
         tol = dict(rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(b).max()))) if 'variance' in k else dict(rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(a, b, err_msg=k, **tol)
+    for part in ('fg', 'bg'):
+        if 'inds_' + part in g and '_inds_' + part in rnd:
+            check_index_agreement(name, part, rnd['_inds_' + part].cpu().numpy(), g['inds_' + part])
 
 
 def test_containers_of_a_pass_share_one_launch():
@@ -238,7 +244,7 @@ def _benchmark_shape_check(train_steps=0, max_offenders=9, same_batch=False):
         # "bit-exact sample indices", stated as the mechanism: an index may differ from the oracle's only (i) at the last u = 1.0, which
         # sits on cdf[-1] = 1 -+ ulp, or (ii) where u is within GEMM rounding of a cdf entry, in which case the SAMPLE does not move
         # (_sample_cdf is continuous across an entry), or (iii) across a run of zero-probability bins (equal cdf entries)
-        assert moved.mean() < 5e-3
+        assert moved[:, :-1].sum() <= 8 and moved[:, -1].sum() <= 1024          # measured: 4 / 221; the last u: <= one per ray
         zg_, zo_ = rnd['_fine_z_fg'].cpu().numpy(), dbg['fg']['fine_z']
         inner = np.argwhere(moved[:, :-1])
         jumps = 0

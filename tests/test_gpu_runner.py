@@ -220,3 +220,57 @@ def test_render_images_script_writes_the_reference_tree(tmp_path):
     # without --resume an existing output tree is refused, as the reference's mkdir(exist_ok=False) does
     with pytest.raises(FileExistsError):
         mod.main(mod._get_render_opts(argv))
+
+
+def test_train_cells_job_two_ranks_merges_in_job_and_evaluates(tmp_path):
+    """The north-star multi-GPU job (`mega-nerf_amd/tools/train_cells.py`; reference: parscripts/run_8.txt:1-8 + scripts/merge_submodules.py:33-78
+    + runner.py:495-510) launched by `torch.distributed.run` with 2 ranks -- sharing this box's one GPU over gloo, the way
+    test_two_ranks_step_the_fixed_eight_cell_set does (RCCL refuses two ranks on one device): 4 cells of a 2 x 2 grid dealt 2 + 2, each
+    trained on its cluster-masked pixels with no collective, merged by ONE all_gather, evaluated image-parallel with one all_reduce.
+      * the in-job container is BIT-IDENTICAL to the one scripts/merge_submodules.py builds from the same ranks' checkpoint files;
+      * every rank ends with the same all-reduced validation PSNR / SSIM, and it is what a single-process eval of the container gives."""
+    import json
+    import os
+    data = tmp_path / 'data'
+    tools = ROOT / 'mega-nerf_amd' / 'tools'
+    scripts = ROOT / 'mega-nerf_amd' / 'scripts'
+    subprocess.run([sys.executable, str(tools / 'make_synthetic_dataset.py'), '--out', str(data), '--images', '8', '--val_every', '4',
+                    '--size', '32', '--samples', '32', '64'], check=True)
+    flags = ['--dataset_path', str(data), '--coarse_samples', '64', '--fine_samples', '128', '--near', '0.01', '--ray_altitude_range', '-0.5', '0.2',
+             '--val_scale_factor', '1', '--boundary_margin', '1.5']
+    masks = tmp_path / 'masks'
+    subprocess.run([sys.executable, str(scripts / 'create_cluster_masks.py'), '--output', str(masks), '--grid_dim', '2', '2', '--ray_samples', '64'] + flags,
+                   check=True)
+    assert (masks / 'params.pt').exists() and sorted(p.name for p in masks.iterdir() if p.is_dir()) == ['0', '1', '2', '3']
+    exp = tmp_path / 'job'
+    env = dict(os.environ, MNR_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', MNR_NO_VAL_IMAGES='1')
+    train_flags = flags + ['--train_iterations', '6', '--ckpt_interval', '6', '--val_interval', '1000', '--batch_size', '256']
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29541', str(tools / 'train_cells.py'), '--mask_path', str(masks), '--exp_name', str(exp)] + train_flags,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [json.loads(ln.split('TRAIN_CELLS ', 1)[1]) for ln in r.stdout.splitlines() if 'TRAIN_CELLS ' in ln]
+    assert sorted(ln['rank'] for ln in lines) == [0, 1] and {tuple(ln['cells']) for ln in lines} == {(0, 2), (1, 3)}
+    assert lines[0]['val_psnr'] == lines[1]['val_psnr'] and lines[0]['val_ssim'] == lines[1]['val_ssim'] and lines[0]['val_psnr'] > 3.0
+    for j in range(4):                                   # checkpoints where the reference's per-cell runs put them
+        assert (tmp_path / 'job-{}'.format(j) / '0' / 'models' / '6.pt').exists(), j
+    assert 'Average val/psnr' in (tmp_path / 'job-eval' / '0' / 'metrics.txt').read_text()
+    # the reference's file hand-off over the same checkpoints
+    by_file = tmp_path / 'by_file.pt'
+    subprocess.run([sys.executable, str(scripts / 'merge_submodules.py'), '--ckpt_prefix', str(tmp_path / 'job-'), '--centroid_path', str(masks / 'params.pt'),
+                    '--output', str(by_file), '--train_iterations', '6'] + flags[2:], check=True, env=env)
+    a = torch.jit.load(str(tmp_path / 'job-merged.pt'), map_location='cpu').state_dict()
+    b = torch.jit.load(str(by_file), map_location='cpu').state_dict()
+    assert a.keys() == b.keys() and len(a) > 100
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # a single-process evaluation of the merged container reproduces the job's all-reduced metrics
+    from mega_nerf import eval as ev
+    from mega_nerf.opts import get_opts_base
+    p = get_opts_base()
+    p.add_argument('--exp_name', type=str, required=True)
+    p.add_argument('--dataset_path', type=str, required=True)
+    ev.main(p.parse_args(flags + ['--exp_name', str(tmp_path / 'solo'), '--container_path', str(tmp_path / 'job-merged.pt')]))
+    solo = (tmp_path / 'solo' / '0' / 'metrics.txt').read_text()
+    solo_psnr = float([ln for ln in solo.splitlines() if ln.startswith('Average val/psnr')][0].split(':')[1])
+    assert abs(solo_psnr - lines[0]['val_psnr']) < 1e-4, (solo_psnr, lines[0]['val_psnr'])

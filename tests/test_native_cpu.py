@@ -97,3 +97,29 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
     for n, cls in names.items():
         assert int(sizes[n]) == ctypes.sizeof(cls), (n, sizes[n], ctypes.sizeof(cls))
     assert int(sizes['mnr_mlp_cell']) == 5 * 8            # MegaNeRF._routed packs cells as rows of five int64
+
+
+# Kernels of the one-call paths (mnr_train_step / mnr_render_fwd: csrc/step.hip's launch sequences) and of the routed render: none of
+# them may touch scratch.  A spilled VGPR is a scratch_store / scratch_load pair inside the instruction stream (each reload a vmcnt
+# dependency) plus HBM write-back traffic; round 4 shipped 51-182 of them in kernels the design notes called spill-free.  The check
+# reads the code objects' own metadata (tools/kernel_resources.py), so it runs on the CPU and spills cannot come back silently.
+NO_SCRATCH_KERNELS = ('k_mlp_fwd_multi<', 'k_mlp_bwd_multi<', 'k_mlp_fwd<', 'k_wgrad2<0, false>', 'k_wgrad2<1, false>',
+                      'k_wgrad2_reduce', 'k_head_grads', 'k_sh_head_bwd', 'k_step_', 'k_render_tail', 'k_route', 'k_tgemm')
+
+
+def test_hot_path_kernels_have_no_scratch():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kernel_resources', ROOT / 'mega-nerf_amd' / 'tools' / 'kernel_resources.py')
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not kr.tools_available():
+        pytest.skip('llvm-objdump / llvm-readelf not found')
+    ks = kr.kernel_resources(str(N.LIB_PATH))
+    assert len(ks) > 100
+    hot = [k for k in ks if any(('mnr::' + p) in k['name'] for p in NO_SCRATCH_KERNELS)]
+    assert len(hot) >= 36, len(hot)
+    # (a spill count with a zero-byte private segment = registers parked in AGPRs by the one-wavefront-per-SIMD 512-wide kernel, which
+    # owns all 512 registers: v_accvgpr moves, no memory traffic -- allowed, two of them at the time of writing)
+    bad = [(k['name'][:120], k['vgpr_spill_count'], k['private_segment_fixed_size']) for k in hot
+           if k['private_segment_fixed_size'] or (k['vgpr_spill_count'] and k['vgpr_count'] <= 256)]
+    assert not bad, bad

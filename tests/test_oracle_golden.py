@@ -112,6 +112,32 @@ def test_mlp_forward(name):
         O.nerf_forward(w, cfg, x[:, :-1] if x.shape[1] > cfg.xyz_dim else np.zeros((3, cfg.xyz_dim + 5), f32))
 
 
+
+# ---- "bit-exact sample indices", end to end ------------------------------------------------------------------------------------
+# Stage level (identical inputs) the indices ARE bit-exact (test_sample_pdf_*).  End to end the inputs are a GEMM's outputs, and two
+# fp32 GEMM implementations round differently; what that can move, measured over every fixture (numpy oracle AND the HIP path):
+#  * the LAST deterministic sample of a ray: u = linspace(0, 1, Nf) ends in exactly 1.0 while cdf[-1] is 1 - ulp or 1 (+ ulp) depending
+#    on the last bits of the pdf -> searchsorted(right=True) returns Nc - 1 or Nc - 2 (`inds` differs by one) -- and _sample_cdf
+#    (rendering.py:521-534) yields the same z either way: below / above clamp to the last bin, t -> 1.  18 of 96 rays in
+#    render_fgbg_eval, 3 of 13 background rays; never in training mode (random u).  Counted, not bounded: at most one per ray.
+#  * anything else is a u that straddles a cdf entry by an ulp: measured 0 in every 64 + 128 fixture, 1 of 4 096 at 256 + 512 samples
+#    (cdf steps of 1e-3 instead of 1e-2).  Bound: INDEX_OTHER_MAX (<= 2 x measured, 0 where 0 was measured).
+INDEX_OTHER_MAX = {'render_default_samples_eval': 2, 'render_default_samples_train': 2}
+INDEX_LOG = []
+
+
+def check_index_agreement(name, part, got, ref, other_max=None):
+    ref = np.asarray(ref).astype(np.int64)
+    got = np.asarray(got).astype(np.int64)[:ref.shape[0]]
+    diff = got != ref
+    last, other = int(diff[..., -1].sum()), int(diff[..., :-1].sum())
+    INDEX_LOG.append(dict(fixture=name, part=part, indices=int(ref.size), rays=int(ref.shape[0]), last_u=last, other=other))
+    bound = INDEX_OTHER_MAX.get(name, 0) if other_max is None else other_max
+    assert other <= bound, (name, part, 'indices off the last column that differ', other, 'of', ref.size, 'bound', bound)
+    assert np.abs(got - ref)[diff].max(initial=0) <= 1, (name, part, 'an index moved by more than one bin')
+    return last, other
+
+
 # ---- end-to-end render_rays ---------------------------------------------------------------------
 RENDER_CASES = {
     'render_fgbg_eval': dict(hp=dict(), seed=1),
@@ -144,6 +170,10 @@ RENDER_CASES = {
     'render_container25_eval': dict(hp=dict(container_path='dummy', layer_dim=512, bg_layer_dim=512), seed=25, container=25),
     'render_nerf_cfg_train': dict(hp=dict(coarse_samples=48, fine_samples=0, use_cascade=True, appearance_dim=0, layer_dim=160),
                                   seed=15, bg=False, cascade=True, fg_train=True),
+    # cluster_2d (Quad configs): distances over dims 1:3, background routed per sample on the true far-away point
+    'render_container_2d_eval': dict(hp=dict(container_path='dummy'), seed=28, container=4, cluster_2d=True),
+    'render_joint_2d_train': dict(hp=dict(train_mega_nerf='dummy', layer_dim=64, bg_layer_dim=64), seed=29, container=4, joint=True,
+                                  cluster_2d=True, fg_train=True, bg_train=True),
 }
 
 
@@ -165,9 +195,9 @@ def build_case(name):
         cent = g['centroids']
         margin = 1.0 if c.get('joint') else hp.boundary_margin          # --train_mega_nerf routes hard (model_utils.py:37-42)
         nerf = O.Model(fcfg, subs=[common.make_weights(fcfg, A, seed * 1000 + i) for i in range(n)], centroids=cent,
-                       boundary_margin=margin, xyz_real=False, training=ft)
+                       boundary_margin=margin, xyz_real=False, cluster_2d=c.get('cluster_2d', False), training=ft)
         bg_nerf = O.Model(bcfg, subs=[common.make_weights(bcfg, A, seed * 1000 + 500 + i) for i in range(n)],
-                          centroids=cent, boundary_margin=margin, xyz_real=True, training=bt)
+                          centroids=cent, boundary_margin=margin, xyz_real=True, cluster_2d=c.get('cluster_2d', False), training=bt)
     elif c.get('cascade'):
         nerf = O.Model(fcfg, cascade=(common.make_weights(fcfg, A, seed * 1000),
                                       common.make_weights(fcfg, A, seed * 1000 + 1)), training=ft)
@@ -208,12 +238,9 @@ def test_render_rays_matches_reference(name):
             close(a, b, 1e-3, 1e-4 * max(1.0, float(np.abs(b).max())))
         else:
             close(a, b, 2e-4, 2e-5)
-    # searchsorted indices: upstream GEMM rounding differs (numpy vs MKL), so report the mismatch
-    # rate rather than demanding equality end-to-end (stage-level equality is tested above).
     for part in ('fg', 'bg'):
         if 'inds_' + part in g and part in dbg and 'inds' in dbg[part]:
-            mism = float((dbg[part]['inds'] != g['inds_' + part].astype(np.int64)).mean())
-            assert mism < (5e-3 if part == "fg" else 3e-2), (part, mism)
+            check_index_agreement(name, part, dbg[part]['inds'], g['inds_' + part])
 
 
 # ---- torch-CPU baseline oracle (oracle/torch_oracle.py) -------------------------------------------
