@@ -170,6 +170,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
     }
 
     // ---- final^T (+ sigma head): dZ of trunk layer L-1 ---------------------------------------------
+    constexpr bool PUBT = seg_weaves<TILE, NOB, H / 4, C::GPC, 0>();
     AccT acc[NOB];
     {
         const float *ws = aux + a.sigma_off + part * H;
@@ -184,7 +185,8 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[C::NL - 1] * cap, trow, a.tl.mask_w, part);
         st.next_chunk();
         gtape_store<P>(g, a.gtape + a.tl.fin_off * cap, (unsigned)((trow * W + 4 * part) * 4), valid);
-        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
+        // (woven pipeline: every W x W layer publishes its successor's first chunk two batches before its own end -- run_segment PUB_END)
+        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && C::NL > 1)>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
     }
@@ -194,9 +196,9 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         constexpr int l = C::NL - 1 - decltype(jc)::value;       // consumes dZ_l, produces dZ_{l-1}
         zero_acc(acc);
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);
-        st.next_chunk();
+        if constexpr (!PUBT) st.next_chunk();
         gtape_store<P>(g, a.gtape + a.tl.act_off[l] * cap, (unsigned)((trow * W + 4 * part) * 4), valid);       // dZ_l (deferred, see gtape_store)
-        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, g, st, lane);
+        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && l > 1)>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
     });

@@ -167,6 +167,7 @@ __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0
 // an empty asm that "redefines" a register: MFMAs consuming it cannot be scheduled above the wait that precedes the pin
 __device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(floatx4 &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(floatx16 &x) { asm volatile("" : "+v"(x)); }
 
 // Static schedule of a K segment's fragment batches (TILE = 16): batch t = (group G0 + t / NBATCH, blocks (t % NBATCH) * OBB ..).  A "run" is
 // a stretch of batches inside one weight chunk; its fragment reads are software-pipelined two batches deep and restart behind the
@@ -232,11 +233,21 @@ __device__ __forceinline__ void frag_mfmas_weave(floatx4 (&acc)[NOB], floatx4 (&
     });
 }
 
+// does run_segment<TILE, NOB, NG, GPC, G0> take the woven one-pipeline form (and can it therefore publish the next layer's first chunk)?
+template <int TILE, int NOB, int NG, int GPC, int G0>
+constexpr bool seg_weaves() {
+    constexpr int OBB = NOB < 4 ? NOB : 4, NBATCH = NOB / OBB, T = NG * NBATCH;
+    return MNR_FRAG_WEAVE && TILE == 16 && OBB == 4 && T >= 2 && !SegSched<NBATCH, GPC, G0, T>::chunk_start(1);
+}
+
 // One K segment of a layer: NG groups of 4 steps whose B operands are b[0 .. 4*NG).
 // G0 = index of the segment's first group inside the layer (chunk boundaries are static).
-template <int TILE, int NOB, int NG, int GPC, int G0, class AccT, int NB, class Stream>
+// PUB_END (woven form only): this is a layer's LAST segment and another layer follows -- its first chunk is published from here, two
+// batches before the end, exactly like a chunk boundary inside the segment; the caller then skips the next layer's next_chunk().
+template <int TILE, int NOB, int NG, int GPC, int G0, bool PUB_END = false, class AccT, int NB, class Stream>
 __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], Stream &st, int lane) {
     static_assert(NB >= 4 * NG, "B register array too small");
+    static_assert(!PUB_END || seg_weaves<TILE, NOB, NG, GPC, G0>(), "only the woven pipeline publishes ahead");
     if constexpr (TILE == 32) {
         static_for<0, NG>([&](auto gi) {
             constexpr int g = G0 + decltype(gi)::value;
@@ -262,7 +273,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
         using S = SegSched<NBATCH, GPC, G0, T>;
         unsigned addr = 0;
         // (a segment whose SECOND batch opens a chunk -- 64-wide test models only -- takes the restartable form below)
-        if constexpr (MNR_FRAG_WEAVE && OBB == 4 && !(T > 1 && S::chunk_start(1))) {
+        if constexpr (seg_weaves<TILE, NOB, NG, GPC, G0>()) {
             // ONE software pipeline over the whole segment.  Three fragment buffers: batch t computes from one, batch t + 1 is in flight in
             // the second, batch t + 2 is requested -- one read behind each K step of batch t -- into the third (released by batch t - 1).
             // Chunk boundaries do not restart it: when batch t + 2 opens a new weight chunk, the chunk barrier is taken at the START of
@@ -280,7 +291,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
             static_for<0, T>([&](auto tc) {
                 constexpr int t = decltype(tc)::value, u = t + 2;
                 constexpr int gl = t / NBATCH;
-                constexpr bool early = u < T && S::chunk_start(u);
+                constexpr bool early = (u < T && S::chunk_start(u)) || (PUB_END && u == T);
                 if constexpr (early) {
                     wait_lgkm<0>();
                     st.publish();

@@ -112,7 +112,7 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
 // a lane-private LDS slot behind the weight ring (ED floats per lane; slot i of thread t at (i * NT + t) * 4: conflict-free) and read
 // back in front of its K segment.  asm on both sides: a compiler-visible access to the ring's array would get a vmcnt(0) (mlp_device.h).
 template <class C, int NW>
-constexpr size_t fwd_lds_bytes() { return (size_t)2 * CHUNK_BYTES + (size_t)C::ED * 64 * NW * 4; }
+constexpr size_t fwd_lds_bytes() { return (size_t)2 * CHUNK_BYTES + (size_t)C::ED * 64 * NW * 4 + (size_t)2 * C::W * 4; }
 template <int I, int NT>
 __device__ __forceinline__ void stash_put(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(I * NT * 4) : "memory"); }
 template <int I, int NT>
@@ -120,6 +120,38 @@ __device__ __forceinline__ float stash_get(unsigned addr) {
     float v;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(I * NT * 4) : "memory");
     return v;
+}
+
+// Biases through LDS.  A layer's accumulators start as its bias (64 registers per lane at W = 256); fetched from the aux block with vector
+// loads at the top of every layer, they put an L2 round trip in front of the layer's first MFMA (1.5 % of the forward kernels, measured
+// with a zero-bias build in round 4) and, being FLAT loads, counted on lgkmcnt as well.  Now the NEXT layer's bias row (W floats = one
+// 16-byte piece per lane of W / 4 lanes) rides the LDS-DMA engine like the weight chunks do: requested at the top of a layer into one
+// of two slots behind the encoding stash, published by the chunk barriers in between, read with W / 64 broadcast ds_read_b128 per lane.
+template <int W, int NT>
+__device__ __forceinline__ void bias_dma(const float *aux_bias, float4 *slot) {
+    if ((int)threadIdx.x < W / 4) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        unsigned lo = threadIdx.x * 16u;
+        asm("" : "+v"(lo));
+        __builtin_amdgcn_global_load_lds((global_cvoid_t *)(uniform_ptr(reinterpret_cast<const char *>(aux_bias)) + lo),
+                                         (lds_void_t *)(slot + wave * 64), 16, 0, 0);
+    }
+}
+template <int NOB, int RPB, class AccT>
+__device__ __forceinline__ void init_acc_lds(AccT (&acc)[NOB], unsigned addr) {      // addr: this lane-part's first bias float in the slot
+    constexpr int NQ = NOB * RPB / 4;
+    floatx4 t[NQ];
+    static_for<0, NQ>([&](auto qc) { t[decltype(qc)::value] = lds_ld4<decltype(qc)::value * 16>(addr); });
+    wait_lgkm<0>();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) pin(t[q]);                      // (uses stay behind the wait: the compiler does not see an asm read's latency)
+    static_for<0, NOB>([&](auto oc) {                               // (static indices: a 32-block instantiation left as a loop indexed `t` in scratch)
+        constexpr int ob = decltype(oc)::value;
+        static_for<0, RPB>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            acc[ob][r] = t[(ob * RPB + r) / 4][r % 4];
+        });
+    });
 }
 
 // NW = wavefronts per workgroup sharing one weight stream (4: two workgroups per CU; 8: one -- half the stream traffic and barriers per CU)
@@ -222,26 +254,43 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     AccT acc[NOB];
     int li = 0;   // MFMA layer counter (compile-time after unrolling)
 
+    // bias rows: two LDS slots behind the encoding stash, the next layer's row requested at the top of every layer (bias_dma above)
+    float4 *bias_slot = lds_ring + 2 * CHUNK_F4 + (C::ED * 64 * NW) / 4;
+    auto bias_at = [&](int layer, int regs_per_part) {
+        return lds_addr(bias_slot + (layer & 1) * (C::W / 4)) + (unsigned)(part * regs_per_part * 4);
+    };
+    bias_dma<C::W, 64 * NW>(aux + a.bias_off[0], bias_slot);
+    // a layer whose last K segment runs as the woven pipeline publishes the NEXT layer's first chunk itself (run_segment PUB_END)
+    constexpr bool PUB_PLAIN = seg_weaves<TILE, NOB, H / 4, C::GPC, 0>();
+    constexpr bool PUB_SKIP = seg_weaves<TILE, NOB, H / 4, C::GPC, C::EX / 4>();
+    constexpr bool PUB_L0 = seg_weaves<TILE, NOB, C::EX / 4, C::GPC, 0>();
+    auto publishes = [](int l) constexpr {             // does trunk layer l publish for its successor?
+        if (l + 1 >= C::NL && !C::HAS_FINAL) return false;
+        return l == 0 ? PUB_L0 : (((C::SKIP >> l) & 1) ? PUB_SKIP : PUB_PLAIN);
+    };
+
     // ---- trunk: nerf.py:127-130 ------------------------------------------------------------------
     static_for<0, C::NL>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        init_acc<NOB, RPB>(acc, aux + a.bias_off[l] + part * H);
-        st.next_chunk();
+        constexpr bool PUB = publishes(l);
+        if constexpr (l == 0 || !publishes(l > 0 ? l - 1 : 0)) st.next_chunk();
+        if constexpr (l + 1 < C::NL || C::HAS_FINAL) bias_dma<C::W, 64 * NW>(aux + a.bias_off[l + 1], bias_slot + ((l + 1) & 1) * (C::W / 4));
+        init_acc_lds<NOB, RPB>(acc, bias_at(l, H));
         if constexpr (TRAIN && l > 0) {
-            // Tape stores of the previous layer's output are issued right AFTER the chunk barrier: a barrier drains
-            // vmcnt, so stores issued just before one would stall the wave for a full HBM write round trip.
+            // Tape stores of the previous layer's output go out in front of the layer's first MFMAs: the next chunk barrier (which
+            // drains vmcnt) is six batches away, so a store issued here has ~3 000 cycles to retire.
             if (valid) {
                 tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
                 tape_store_mask<P>(a.tape + a.tl.mask_off[l - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
         if constexpr (l == 0) {
-            run_segment<TILE, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane);
+            run_segment<TILE, NOB, C::EX / 4, C::GPC, 0, PUB>(acc, ex, st, lane);
         } else if constexpr ((C::SKIP >> l) & 1) {
             run_segment<TILE, NOB, C::EX / 4, C::GPC, 0>(acc, ex, st, lane);
-            run_segment<TILE, NOB, H / 4, C::GPC, C::EX / 4>(acc, h, st, lane);
+            run_segment<TILE, NOB, H / 4, C::GPC, C::EX / 4, PUB>(acc, h, st, lane);
         } else {
-            run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
+            run_segment<TILE, NOB, H / 4, C::GPC, 0, PUB>(acc, h, st, lane);
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
     });
@@ -271,22 +320,23 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     float rgbraw[C::RGB];
     const float *wr = aux + a.rgb_off;
     if constexpr (C::HAS_FINAL) {
-        init_acc<NOB, RPB>(acc, aux + a.bias_off[li] + part * H);
-        st.next_chunk();
+        if constexpr (!publishes(C::NL - 1)) st.next_chunk();
+        bias_dma<C::W / 2, 64 * NW>(aux + a.bias_off[C::NL + 1], bias_slot + ((C::NL + 1) & 1) * (C::W / 4));
+        init_acc_lds<NOB, RPB>(acc, bias_at(C::NL, H));
         if constexpr (TRAIN) {                                   // deferred store of the last trunk layer (see above)
             if (valid) {
                 tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
                 tape_store_mask<P>(a.tape + a.tl.mask_off[C::NL - 1] * a.tape_rows, tape_row<TILE>(trow0), a.tl.mask_w, h, part);
             }
         }
-        run_segment<TILE, NOB, H / 4, C::GPC, 0>(acc, h, st, lane);
+        run_segment<TILE, NOB, H / 4, C::GPC, 0, PUB_PLAIN>(acc, h, st, lane);
         acc_to_regs<NOB, RPB, false>(h, acc);                    // xyz_encoding_final: no activation
         ++li;
 
         constexpr int NOB2 = C::NOB2, H2 = C::H2;
         AccT acc2[NOB2];
-        init_acc<NOB2, RPB>(acc2, aux + a.bias_off[li] + part * H2);
-        st.next_chunk();
+        if constexpr (!PUB_PLAIN) st.next_chunk();
+        init_acc_lds<NOB2, RPB>(acc2, bias_at(C::NL + 1, H2));
         if constexpr (TRAIN) {
             if (valid) tape_store_regs_part<P, 0, H / 4>(a.tape + a.tl.fin_off * a.tape_rows, tape_row_off<TILE>(trow0, C::W, part), h);
         }

@@ -43,7 +43,9 @@ int mnr::mlp_forward_multi_impl(const mnr_mlp_launch *segs, int n_segs, const Ce
         if (ok) return mlp_forward_multi_pair<CfgFG, CfgBG, 8>(segs, n_segs, cells, s);
     }
 #endif
-    return pair == 1 ? mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s) : mlp_forward_multi_sh(segs, n_segs, cells, pair, s);
+    // (pair codes 2 / 3 are the spherical-harmonics pairs of rgb_dim 27 / 48, i.e. of degree 2 / 3: passed on as the DEGREE)
+    const int sh_deg = pair == 2 ? 2 : 3;
+    return pair == 1 ? mlp_forward_multi_pair<CfgFG, CfgBG>(segs, n_segs, cells, s) : mlp_forward_multi_sh(segs, n_segs, cells, sh_deg, s);
 }
 
 extern "C" int mnr_mlp_forward_multi(const mnr_mlp_launch *segs, int n_segs, void *stream) {

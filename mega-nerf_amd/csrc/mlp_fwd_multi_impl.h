@@ -25,7 +25,9 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
         MNR_REQUIRE((L.tape_dev != nullptr) == train, "segments must be all training or all inference launches");
         MNR_REQUIRE(!L.io->row_index && !L.io->sigma_only, "segment %d: gather / sigma_only are single-launch features", i);
         // spherical-harmonics pair: the colour epilogue (eval_sh + sigmoid) must be ON -- a multi-segment launch writes 4 floats per row
-        MNR_REQUIRE(CfgFG::RGB == 3 ? L.io->apply_sh_deg < 0 : L.io->apply_sh_deg >= 0, "segment %d: apply_sh_deg does not fit the architecture", i);
+        // ... of exactly the degree the instantiated head has coefficients for: rgb_dim = 3 (deg + 1)^2 (27 <-> 2, 48 <-> 3)
+        MNR_REQUIRE(CfgFG::RGB == 3 ? L.io->apply_sh_deg < 0 : (L.io->apply_sh_deg >= 0 && 3 * (L.io->apply_sh_deg + 1) * (L.io->apply_sh_deg + 1) == CfgFG::RGB),
+                    "segment %d: apply_sh_deg %d does not fit an rgb head of %d outputs", i, L.io->apply_sh_deg, CfgFG::RGB);
         MNR_REQUIRE(L.io->rows_per_ray >= 1 && L.io->n_rows >= 0, "segment %d: bad row counts", i);
         MNR_REQUIRE(L.io->dir && L.io->idx && L.desc->embedding_a, "segment %d: dir / idx / embedding_a required", i);
         if (train) MNR_REQUIRE(L.tape_row0 >= 0 && L.tape_rows >= L.tape_row0 + L.io->n_rows, "segment %d: tape buffer too small", i);

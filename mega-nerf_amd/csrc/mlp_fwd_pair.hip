@@ -284,8 +284,13 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     {
         const float *ws = aux + a.sigma_off;
         float s = 0.f;
+        // (the head's weight loads stay behind the last exchange: hoisted into it, eight quads sat on top of its 64 own + 128 input
+        // + 32 partner registers and the tape-writing instantiation spilled 50)
+        asm volatile("" : "+v"(s)::"memory");
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
+            // eight weight quads in flight at most: left alone, hipcc requests all 32 up front (128 registers beside the 128 inputs)
+            if (q % 8 == 0 && q > 0) asm volatile("" : "+v"(s)::"memory");
             const float4 w4 = *reinterpret_cast<const float4 *>(ws + part * H + 4 * q);
             s = fmaf(h[4 * q + 0], w4.x, s); s = fmaf(h[4 * q + 1], w4.y, s);
             s = fmaf(h[4 * q + 2], w4.z, s); s = fmaf(h[4 * q + 3], w4.w, s);

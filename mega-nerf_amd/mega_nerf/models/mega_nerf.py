@@ -113,7 +113,10 @@ class MegaNeRF(nn.Module):
         allocator hands every evaluation the buffers of the previous one, so the last tables are kept (keyed by their content) and
         a changed table goes up from pinned memory without waiting.  A new table is a new tensor: launches still reading the old
         one keep it alive."""
-        key = tuple(v for r in rows for v in r)
+        # keyed by the STREAM as well: the upload is ordered on the stream that was current at first use, and a cache hit on another
+        # stream (rendering._render_ws renders per (device, stream)) would launch against the table with nothing ordering it behind
+        # that copy (ADVICE round 4)
+        key = (torch.cuda.current_stream(dev).cuda_stream,) + tuple(v for r in rows for v in r)
         cache = self.__dict__.setdefault('_cell_tables', {})
         hit = cache.get(key)
         if hit is not None:

@@ -159,7 +159,7 @@ class Runner:
         if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD') and \
                 fused_step_supported(self.nerf, self.bg_nerf, hp, hp.batch_size):
             trainer = CellTrainer(self.nerf, self.bg_nerf, hp, self.sphere_center, self.sphere_radius, optimizers, schedulers,
-                                  seed=int(hp.random_seed), iteration=train_iterations)
+                                  seed=int(hp.random_seed), iteration=train_iterations, plan_rays=int(hp.batch_size))
         self.trainer = trainer
         check_every = max(1, min(hp.ckpt_interval, 100))      # fused path: loss finiteness / sphere errors are checked at this interval
         filesystem = hp.dataset_type == 'filesystem'

@@ -20,6 +20,8 @@ rows routed hard to the nearest centroid) goes through the general path with per
 """
 from __future__ import annotations
 
+import math
+
 import ctypes as C
 from argparse import Namespace
 from typing import NamedTuple, Dict, Optional
@@ -1014,8 +1016,11 @@ class CellTrainer:
     def __init__(self, nerf: nn.Module, bg_nerf: Optional[nn.Module], hparams: Namespace, sphere_center, sphere_radius,
                  optimizers: Optional[Dict[str, torch.optim.Optimizer]] = None, schedulers: Optional[dict] = None,
                  lr: float = 5e-4, lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None,
-                 split_precision: bool = False, iteration: int = 0):
+                 split_precision: bool = False, iteration: int = 0, plan_rays: Optional[int] = None):
         self.nerf, self.bg_nerf, self.hparams = nerf, bg_nerf, hparams
+        # the batch size the one-call plan is built for (the trainer's nominal --batch_size): a ragged batch that happens to come first --
+        # right after a resume, say -- must not pin the plan to ITS size and send every full batch down the autograd path
+        self.plan_rays = plan_rays
         self.sc, self.sr = sphere_center, sphere_radius
         self._seed, self._split = seed, split_precision
         if optimizers is None:
@@ -1077,10 +1082,15 @@ class CellTrainer:
         """:meth:`step` for a batch given as rows of a device-resident training set: the fused step gathers them itself (no torch
         kernels at all in the iteration); anything the fused step does not take is gathered here and goes through :meth:`step`."""
         n = batch.select.numel()
-        if fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n) and (self.fused is None or n == self.fused.n_rays):
+        if fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n) and self._plan_takes(n):
             return self._fused_call(batch, n)
         sel = batch.select
         return self.step(batch.rays[sel], batch.img_indices[sel], batch.u8_table[batch.rgbs_u8[sel].long()])
+
+    def _plan_takes(self, n: int) -> bool:
+        if self.fused is not None:
+            return n == self.fused.n_rays
+        return self.plan_rays is None or n == self.plan_rays
 
     def _fused_call(self, batch, n: int):
         if self.fused is None:
@@ -1100,7 +1110,7 @@ class CellTrainer:
         fused path."""
         n = rays.shape[0]
         fusable = image_indices is not None and fused_step_supported(self.nerf, self.bg_nerf, self.hparams, n)
-        if fusable and (self.fused is None or n == self.fused.n_rays):
+        if fusable and self._plan_takes(n):
             return self._fused_call((rays, image_indices, rgbs), n)
         self.iteration += 1
         # stage-by-stage path under autograd, same optimisers (their state tensors are the plan's buffers when one exists)
@@ -1113,6 +1123,13 @@ class CellTrainer:
         loss = torch.nn.functional.mse_loss(results['rgb_' + typ], rgbs, reduction='mean')
         if self.hparams.use_cascade and typ != 'coarse':
             loss = (loss + torch.nn.functional.mse_loss(results['rgb_coarse'], rgbs, reduction='mean')) / 2
+        # this path synchronises anyway (n_bg below), so it checks what the reference checks every iteration (rendering.py:412-414,
+        # runner.py:260-261) BEFORE Adam can write a non-finite update into the weights
+        if err is not None and int(err.max().item()) != 0:
+            from mega_nerf.rendering import _ERR_TEXT
+            raise Exception(_ERR_TEXT)
+        if not math.isfinite(float(loss.detach())):
+            raise Exception('Train metrics not finite: {}'.format({'loss': float(loss.detach())}))
         loss.backward()
         bg_present = n_bg is not None and int(n_bg.item()) > 0          # runner.py:268-272 (this path synchronises, like the reference)
         for key, o in self.optimizers.items():
