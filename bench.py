@@ -46,7 +46,7 @@ FG_FLOP_PER_SAMPLE = 1211392      # 2 x 605 696 MAC
 BG_FLOP_PER_SAMPLE = 1236992
 HEAD_FLOP_PER_SAMPLE = 2 * (256 + 3 * 128)          # sigma / rgb heads: VALU, not part of the MFMA kernels' work
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
-PMC_FILE = ROOT / 'profiles' / 'r04_pmc_summary.json'
+PMC_FILE = ROOT / 'profiles' / 'r05_pmc_summary.json'
 
 
 def build_models(hp, dev, seed, layer_dim=256):

@@ -192,7 +192,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
     }
 
     // ---- trunk layers L-1 .. 1 transposed ------------------------------------------------------------
-    static_for<0, C::NL - 1>([&](auto jc) {
+    static_for<0, C::NL - 1>([&](auto jc) __attribute__((always_inline)) {
         constexpr int l = C::NL - 1 - decltype(jc)::value;       // consumes dZ_l, produces dZ_{l-1}
         zero_acc(acc);
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);

@@ -215,7 +215,7 @@ __device__ __forceinline__ void frag_mfmas_weave(floatx4 (&acc)[NOB], floatx4 (&
 #pragma unroll
     for (int ob = 0; ob < OBB; ++ob) pin(a[ob]);
     const float bk[4] = {b0, b1, b2, b3};
-    static_for<0, 4>([&](auto kc) {
+    static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll
         for (int ob = 0; ob < OBB; ++ob) acc[O0 + ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][k], bk[k], acc[O0 + ob], 0, 0, 0);
@@ -288,7 +288,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
             addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
             frag_load<G0 % GPC, 0, NOB>(a[0], addr);
             if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * OBB, NOB>(a[1], addr);
-            static_for<0, T>([&](auto tc) {
+            static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, u = t + 2;
                 constexpr int gl = t / NBATCH;
                 constexpr bool early = (u < T && S::chunk_start(u)) || (PUB_END && u == T);
@@ -309,7 +309,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
             constexpr int D = MNR_FRAG_DEPTH;                  // fragment batches in flight
             static_assert(OBB * (D - 1) <= 15, "lgkmcnt is a 4-bit counter");
             floatx4 a[D][OBB];
-            static_for<0, T>([&](auto tc) {
+            static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, t0 = S::run_start(t), t1 = S::run_end(t);
                 constexpr int gl = t / NBATCH;
                 if constexpr (t == t0) {

@@ -31,6 +31,12 @@ namespace mnr {
 // mlp_fwd_pair.hip: 512-wide default architectures, two wavefronts per SIMD (a wavefront pair splits the output features)
 int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                               const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0);
+// mlp_fwd_wide.hip / mlp_fwd_variants.hip: the remaining inference instantiations (their own translation units: the instantiations of this
+// file alone compiled for ten minutes); 1 = "not mine", otherwise the launch's return code
+int mlp_forward_wide_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                              const mnr_mlp_cell *cells, int n_cells);
+int mlp_forward_variants_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                                  const mnr_mlp_cell *cells, int n_cells);
 // mlp_fwd_train.hip: launches the tape-writing instantiation for this architecture (MNR_E_UNSUPPORTED if there is none)
 int mlp_forward_train_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                                float *tape, long tape_rows, long tape_row0);
@@ -139,23 +145,12 @@ static int mlp_forward_impl(const void *packed_dev, const mnr_model_desc *d, con
         const int prc = mlp_forward_pair_dispatch(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
         if (prc != MNR_E_UNSUPPORTED) return prc;
     }
-    MNR_TRY(3, 12, 4, 48, 512, 8, 16, 3)
-    MNR_TRY(4, 12, 4, 48, 512, 8, 16, 3)
-#ifdef MNR_ALL_VARIANTS
-    // configs/mega-nerf-sh-3 (sh_deg 2, pos_dir_dim 0)
-    MNR_TRY(3, 12, 0, 48, 256, 8, 16, 27)
-    MNR_TRY(4, 12, 0, 48, 256, 8, 16, 27)
-    // sh_deg 3 (BASELINE.json's wording of configs[4]): 48 colour coefficients
-    MNR_TRY(3, 12, 0, 48, 256, 8, 16, 48)
-    MNR_TRY(4, 12, 0, 48, 256, 8, 16, 48)
-    // small-width models used by the cascade tests
-    MNR_TRY(3, 12, 4, 0, 64, 8, 16, 3)
-    MNR_TRY(3, 12, 4, 48, 64, 8, 16, 3)
-    MNR_TRY(4, 12, 4, 48, 64, 8, 16, 3)
-    // appearance_dim 0 (configs/mega-nerf-no-embed, configs/npp)
-    MNR_TRY(3, 12, 4, 0, 256, 8, 16, 3)
-    MNR_TRY(4, 12, 4, 0, 256, 8, 16, 3)
-#endif
+    {
+        int orc = mlp_forward_wide_dispatch(m, packed_dev, d, io, s, cells, n_cells);          // one wavefront per SIMD at 512 channels (comparison runs)
+        if (orc != 1) return orc;
+        orc = mlp_forward_variants_dispatch(m, packed_dev, d, io, s, cells, n_cells);          // SH heads, 64-wide test models, no appearance
+        if (orc != 1) return orc;
+    }
 #undef MNR_TRY
 #undef MNR_TRY_T
     return set_err(MNR_E_UNSUPPORTED,

@@ -139,17 +139,21 @@ __device__ __forceinline__ void bias_dma(const float *aux_bias, float4 *slot) {
 }
 template <int NOB, int RPB, class AccT>
 __device__ __forceinline__ void init_acc_lds(AccT (&acc)[NOB], unsigned addr) {      // addr: this lane-part's first bias float in the slot
-    constexpr int NQ = NOB * RPB / 4;
-    floatx4 t[NQ];
-    static_for<0, NQ>([&](auto qc) { t[decltype(qc)::value] = lds_ld4<decltype(qc)::value * 16>(addr); });
-    wait_lgkm<0>();
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) pin(t[q]);                      // (uses stay behind the wait: the compiler does not see an asm read's latency)
-    static_for<0, NOB>([&](auto oc) {                               // (static indices: a 32-block instantiation left as a loop indexed `t` in scratch)
-        constexpr int ob = decltype(oc)::value;
-        static_for<0, RPB>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            acc[ob][r] = t[(ob * RPB + r) / 4][r % 4];
+    // eight quads per round (a 32-block layer in one round left the whole kernel's arrays in scratch: hipcc gave up promoting them)
+    constexpr int NQ = NOB * RPB / 4, QR = NQ < 8 ? NQ : 8;
+    static_assert(NQ % QR == 0, "bias quads per round");
+    static_for<0, NQ / QR>([&](auto rc) {
+        constexpr int q0 = decltype(rc)::value * QR;
+        floatx4 t[QR];
+        static_for<0, QR>([&](auto qc) { t[decltype(qc)::value] = lds_ld4<(q0 + decltype(qc)::value) * 16>(addr); });
+        wait_lgkm<0>();
+        static_for<0, QR>([&](auto qc) {                        // (uses stay behind the wait: the compiler does not see an asm read's latency)
+            constexpr int q = decltype(qc)::value;
+            pin(t[q]);
+            static_for<0, 4>([&](auto ec) {
+                constexpr int e = 4 * (q0 + q) + decltype(ec)::value;          // flat accumulator register
+                acc[e / RPB][e % RPB] = t[q][decltype(ec)::value];
+            });
         });
     });
 }
@@ -270,7 +274,9 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     };
 
     // ---- trunk: nerf.py:127-130 ------------------------------------------------------------------
-    static_for<0, C::NL>([&](auto lc) {
+    // (always_inline: left to the inliner's cost model, the 512-wide instantiation kept the skip layer's body as a FUNCTION, and everything the
+    // lambda captures by reference -- accumulators, activations, stream -- then lived in scratch: 58 000 scratch instructions)
+    static_for<0, C::NL>([&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         constexpr bool PUB = publishes(l);
         if constexpr (l == 0 || !publishes(l > 0 ? l - 1 : 0)) st.next_chunk();

@@ -75,7 +75,7 @@ __device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const flo
     unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + lane);
     frag_load<G0 % GPC, 0, NOB_FULL>(a0, addr);
     if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * 4, NOB_FULL>(a1, addr);
-    static_for<0, T>([&](auto tc) {
+    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, u = t + 2, gl = t / NBATCH;
         constexpr bool early = u < T && S::chunk_start(u), group_start = BSTASH && t % NBATCH == 0;
         if constexpr (group_start) bq = lds_ld4<gl * BST_STRIDE>(bst);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     floatx4 acc[NOBH];
     const int ob0 = half * NOBH;
     // ---- trunk -------------------------------------------------------------------------------------
-    static_for<0, C::NL>([&](auto lc) {
+    static_for<0, C::NL>([&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         constexpr bool ENC = l == 0 || ((C::SKIP >> l) & 1);
         const float *bias = aux + a.bias_off[l] + part * H + half * HH;
@@ -410,19 +410,30 @@ static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_m
     return check_launch("k_mlp_fwd_pair");
 }
 
-// inference launch of a 512-wide default architecture through the pair kernel; MNR_E_UNSUPPORTED for anything else
+// The tape-writing instantiations live in their own translation unit (mlp_fwd_pair_train.hip = this file with MNR_PAIR_TRAIN_TU: the four
+// instantiations together compiled for ten minutes).
+using PairFG = MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>;
+using PairBG = MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>;
+#ifdef MNR_PAIR_TRAIN_TU
+int launch_fwd_pair_train(bool bg, const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                          float *tape, long tape_rows, long tape_row0) {
+    return bg ? launch_fwd_pair<PairBG, true>(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0)
+              : launch_fwd_pair<PairFG, true>(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0);
+}
+#else
+int launch_fwd_pair_train(bool bg, const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
+                          float *tape, long tape_rows, long tape_row0);
+// launch of a 512-wide default architecture through the pair kernel; MNR_E_UNSUPPORTED for anything else
 int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                               const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0) {
     const bool arch = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 512 && d->layers == 8 &&
                       d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
-    using FG = MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>;
-    using BG = MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>;
     if (tape && (cells || io->sigma_only)) return set_err(MNR_E_INVALID, "the tape-writing pair kernel takes plain launches");
-    if (arch && d->xyz_dim == 3) return tape ? launch_fwd_pair<FG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0)
-                                             : launch_fwd_pair<FG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
-    if (arch && d->xyz_dim == 4) return tape ? launch_fwd_pair<BG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0)
-                                             : launch_fwd_pair<BG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
+    if (arch && (d->xyz_dim == 3 || d->xyz_dim == 4) && tape) return launch_fwd_pair_train(d->xyz_dim == 4, m, packed_dev, d, io, s, tape, tape_rows, tape_row0);
+    if (arch && d->xyz_dim == 3) return launch_fwd_pair<PairFG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
+    if (arch && d->xyz_dim == 4) return launch_fwd_pair<PairBG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
     return set_err(MNR_E_UNSUPPORTED, "the pair kernel covers the 512-wide default fg / bg architectures");
 }
+#endif
 
 }  // namespace mnr

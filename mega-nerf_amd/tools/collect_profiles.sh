@@ -2,9 +2,9 @@
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box from the repo root):
 #   kernel trace + stats of the default training bench and of the eval bench, then separate --pmc passes
 #   (HBM counters in their own passes as MI355X_MICROARCH.md prescribes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).
-# Output: $OUT (default gpurun_out/r04_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r04
+# Output: $OUT (default gpurun_out/r05_prof); summarise with  python mega-nerf_amd/tools/summarize_pmc.py $OUT profiles r05
 set -u
-OUT=${1:-$PWD/gpurun_out/r04_prof}
+OUT=${1:-$PWD/gpurun_out/r05_prof}
 B=$PWD/bench.py
 mkdir -p "$OUT"
 export TMPDIR=/tmp
