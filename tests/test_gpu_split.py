@@ -116,16 +116,18 @@ def test_split_precision_benchmark_shape_all_rays_after_training_steps(split_pre
     _benchmark_shape_check(train_steps=30, max_offenders=100, same_batch=True)
 
 
-def test_split_precision_routed_container(split_precision):
-    """An 8-cell merged container (MegaNeRF router, boundary margin 1.15) with every cell's rows on the split-precision kernel in ONE
-    launch per pass (mnr_mlp_forward_cells_h2): the reference's outputs at the fp32 path's tolerances."""
+@pytest.mark.parametrize('fixture', ['render_container8_eval', 'render_container_2d_eval'])
+def test_split_precision_routed_container(split_precision, fixture):
+    """A merged container (MegaNeRF router, boundary margin 1.15; 8 cells clustered in 3-D, and 4 cells clustered in 2-D with the background
+    routed per sample on its true far-away point) with every cell's rows on the split-precision kernel in ONE launch per pass
+    (mnr_mlp_forward_cells_h2): the reference's outputs at the fp32 path's tolerances."""
     from test_gpu_parity_extra import test_new_render_goldens
     from mega_nerf.models.mega_nerf import MegaNeRF
-    test_new_render_goldens('render_container8_eval')
-    hp, nerf, bg_nerf = native_models('render_container8_eval')
+    test_new_render_goldens(fixture)
+    hp, nerf, bg_nerf = native_models(fixture)
     assert isinstance(nerf, MegaNeRF)
     from mega_nerf.rendering import render_rays
-    g = load('render_container8_eval')
+    g = load(fixture)
     s = common.SCENE
     with torch.no_grad():
         render_rays(nerf, bg_nerf, T(g['rays']), T(g['idx'].astype(f32)), Namespace(**vars(hp)), T(s['sphere_center']), T(s['sphere_radius']),
