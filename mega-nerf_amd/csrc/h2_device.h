@@ -174,8 +174,8 @@ struct H2NoHook {
 // `hook(chunk index inside the layer)` runs right behind every chunk boundary (behind the DMA issue of the following chunk): the
 // place for the training kernels' tape stores (a boundary drains vmcnt: stores issued just BEFORE one cost a write round trip)
 // G = output blocks whose (hi, lo) fragments are read ahead of their MFMAs (32 registers at 4; the training forward takes 2)
-template <int NOB, int NK, int K0, int G, bool ASM_READS, int NSRC, class Hook = H2NoHook>
-__device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
+template <int NOB, int NK, int K0, int G, int NSRC, class Hook = H2NoHook>
+__device__ __forceinline__ void h2_segment_visible(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
     constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64);
     static_for<0, NK>([&](auto kc) {
         constexpr int kl = decltype(kc)::value, k = K0 + kl;
@@ -186,12 +186,7 @@ __device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&
         uint4v bh, bl;
         h2_split8(x, bh, bl, st.one);
         static_assert(NOB % G == 0, "output blocks per fragment group");
-#if defined(H2_EXPERIMENT_HALF_LDS)
-        constexpr bool asm_reads = false;
-#else
-        constexpr bool asm_reads = ASM_READS;
-#endif
-        if constexpr (!asm_reads) {
+        {
         const uint4v *p = st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane;
 #pragma unroll
         for (int o0 = 0; o0 < NOB; o0 += G) {
@@ -209,47 +204,84 @@ __device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&
 #pragma unroll
             for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
         }
-        } else {
-        // (hi, lo) fragments of G output blocks per batch, read with inline asm and hand-counted lgkmcnt, two batches in flight: a
-        // compiler-visible read of the ring gets `s_waitcnt vmcnt(0)` in front of it -- right behind the DMA burst of the NEXT chunk, so
-        // every wavefront of the (single, eight-wavefront) workgroup waited for the prefetch it had just issued (mlp_device.h; round 4)
-        constexpr int NBATCH = NOB / G;
-        const unsigned addr = lds_addr(st.lds + st.cur * H2_CHUNK_U4 + (k % SPC) * NOB * 2 * 64 + lane);
-        uint4v ahA[G], alA[G], ahB[G], alB[G];
-        auto load = [&](uint4v (&ah)[G], uint4v (&al)[G], auto batch) {
-            constexpr int o0 = decltype(batch)::value * G;
-            static_for<0, G>([&](auto oc) {
-                constexpr int o = o0 + decltype(oc)::value;
-                ah[decltype(oc)::value] = lds_ld4u<o * 2048>(addr);
-                al[decltype(oc)::value] = lds_ld4u<o * 2048 + 1024>(addr);
-            });
-        };
-        auto mfmas = [&](uint4v (&ah)[G], uint4v (&al)[G], auto batch) {
-            constexpr int o0 = decltype(batch)::value * G;
-#pragma unroll
-            for (int o = 0; o < G; ++o) { pin_u(ah[o]); pin_u(al[o]); }
-#pragma unroll
-            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bh, acc[o0 + o]);
-#pragma unroll
-            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(al[o], bh, acc[o0 + o]);
-#pragma unroll
-            for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ah[o], bl, acc[o0 + o]);
-        };
-        load(ahA, alA, std::integral_constant<int, 0>{});
-        if constexpr (NBATCH > 1) load(ahB, alB, std::integral_constant<int, 1>{});
-        static_for<0, NBATCH>([&](auto bc) {
-            constexpr int bi = decltype(bc)::value;
-            if constexpr (bi + 1 < NBATCH) wait_lgkm<2 * G>(); else wait_lgkm<0>();
-            if constexpr (bi % 2 == 0) {
-                mfmas(ahA, alA, bc);
-                if constexpr (bi + 2 < NBATCH) load(ahA, alA, std::integral_constant<int, bi + 2>{});
-            } else {
-                mfmas(ahB, alB, bc);
-                if constexpr (bi + 2 < NBATCH) load(ahB, alB, std::integral_constant<int, bi + 2>{});
-            }
-        });
         }
     });
+}
+
+// ---- the asm-read form: ONE software pipeline over the segment (round 5; the fp32 kernels' scheme, mlp_device.h run_segment) ------------
+// batch t = (K-step t / NBATCH, output blocks (t % NBATCH) * G ..): 2G fragment reads (hi, lo), 3G MFMAs.  Three fragment buffers: batch t
+// computes, t + 1 is in flight, t + 2 is requested behind the first MFMA group of t.  The accumulator pins behind every group keep the
+// MFMAs above the reads that follow them in the source (left to hipcc the MFMAs sink below the asm reads, every batch gets fresh
+// registers, and the forward spilled 125-196 VGPRs -- which is why rounds 3-4 kept its reads compiler-visible, with a vmcnt(0) in front of
+// each chunk's first read).  A chunk boundary does not restart the pipeline: when batch t + 2 opens a new chunk the barrier is taken at
+// the START of batch t, once the old chunk's reads have landed; the wavefront waits there with two batches in hand.
+template <int GS, int O0, int NOB, int G>
+__device__ __forceinline__ void h2_frag_load(uint4v (&ah)[G], uint4v (&al)[G], unsigned addr) {
+    static_for<0, G>([&](auto oc) {
+        constexpr int o = O0 + decltype(oc)::value;
+        ah[decltype(oc)::value] = lds_ld4u<(GS * NOB + o) * 2048>(addr);
+        al[decltype(oc)::value] = lds_ld4u<(GS * NOB + o) * 2048 + 1024>(addr);
+    });
+}
+template <int O0, int G, int NOB>
+__device__ __forceinline__ void h2_pin_acc(floatx4 (&acc)[NOB]) {
+#pragma unroll
+    for (int o = 0; o < G; ++o) pin(acc[O0 + o]);
+}
+template <int NOB, int NK, int K0, int G, int NSRC, class Hook>
+__device__ __forceinline__ void h2_segment_pipe(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook) {
+    constexpr int SPC = H2_CHUNK_U4 / (NOB * 2 * 64), NBATCH = NOB / G, T = NK * NBATCH;
+    static_assert(NOB % G == 0 && NBATCH >= 2, "at least two batches per K-step");
+    static_assert(SPC * NOB * 2048 <= 65536 + 2048, "fragment offsets must fit the ds_read immediate");
+    auto chunk_start = [](int t) constexpr { return t % NBATCH == 0 && (K0 + t / NBATCH) % SPC == 0; };
+    uint4v ah[3][G], al[3][G];
+    uint4v bh = {0u, 0u, 0u, 0u}, bl = {0u, 0u, 0u, 0u};
+    if constexpr (chunk_start(0)) { st.next_chunk(); hook(std::integral_constant<int, K0 / SPC>{}); }
+    unsigned addr = lds_addr(st.lds + st.cur * H2_CHUNK_U4 + lane);
+    h2_frag_load<K0 % SPC, 0, NOB, G>(ah[0], al[0], addr);
+    if constexpr (T > 1) h2_frag_load<(K0 + 1 / NBATCH) % SPC, (1 % NBATCH) * G, NOB, G>(ah[1], al[1], addr);
+    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, u = t + 2, kl = t / NBATCH, o0 = (t % NBATCH) * G;
+        constexpr bool early = u < T && chunk_start(u);
+        if constexpr (t % NBATCH == 0) {                       // this K-step's B operand: 8 activations -> (hi, lo) f16 octets
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (8 * kl + j < NSRC) ? src[(8 * kl + j < NSRC) ? 8 * kl + j : 0] : 0.f;
+            h2_split8(x, bh, bl, st.one);
+        }
+        if constexpr (early) {
+            wait_lgkm<0>();
+            st.next_chunk();
+            hook(std::integral_constant<int, (K0 + u / NBATCH) / SPC>{});
+            addr = lds_addr(st.lds + st.cur * H2_CHUNK_U4 + lane);
+        } else if constexpr (t + 1 < T) {
+            wait_lgkm<2 * G>();
+        } else {
+            wait_lgkm<0>();
+        }
+        uint4v (&ch)[G] = ah[t % 3], (&cl)[G] = al[t % 3];
+#pragma unroll
+        for (int o = 0; o < G; ++o) { pin_u(ch[o]); pin_u(cl[o]); }
+#pragma unroll
+        for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ch[o], bh, acc[o0 + o]);
+        h2_pin_acc<o0, G>(acc);
+        if constexpr (u < T) h2_frag_load<(K0 + u / NBATCH) % SPC, (u % NBATCH) * G, NOB, G>(ah[u % 3], al[u % 3], addr);
+#pragma unroll
+        for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(cl[o], bh, acc[o0 + o]);
+#pragma unroll
+        for (int o = 0; o < G; ++o) acc[o0 + o] = h2_mfma(ch[o], bl, acc[o0 + o]);
+        h2_pin_acc<o0, G>(acc);
+    });
+}
+
+template <int NOB, int NK, int K0, int G, bool ASM_READS, int NSRC, class Hook = H2NoHook>
+__device__ __forceinline__ void h2_segment_g(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {
+#if defined(H2_EXPERIMENT_HALF_LDS)
+    h2_segment_visible<NOB, NK, K0, G>(acc, src, st, lane, hook);
+#else
+    if constexpr (ASM_READS) h2_segment_pipe<NOB, NK, K0, G>(acc, src, st, lane, hook);
+    else h2_segment_visible<NOB, NK, K0, G>(acc, src, st, lane, hook);
+#endif
 }
 template <int NOB, int NK, int K0, int NSRC, class Hook = H2NoHook>
 __device__ __forceinline__ void h2_segment(floatx4 (&acc)[NOB], const float (&src)[NSRC], H2Stream &st, int lane, Hook hook = Hook()) {

@@ -134,12 +134,12 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
         constexpr int l = decltype(lc)::value;
         init_acc<NOB, RPB>(acc, aux + a.bias_off[l] + part * H);
         if constexpr (l == 0) {
-            h2_segment_g<NOB, KE, 0, FG, false>(acc, ex, st, lane);
+            h2_segment_g<NOB, KE, 0, FG, true>(acc, ex, st, lane);
         } else if constexpr ((C::SKIP >> l) & 1) {
-            h2_segment_g<NOB, KE, 0, FG, false>(acc, ex, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
-            h2_segment_g<NOB, KH, KE, FG, false>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
+            h2_segment_g<NOB, KE, 0, FG, true>(acc, ex, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
+            h2_segment_g<NOB, KH, KE, FG, true>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
         } else {
-            h2_segment_g<NOB, KH, 0, FG, false>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
+            h2_segment_g<NOB, KH, 0, FG, true>(acc, h, st, lane, store_prev(std::integral_constant<int, l - 1>{}));
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
     });
@@ -162,12 +162,12 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
 
     // xyz_encoding_final (no activation), then dir_a_encoding over [final | dir embedding | appearance]
     init_acc<NOB, RPB>(acc, aux + a.bias_off[C::NL] + part * H);
-    h2_segment_g<NOB, KH, 0, FG, false>(acc, h, st, lane, store_prev(std::integral_constant<int, C::NL - 1>{}));      // (the last trunk layer's plane)
+    h2_segment_g<NOB, KH, 0, FG, true>(acc, h, st, lane, store_prev(std::integral_constant<int, C::NL - 1>{}));      // (the last trunk layer's plane)
     acc_to_regs<NOB, RPB, false>(h, acc);
     floatx4 acc2[NOB2];
     init_acc<NOB2, RPB>(acc2, aux + a.bias_off[C::NL + 1] + part * H2);
     // ... and xyz_encoding_final's plane during dir_a's first segment (two chunks: half the plane behind each boundary)
-    h2_segment_g<NOB2, KH, 0, FG, false>(acc2, h, st, lane, [&](auto cc) {
+    h2_segment_g<NOB2, KH, 0, FG, true>(acc2, h, st, lane, [&](auto cc) {
         if constexpr (TRAIN && decltype(cc)::value == 0) {
             if (valid) tape_store_regs_part<P, 0, 16>(a.tape + a.tl.fin_off * a.tape_rows, trow_off, h);
         }
@@ -181,7 +181,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
         if constexpr (TRAIN) {
             if (valid) tape_store_emb<3, C::LD, P>(a.tape + a.tl.embd_off * a.tape_rows, tape_row<16>(trow0), a.tl.embd_w, ed, part);
         }
-        h2_segment_g<NOB2, KD, KH, FG, false>(acc2, ed, st, lane);
+        h2_segment_g<NOB2, KD, KH, FG, true>(acc2, ed, st, lane);
         long idx = io.idx_is_float ? (long)reinterpret_cast<const float *>(io.idx)[ray * io.idx_stride]
                                    : (long)reinterpret_cast<const int32_t *>(io.idx)[ray * io.idx_stride];
         idx = idx < 0 ? 0 : (idx >= a.app_count ? a.app_count - 1 : idx);
@@ -196,7 +196,7 @@ __device__ __forceinline__ void mlp_fwd_h2_body(const H2Args &a, long blk, int c
                 for (int i = 0; i < C::APP / P; ++i) r[i] = ap[i];
             }
         }
-        h2_segment_g<NOB2, (C::AP + 7) / 8, KH + KD, FG, false>(acc2, ap, st, lane);
+        h2_segment_g<NOB2, (C::AP + 7) / 8, KH + KD, FG, true>(acc2, ap, st, lane);
     }
     float dreg[H2];
     acc_to_regs<NOB2, RPB, true>(dreg, acc2);

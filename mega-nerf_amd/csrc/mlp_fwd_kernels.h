@@ -68,6 +68,9 @@ __device__ __forceinline__ void tape_store_regs_part(const float *plane, unsigne
 // ReLU sign bits of a C-layout register array, packed per lane (TapeLayout mask planes)
 template <int P, int NH>
 __device__ __forceinline__ void tape_store_mask(float *plane, long row, int width, const float (&h)[NH], int part) {
+#ifdef MNR_EXPERIMENT_NO_MASK          // timing experiment only (results invalid): what do the sign-bit planes cost?
+    return;
+#endif
     constexpr int NW = (NH + 31) / 32;
     uint32_t *r = reinterpret_cast<uint32_t *>(plane) + row * width + part * NW;
     uint32_t w[NW];

@@ -103,7 +103,7 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
 # them may touch scratch.  A spilled VGPR is a scratch_store / scratch_load pair inside the instruction stream (each reload a vmcnt
 # dependency) plus HBM write-back traffic; round 4 shipped 51-182 of them in kernels the design notes called spill-free.  The check
 # reads the code objects' own metadata (tools/kernel_resources.py), so it runs on the CPU and spills cannot come back silently.
-NO_SCRATCH_KERNELS = ('k_mlp_fwd_multi<', 'k_mlp_bwd_multi<', 'k_mlp_fwd<', 'k_wgrad2<0, false>', 'k_wgrad2<1, false>',
+NO_SCRATCH_KERNELS = ('k_mlp_fwd_multi<', 'k_mlp_bwd_multi<', 'k_mlp_fwd<', 'k_wgrad2<', 'k_mlp_fwd_h2<', 'k_mlp_bwd_h2<',
                       'k_wgrad2_reduce', 'k_head_grads', 'k_sh_head_bwd', 'k_step_', 'k_render_tail', 'k_route', 'k_tgemm')
 
 
@@ -117,7 +117,10 @@ def test_hot_path_kernels_have_no_scratch():
     ks = kr.kernel_resources(str(N.LIB_PATH))
     assert len(ks) > 100
     hot = [k for k in ks if any(('mnr::' + p) in k['name'] for p in NO_SCRATCH_KERNELS)]
-    assert len(hot) >= 36, len(hot)
+    assert len(hot) >= 40, len(hot)
+    # the inference instantiations of the 512-wide pair kernel (mnr_render_fwd's Building shape, routed containers) as well; its tape-writing
+    # instantiation (forward of the W = 512 training path) still spills 50 VGPRs in its last exchange and is not on a one-call path
+    hot += [k for k in ks if 'mnr::k_mlp_fwd_pair<' in k['name'] and 'false>' in k['name']]
     # (a spill count with a zero-byte private segment = registers parked in AGPRs by the one-wavefront-per-SIMD 512-wide kernel, which
     # owns all 512 registers: v_accvgpr moves, no memory traffic -- allowed, two of them at the time of writing)
     bad = [(k['name'][:120], k['vgpr_spill_count'], k['private_segment_fixed_size']) for k in hot
