@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void k_cluster_ratios(float *__restrict__ rati
             float sqmin = INFINITY;
 #pragma unroll
             for (int j = 0; j < MAXC; ++j) {
+                // (eight centroid reads in flight at most: hipcc hoisted all MAXC float4 reads in front of the loop -- 256 registers at 64
+                // cells, 96 VGPRs spilled out of a 512-register kernel)
+                if (j % 8 == 0 && j > 0) asm volatile("" ::: "memory");
                 const float4 c = cs[j];
                 float acc = dim0 == 0 ? fmaf(a1, c.y, a0 * c.x) : a1 * c.y;
                 acc = fmaf(a2, c.z, acc);

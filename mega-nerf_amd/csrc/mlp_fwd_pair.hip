@@ -49,6 +49,13 @@ struct WStream8 {      // WStream (mlp_device.h) for a 512-thread workgroup
 // The A fragments are read with inline-asm ds_read_b128 and hand-counted waits (lds_asm.h), two batches of four blocks in flight:
 // left to the compiler, all 16 reads of a group are hoisted in front of its MFMAs (64 registers on top of 128 inputs + 64 accumulators:
 // 31-78 spilled VGPRs), and scheduling fences / group barriers either spilled more or did not finish compiling.
+// the lane id, re-read where it is needed (v_mbcnt needs no input register) instead of living in a VGPR for the whole kernel
+__device__ __forceinline__ int fresh_lane() {
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return (int)l;
+}
+
 struct NoHook { template <class G> __device__ __forceinline__ void operator()(G) const {} };
 
 // BSTASH: the B operands (a positional encoding) are not a register array but sit in LDS, one float4 per K group and lane at
@@ -72,7 +79,7 @@ __device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const flo
     using S = SegSched<NBATCH, GPC, G0, T>;
     floatx4 a0[4], a1[4], bq = floatx4(0.f);
     if constexpr (S::chunk_start(0)) { st.next_chunk(); hook(std::integral_constant<int, G0>{}); }      // (hook: right behind a chunk barrier)
-    unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + lane);
+    unsigned addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + fresh_lane());
     frag_load<G0 % GPC, 0, NOB_FULL>(a0, addr);
     if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * 4, NOB_FULL>(a1, addr);
     static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
@@ -83,7 +90,7 @@ __device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const flo
             wait_lgkm<0>();
             st.next_chunk();
             hook(std::integral_constant<int, G0 + u / NBATCH>{});
-            addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + lane);
+            addr = lds_addr(st.lds + st.cur * CHUNK_F4 + ob0 * 64 + fresh_lane());
         } else if constexpr (group_start || t + 1 >= T) {
             wait_lgkm<0>();
         } else {
@@ -116,11 +123,12 @@ __device__ __forceinline__ void stash_encoding(unsigned bst, const float (&e)[NE
 
 // The halves of a pair swap their NH output registers (lane for lane) through LDS in two rounds of NH / 2 registers:
 // h[own0 .. own0 + NH) = own, h[oth0 .. oth0 + NH) = the partner's.
-template <int NH, int NHF>
-__device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[NH], float4 *xb, int wave, int lane, bool upper) {
+template <int NH, bool UPPER, int NHF>
+__device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[NH], float4 *xb, int wave, int lane) {
     static_assert(NH % 8 == 0 && NH <= 64 && NHF >= 2 * NH, "exchange in two rounds of at most 32 registers");
     constexpr int Q = NH / 8;                 // float4 pieces per round
-    float4 *mine = xb + wave * 512 + lane, *theirs = xb + (wave ^ 4) * 512 + lane;
+    const int ln = fresh_lane();
+    float4 *mine = xb + wave * 512 + ln, *theirs = xb + (wave ^ 4) * 512 + ln;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -133,13 +141,16 @@ __device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[
         for (int q = 0; q < Q; ++q) {
             const int i = 4 * (round * Q + q);
             const float4 v = theirs[q * 64];
-            // `upper` is wave-uniform but not a compile-time constant: every h register is written once, by a VALUE select between
-            // the own and the partner's number (an `if` around the two stores is turned into one store to a selected ADDRESS, which
-            // sends the whole array to scratch)
-            h[i] = upper ? v.x : o[i];          h[NH + i] = upper ? o[i] : v.x;
-            h[i + 1] = upper ? v.y : o[i + 1];  h[NH + i + 1] = upper ? o[i + 1] : v.y;
-            h[i + 2] = upper ? v.z : o[i + 2];  h[NH + i + 2] = upper ? o[i + 2] : v.z;
-            h[i + 3] = upper ? v.w : o[i + 3];  h[NH + i + 3] = upper ? o[i + 3] : v.w;
+            // which half a wavefront is, is a TEMPLATE parameter of the kernel body (k_mlp_fwd_pair branches once, at its top): own registers
+            // move by renaming, the partner's land where they belong -- no selects.  (Rounds 4-5 selected by value on a run-time `upper`:
+            // 128 v_cndmask per layer and, in the tape-writing instantiation, 50 registers of scratch in the last exchange.)
+            if constexpr (UPPER) {
+                h[i] = v.x; h[i + 1] = v.y; h[i + 2] = v.z; h[i + 3] = v.w;
+                h[NH + i] = o[i]; h[NH + i + 1] = o[i + 1]; h[NH + i + 2] = o[i + 2]; h[NH + i + 3] = o[i + 3];
+            } else {
+                h[i] = o[i]; h[i + 1] = o[i + 1]; h[i + 2] = o[i + 2]; h[i + 3] = o[i + 3];
+                h[NH + i] = v.x; h[NH + i + 1] = v.y; h[NH + i + 2] = v.z; h[NH + i + 3] = v.w;
+            }
         }
         __syncthreads();
     }
@@ -150,18 +161,18 @@ __device__ __forceinline__ void pair_exchange(float (&h)[NHF], const float (&o)[
 // 256 (128) columns it computed.  The stores of a layer's output are issued from the NEXT layer's input registers, a quarter behind
 // each of that layer's first four chunk barriers: a barrier drains vmcnt, so a store issued in front of one (and the exchange is four
 // barriers) would stall the wavefront for a write round trip.
-template <int Q0, int NQ, int NH2>
-__device__ __forceinline__ void pair_store_own(const float *plane, unsigned row_byte_off, const float (&h)[NH2], bool upper) {
+template <int Q0, int NQ, bool UPPER, int NH2>
+__device__ __forceinline__ void pair_store_own(const float *plane, unsigned row_byte_off, const float (&h)[NH2]) {
     constexpr int NH = NH2 / 2;
     static_for<Q0, Q0 + NQ>([&](auto qc) {
         constexpr int q = decltype(qc)::value, i = 4 * q;
-        gstore4<64 * q>(plane, row_byte_off, make_float4(upper ? h[NH + i] : h[i], upper ? h[NH + i + 1] : h[i + 1],
-                                                         upper ? h[NH + i + 2] : h[i + 2], upper ? h[NH + i + 3] : h[i + 3]));
+        constexpr int j = UPPER ? NH + i : i;
+        gstore4<64 * q>(plane, row_byte_off, make_float4(h[j], h[j + 1], h[j + 2], h[j + 3]));
     });
 }
 
-template <class C, bool TRAIN>
-__global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) {
+template <class C, bool TRAIN, int HALF>
+__device__ __forceinline__ void pair_body(const MlpFwdArgs &a) {
     static_assert(C::TILE == 16 && C::W == 512 && C::HAS_FINAL && C::RGB == 3, "pair kernel: the 512-wide default architectures");
     constexpr int P = C::P, H = C::H, NOB = C::NOB, NOBH = NOB / 2, HH = H / 2;          // H = 128 input registers, HH = 64 own outputs
     constexpr int NOB2 = C::NOB2, NOB2H = NOB2 / 2, H2 = C::H2, H2H = H2 / 2;             // dir_a: 256 outputs -> 64 registers, 32 own
@@ -204,7 +215,8 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     n_rows = uniform_long(n_rows);
     blk = uniform_long(blk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave & 3, half = wave >> 2;            // waves w and w + 4 share their 16 rows
+    const int pair = wave & 3;                              // waves w and w + 4 share their 16 rows
+    constexpr int half = HALF;                               // (0: wavefronts 0-3, the lower output blocks; 1: wavefronts 4-7)
     const int part = lane / 16;
     auto row_of = [&]() -> long {                            // this lane's row inside the launch (the cell's list)
         unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         const unsigned trow = (unsigned)((blk * 4 + pair) * 16 + a.tape_row0) + (l & 15u);
         return (trow * width + 4u * (l >> 4)) * 4u + 2u * width * (unsigned)half;
     };
-    const bool upper = half != 0;
+    constexpr bool upper = HALF != 0;
 
     WStream8 st;
     st.g = reinterpret_cast<const float4 *>(uniform_ptr(reinterpret_cast<const char *>(chunks)));
@@ -239,8 +251,9 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     static_for<0, C::NL>([&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         constexpr bool ENC = l == 0 || ((C::SKIP >> l) & 1);
-        const float *bias = aux + a.bias_off[l] + part * H + half * HH;
-        const unsigned bst = lds_addr(xb + wave * 64 + lane);
+        const int ln = fresh_lane();
+        const float *bias = aux + a.bias_off[l] + (ln >> 4) * H + half * HH;
+        const unsigned bst = lds_addr(xb + wave * 64 + ln);
         if constexpr (ENC) {
             // The positional encoding is evaluated where it is consumed (layer 0 and the skip layer) -- BEFORE this layer's accumulators
             // exist (sincosf wants ~40 registers of its own) -- and parked in this wavefront's slice of the exchange buffer, which is idle
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
 #pragma unroll
             for (int d = 0; d < C::XYZ; ++d) x[d] = io.xyz[src * io.xyz_stride + d];
             float ex[C::EX];
-            embed<C::XYZ, C::LX, P>(ex, x, part);
+            embed<C::XYZ, C::LX, P>(ex, x, ln >> 4);
             stash_encoding(bst, ex);
             asm volatile("" : "+v"(bias));            // the bias loads below stay below (they would hold 64 registers across the sincosf code)
         }
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         auto hook = [&](auto gc) {
             if constexpr (TRAIN && l > 0) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, off_of(512u), h, upper); }
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4, upper>(a.tape + a.tl.act_off[l - 1] * a.tape_rows, off_of(512u), h); }
             }
         };
         hook(std::integral_constant<int, 0>{});
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         // layer 0 ends in its encoding segment: a wavefront that is done must not start writing exchange data over the slice another one
         // still fetches its last encoding group from (in the skip layer the hidden-state segment's chunk barriers lie in between)
         if constexpr (l == 0) __syncthreads();
-        pair_exchange<HH>(h, o, xb, wave, lane, upper);
+        pair_exchange<HH, upper>(h, o, xb, wave, lane);
     });
 
     // ---- sigma head (both halves hold the full activation: computed twice, written once) ------------
@@ -311,14 +324,14 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
         auto hook = [&](auto gc) {
             if constexpr (TRAIN) {
                 constexpr int g = decltype(gc)::value;
-                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, off_of(512u), h, upper); }
+                if constexpr (g < 4) { if (valid) pair_store_own<4 * g, 4, upper>(a.tape + a.tl.act_off[C::NL - 1] * a.tape_rows, off_of(512u), h); }
             }
         };
         hook(std::integral_constant<int, 0>{});
         run_segment_half<NOBH, NOB, H / 4, C::GPC, 0>(acc, h, st, lane, ob0, hook);
         float o[HH];
         acc_to_regs<NOBH, 4, false>(o, acc);
-        pair_exchange<HH>(h, o, xb, wave, lane, upper);
+        pair_exchange<HH, upper>(h, o, xb, wave, lane);
     }
 
     // ---- dir_a_encoding: 256 outputs, 128 per half --------------------------------------------------------
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     auto hook_fin = [&](auto gc) {              // (two groups per chunk here: a barrier every other group)
         if constexpr (TRAIN) {
             constexpr int g = decltype(gc)::value;
-            if constexpr (g % 2 == 0 && g < 8) { if (valid) pair_store_own<2 * g, 4>(a.tape + a.tl.fin_off * a.tape_rows, off_of(512u), h, upper); }
+            if constexpr (g % 2 == 0 && g < 8) { if (valid) pair_store_own<2 * g, 4, upper>(a.tape + a.tl.fin_off * a.tape_rows, off_of(512u), h); }
         }
     };
     hook_fin(std::integral_constant<int, 0>{});
@@ -388,6 +401,14 @@ __global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) 
     o[1] = sigmoidf_(rgbp[1] + rs[1] + wr[3 * P * H2 + 1]);
     o[2] = sigmoidf_(rgbp[2] + rs[2] + wr[3 * P * H2 + 2]);
     o[3] = sigma;
+}
+
+// the two halves of every pair run two specialisations of the body (the branch is uniform per wavefront; both sides execute the same
+// barriers in the same order, which is all s_barrier counts)
+template <class C, bool TRAIN>
+__global__ __launch_bounds__(PAIR_THREADS, 1) void k_mlp_fwd_pair(MlpFwdArgs a) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) pair_body<C, TRAIN, 1>(a);
+    else pair_body<C, TRAIN, 0>(a);
 }
 
 template <class C, bool TRAIN>
