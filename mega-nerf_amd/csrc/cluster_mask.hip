@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void k_cluster_ratios(float *__restrict__ rati
             for (int j = 0; j < MAXC; ++j) {
                 // dist/den < best  needs  sq < (best den)^2 up to rounding; 1e-6 relative slack keeps the filter conservative
                 const float lim = best[j] * den;
-                if (sq[j] <= lim * lim * 1.000001f) best[j] = fminf(best[j], sqrtf(sq[j]) / den);
+                // (j < n_c: a padded slot has sq = best = inf, and inf <= inf sent it through the sqrt and the divide for every sample -- 36 cells
+                // in the 64-slot instantiation ran slower than 64)
+                if (j < n_c && sq[j] <= lim * lim * 1.000001f) best[j] = fminf(best[j], sqrtf(sq[j]) / den);
             }
         }
     }
