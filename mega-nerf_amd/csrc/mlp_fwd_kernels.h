@@ -259,7 +259,6 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
 
     float h[H];
     AccT acc[NOB];
-    int li = 0;   // MFMA layer counter (compile-time after unrolling)
 
     // bias rows: two LDS slots behind the encoding stash, the next layer's row requested at the top of every layer (bias_dma above)
     float4 *bias_slot = lds_ring + 2 * CHUNK_F4 + (C::ED * 64 * NW) / 4;
@@ -303,7 +302,6 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         }
         acc_to_regs<NOB, RPB, true>(h, acc);
     });
-    li = C::NL;
 
     // ---- sigma head: nerf.py:132-136 -------------------------------------------------------------
     float sigma;
@@ -340,7 +338,6 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
         }
         run_segment<TILE, NOB, H / 4, C::GPC, 0, PUB_PLAIN>(acc, h, st, lane);
         acc_to_regs<NOB, RPB, false>(h, acc);                    // xyz_encoding_final: no activation
-        ++li;
 
         constexpr int NOB2 = C::NOB2, H2 = C::H2;
         AccT acc2[NOB2];

@@ -431,30 +431,41 @@ static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_m
     return check_launch("k_mlp_fwd_pair");
 }
 
-// The tape-writing instantiations live in their own translation unit (mlp_fwd_pair_train.hip = this file with MNR_PAIR_TRAIN_TU: the four
-// instantiations together compiled for ten minutes).
+// ONE instantiation per translation unit (each is two specialised bodies and compiles for ~6 minutes): this file is MNR_PAIR_TU 0 (foreground,
+// inference, + the dispatcher); mlp_fwd_pair_bg.hip / mlp_fwd_pair_train.hip / mlp_fwd_pair_train_bg.hip include it with MNR_PAIR_TU 1 / 2 / 3.
+#ifndef MNR_PAIR_TU
+#define MNR_PAIR_TU 0
+#endif
 using PairFG = MlpCfg<3, 12, 4, 48, 512, 8, 16, 3, 16>;
 using PairBG = MlpCfg<4, 12, 4, 48, 512, 8, 16, 3, 16>;
-#ifdef MNR_PAIR_TRAIN_TU
-int launch_fwd_pair_train(bool bg, const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
-                          float *tape, long tape_rows, long tape_row0) {
-    return bg ? launch_fwd_pair<PairBG, true>(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0)
-              : launch_fwd_pair<PairFG, true>(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0);
-}
-#else
-int launch_fwd_pair_train(bool bg, const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
-                          float *tape, long tape_rows, long tape_row0);
+#define MNR_PAIR_LAUNCHER(name) \
+    int name(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s, const mnr_mlp_cell *cells, \
+             int n_cells, float *tape, long tape_rows, long tape_row0)
+MNR_PAIR_LAUNCHER(launch_pair_fg_eval);
+MNR_PAIR_LAUNCHER(launch_pair_bg_eval);
+MNR_PAIR_LAUNCHER(launch_pair_fg_train);
+MNR_PAIR_LAUNCHER(launch_pair_bg_train);
+#if MNR_PAIR_TU == 0
+MNR_PAIR_LAUNCHER(launch_pair_fg_eval) { return launch_fwd_pair<PairFG, false>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0); }
 // launch of a 512-wide default architecture through the pair kernel; MNR_E_UNSUPPORTED for anything else
 int mlp_forward_pair_dispatch(const ModelLayout &m, const void *packed_dev, const mnr_model_desc *d, const mnr_mlp_io *io, hipStream_t s,
                               const mnr_mlp_cell *cells, int n_cells, float *tape, long tape_rows, long tape_row0) {
     const bool arch = d->pos_xyz_dim == 12 && d->pos_dir_dim == 4 && d->appearance_dim == 48 && d->layer_dim == 512 && d->layers == 8 &&
                       d->skip_mask == 16 && d->rgb_dim == 3 && m.tile == 16;
     if (tape && (cells || io->sigma_only)) return set_err(MNR_E_INVALID, "the tape-writing pair kernel takes plain launches");
-    if (arch && (d->xyz_dim == 3 || d->xyz_dim == 4) && tape) return launch_fwd_pair_train(d->xyz_dim == 4, m, packed_dev, d, io, s, tape, tape_rows, tape_row0);
-    if (arch && d->xyz_dim == 3) return launch_fwd_pair<PairFG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
-    if (arch && d->xyz_dim == 4) return launch_fwd_pair<PairBG, false>(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
+    if (arch && d->xyz_dim == 3) return tape ? launch_pair_fg_train(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0)
+                                             : launch_pair_fg_eval(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
+    if (arch && d->xyz_dim == 4) return tape ? launch_pair_bg_train(m, packed_dev, d, io, s, nullptr, 0, tape, tape_rows, tape_row0)
+                                             : launch_pair_bg_eval(m, packed_dev, d, io, s, cells, n_cells, nullptr, 0, 0);
     return set_err(MNR_E_UNSUPPORTED, "the pair kernel covers the 512-wide default fg / bg architectures");
 }
+#elif MNR_PAIR_TU == 1
+MNR_PAIR_LAUNCHER(launch_pair_bg_eval) { return launch_fwd_pair<PairBG, false>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0); }
+#elif MNR_PAIR_TU == 2
+MNR_PAIR_LAUNCHER(launch_pair_fg_train) { return launch_fwd_pair<PairFG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0); }
+#else
+MNR_PAIR_LAUNCHER(launch_pair_bg_train) { return launch_fwd_pair<PairBG, true>(m, packed_dev, d, io, s, cells, n_cells, tape, tape_rows, tape_row0); }
 #endif
+#undef MNR_PAIR_LAUNCHER
 
 }  // namespace mnr
