@@ -244,10 +244,13 @@ constexpr bool seg_weaves() {
 // G0 = index of the segment's first group inside the layer (chunk boundaries are static).
 // PUB_END (woven form only): this is a layer's LAST segment and another layer follows -- its first chunk is published from here, two
 // batches before the end, exactly like a chunk boundary inside the segment; the caller then skips the next layer's next_chunk().
-template <int TILE, int NOB, int NG, int GPC, int G0, bool PUB_END = false, class AccT, int NB, class Stream>
+// NOBF / OB0 (feature-split workgroups, mlp_fwd_split_body): the layer has NOBF output blocks per group in the weight stream and this
+// wavefront computes the NOB blocks OB0 .. OB0 + NOB of them.
+template <int TILE, int NOB, int NG, int GPC, int G0, bool PUB_END = false, int NOBF = NOB, int OB0 = 0, class AccT, int NB, class Stream>
 __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], Stream &st, int lane) {
     static_assert(NB >= 4 * NG, "B register array too small");
     static_assert(!PUB_END || seg_weaves<TILE, NOB, NG, GPC, G0>(), "only the woven pipeline publishes ahead");
+    static_assert(TILE == 16 || (NOBF == NOB && OB0 == 0), "feature split: 16-row tiles only");
     if constexpr (TILE == 32) {
         static_for<0, NG>([&](auto gi) {
             constexpr int g = G0 + decltype(gi)::value;
@@ -269,7 +272,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
         // batch t are issued -- across the groups of a chunk (SegSched), so only a chunk barrier restarts the pipeline.
         constexpr int OBB = NOB < 4 ? NOB : 4, NBATCH = NOB / OBB, T = NG * NBATCH;
         static_assert(NOB % OBB == 0, "NOB must be a multiple of the block batch");
-        static_assert(GPC * NOB * 1024 <= 65536, "fragment offsets must fit the ds_read immediate");
+        static_assert(GPC * NOBF * 1024 <= 65536, "fragment offsets must fit the ds_read immediate");
         using S = SegSched<NBATCH, GPC, G0, T>;
         unsigned addr = 0;
         // (a segment whose SECOND batch opens a chunk -- 64-wide test models only -- takes the restartable form below)
@@ -286,8 +289,8 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
             floatx4 a[3][OBB];
             if constexpr (S::chunk_start(0)) st.next_chunk();
             addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
-            frag_load<G0 % GPC, 0, NOB>(a[0], addr);
-            if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, (1 % NBATCH) * OBB, NOB>(a[1], addr);
+            frag_load<G0 % GPC, OB0, NOBF>(a[0], addr);
+            if constexpr (T > 1) frag_load<(G0 + 1 / NBATCH) % GPC, OB0 + (1 % NBATCH) * OBB, NOBF>(a[1], addr);
             static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, u = t + 2;
                 constexpr int gl = t / NBATCH;
@@ -302,7 +305,7 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
                 } else {
                     wait_lgkm<0>();
                 }
-                frag_mfmas_weave<(t % NBATCH) * OBB, (G0 + u / NBATCH) % GPC, (u % NBATCH) * OBB, NOB, (u < T), early>(
+                frag_mfmas_weave<(t % NBATCH) * OBB, (G0 + u / NBATCH) % GPC, OB0 + (u % NBATCH) * OBB, NOBF, (u < T), early>(
                     acc, a[t % 3], a[u % 3], addr, st, b[4 * gl], b[4 * gl + 1], b[4 * gl + 2], b[4 * gl + 3]);
             });
         } else {
@@ -317,13 +320,13 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
                     addr = lds_addr(st.lds + st.cur * CHUNK_F4 + lane);
                     static_for<0, D>([&](auto dc) {
                         constexpr int u = t + decltype(dc)::value;
-                        if constexpr (u < t1) frag_load<(G0 + u / NBATCH) % GPC, (u % NBATCH) * OBB, NOB>(a[decltype(dc)::value], addr);
+                        if constexpr (u < t1) frag_load<(G0 + u / NBATCH) % GPC, OB0 + (u % NBATCH) * OBB, NOBF>(a[decltype(dc)::value], addr);
                     });
                 }
                 constexpr int newer = (t1 - 1 - t) < (D - 1) ? (t1 - 1 - t) : (D - 1);         // batches requested after this one, still in flight
                 wait_lgkm<OBB * newer>();
                 frag_mfmas<(t % NBATCH) * OBB>(acc, a[(t - t0) % D], b[4 * gl], b[4 * gl + 1], b[4 * gl + 2], b[4 * gl + 3]);
-                if constexpr (t + D < t1) frag_load<(G0 + (t + D) / NBATCH) % GPC, ((t + D) % NBATCH) * OBB, NOB>(a[(t - t0) % D], addr);
+                if constexpr (t + D < t1) frag_load<(G0 + (t + D) / NBATCH) % GPC, OB0 + ((t + D) % NBATCH) * OBB, NOBF>(a[(t - t0) % D], addr);
             });
         }
     }

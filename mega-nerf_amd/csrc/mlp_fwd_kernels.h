@@ -114,8 +114,11 @@ __device__ __forceinline__ void tape_store_emb(float *plane, long row, int width
 // spilled).  It is evaluated at the start of the kernel instead, next to the position encoding where nothing else is live, parked in
 // a lane-private LDS slot behind the weight ring (ED floats per lane; slot i of thread t at (i * NT + t) * 4: conflict-free) and read
 // back in front of its K segment.  asm on both sides: a compiler-visible access to the ring's array would get a vmcnt(0) (mlp_device.h).
+// the region behind the weight ring: mlp_fwd_body's direction-encoding stash, mlp_fwd_split_body's exchange slots (8 KB) -- float4 units
 template <class C, int NW>
-constexpr size_t fwd_lds_bytes() { return (size_t)2 * CHUNK_BYTES + (size_t)C::ED * 64 * NW * 4 + (size_t)2 * C::W * 4; }
+constexpr int fwd_stash_f4() { return (C::ED * 64 * NW * 4 >= 8192 ? C::ED * 64 * NW * 4 : 8192) / 16; }
+template <class C, int NW>
+constexpr size_t fwd_lds_bytes() { return (size_t)2 * CHUNK_BYTES + (size_t)fwd_stash_f4<C, NW>() * 16 + (size_t)2 * C::W * 4; }
 template <int I, int NT>
 __device__ __forceinline__ void stash_put(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(I * NT * 4) : "memory"); }
 template <int I, int NT>
@@ -261,7 +264,7 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     AccT acc[NOB];
 
     // bias rows: two LDS slots behind the encoding stash, the next layer's row requested at the top of every layer (bias_dma above)
-    float4 *bias_slot = lds_ring + 2 * CHUNK_F4 + (C::ED * 64 * NW) / 4;
+    float4 *bias_slot = lds_ring + 2 * CHUNK_F4 + fwd_stash_f4<C, NW>();
     auto bias_at = [&](int layer, int regs_per_part) {
         return lds_addr(bias_slot + (layer & 1) * (C::W / 4)) + (unsigned)(part * regs_per_part * 4);
     };
@@ -440,17 +443,47 @@ struct MlpFwdMulti {
     MlpFwdArgs seg[MLP_MAX_SEGS];
     int32_t wg0[MLP_MAX_SEGS + 1];
     int32_t is_b[MLP_MAX_SEGS];
+    // Feature-split tail (mlp_fwd_split.h): segment split_seg (a CB segment, the launch's last; -1: none) takes the 32-row body when its
+    // device-side row count needs at most split_max such workgroups.  The count's sources are repeated here as top-level scalars: read
+    // through seg[s], hipcc merges the alternatives into a select between ADDRESSES of argument fields and generic pointers, which pins
+    // the whole argument block into a private copy.
+    int32_t split_seg, split_max, split_rpu;
+    const int32_t *split_units;        // io.n_units_dev of that segment, or NULL
+    const MlpCellSeg *split_dcells;    // its cell table (one cell), or NULL
+    long split_fixed;                  // the row count when neither holds a device-side count
     int32_t nseg;
 };
+}  // namespace mnr
+#include "mlp_fwd_split.h"
+namespace mnr {
+// can configuration C's segments run as feature-split workgroups (mlp_fwd_split.h)?
+template <class C>
+constexpr bool split_capable() { return C::TILE == 16 && C::HAS_FINAL && C::NOB % 8 == 0 && C::NOB2 % 8 == 0 && C::W <= 256; }
+
 template <class CA, class CB, bool TRAIN, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_mlp_fwd_multi(MlpFwdMulti m) {
     const int blk = blockIdx.x;
     const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
-    if (m.is_b[s]) mlp_fwd_body<CB, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
-    else mlp_fwd_body<CA, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    if (m.is_b[s]) {
+        if constexpr (split_capable<CB>() && NW == 4) {
+            // The launch's LAST segment -- the background rows -- decides here, on its device-side row count, whether it is a partial quantum
+            // worth splitting: at most split_max (= one per CU) half-length workgroups.  The grid covers either layout.
+            if (s == m.split_seg) {
+                const int32_t *nu = m.split_units;
+                if (m.split_dcells) nu = *const_cast<const int32_t *const volatile *>(&m.split_dcells[0].n_units);   // (volatile: not merged with the argument read above)
+                const long n = nu ? (long)*nu * m.split_rpu : m.split_fixed;
+                if ((n + 31) / 32 <= m.split_max) {
+                    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7)) mlp_fwd_split_body<CB, TRAIN, 1>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+                    else mlp_fwd_split_body<CB, TRAIN, 0>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+                    return;
+                }
+            }
+        }
+        mlp_fwd_body<CB, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
+    } else mlp_fwd_body<CA, TRAIN, NW>(m.seg[s], blk - m.wg0[s], blockIdx.y);
 }
 
-// dynamic LDS beyond 64 KiB has to be granted per kernel function (once per process and function: `done` is the call site's flag)
+// dynamic LDS beyond 64 KiB has to be granted per kernel function
 static inline int allow_lds(const void *fn, size_t bytes) {
     if (bytes <= 65536) return MNR_OK;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -2,6 +2,7 @@
 // translation units that instantiate a pair (mlp_fwd_multi.hip: the default models; mlp_fwd_multi_sh.hip: the spherical-harmonics
 // models of configs/mega-nerf-sh-3) so that the pairs compile in parallel.
 #pragma once
+#include <stdlib.h>
 #include "mlp_fwd_kernels.h"
 #include "step_internal.h"
 
@@ -12,10 +13,22 @@ static inline long n_cells_of(const mnr_mlp_launch &L, const CellTable &c) { ret
 // routed: per segment the device table of a merged container's cells (mnr_mlp_forward_cells_multi), else NULL
 struct RoutedSeg { const mnr_mlp_cell *cells; int n_cells; };
 
+// one feature-split workgroup per CU at most (the partial quantum it is meant for); 0 CUs known -> 256
+static inline int split_workgroups_max() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n = cus;
+        else n = 256;
+    }
+    return n;
+}
+
 template <class CfgFG, class CfgBG, int NW = 4>
 static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const CellTable *cells, hipStream_t s, const RoutedSeg *routed = nullptr) {
     constexpr int ROWS_WG = NW * CfgFG::TILE;
     MlpFwdMulti mm{};
+    mm.split_seg = -1;
     const bool train = segs[0].tape_dev != nullptr;
     long wg = 0;
     for (int i = 0; i < n_segs; ++i) {
@@ -48,13 +61,26 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
         }
         mm.is_b[i] = is_bg ? 1 : 0;
         mm.wg0[i] = (int32_t)wg;
+        // the background segment of a single cell's pass may run as feature-split workgroups of 32 rows (mlp_fwd_split.h): the kernel decides
+        // on the device-side row count; the grid covers the finer layout.  (Several cells fill each other's launch tails: not split.)
+        const long ncell = cells ? n_cells_of(L, cells[i]) : 1;
+        const bool may_split = is_bg && NW == 4 && split_capable<CfgBG>() && !routed && ncell == 1 && i == n_segs - 1 && !getenv("MNR_NO_SPLIT_TAIL");
+        if (may_split) {
+            mm.split_seg = i;
+            mm.split_max = split_workgroups_max();
+            mm.split_rpu = L.io->rows_per_unit;
+            mm.split_units = L.io->n_units_dev;
+            mm.split_dcells = mm.seg[i].dcells;
+            mm.split_fixed = mm.seg[i].dcells ? mm.seg[i].cell_rows : (long)L.io->n_rows;
+        }
+        const long rows_wg = may_split ? 32 : ROWS_WG;
         if (cells) {                       // grid = (workgroups per cell, cells): every segment spans the same cells
             MNR_REQUIRE(cells[i].dcells && n_cells_of(L, cells[i]) == n_cells_of(segs[0], cells[0]) && n_cells_of(L, cells[i]) >= 1,
                         "multi-cell launch: every segment needs a cell table over the same number of cells");
-            wg += cells[i].cell_rows / ROWS_WG;
+            wg += cells[i].cell_rows / rows_wg;
         } else
         // (routed: the worst case -- every row routed to every cell; workgroups past the device-side counts exit at once)
-        wg += (L.io->n_rows + ROWS_WG - 1) / ROWS_WG * (routed ? routed[i].n_cells : 1);
+        wg += (L.io->n_rows + rows_wg - 1) / rows_wg * (routed ? routed[i].n_cells : 1);
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
