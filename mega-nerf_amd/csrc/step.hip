@@ -873,6 +873,7 @@ struct mnr_step_plan {
     long pack_blocks, adam_blocks;
     SSphere sp;
     std::vector<hipEvent_t> events;   // profiling: n_slots x MNR_STEP_SPANS x (start, stop)
+    std::vector<uint8_t> ev_alias;    // ... which event of the slot holds boundary (span, end): adjacent spans share one record (mark2)
     int prof_slots = 0;
     long prof_step = 0;
     // single-cell split-precision plans run the background branch of the forward (coarse pass -> fine samples -> fine pass) on a stream
@@ -1097,13 +1098,20 @@ extern "C" int mnr_step_profile(mnr_step_plan *p, int n_slots) {
     MNR_REQUIRE(p && n_slots >= 0 && n_slots <= 4096, "bad arguments to mnr_step_profile");
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     p->events.clear();
+    p->ev_alias.clear();
     p->prof_slots = 0;
     p->prof_step = 0;
     for (int i = 0; i < n_slots * MNR_STEP_SPANS * 2; ++i) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipEventCreate failed");
+        // (timing-only events: a default event performs a system-scope fence when it is recorded -- a cache write-back and invalidation,
+        // 18 times per step, measured at 0.064 ms of a 6.1 ms step; these events are only ever read through hipEventElapsedTime)
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipEventCreate(&e) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipEventCreate failed");
+        }
         p->events.push_back(e);
     }
+    p->ev_alias.assign((size_t)n_slots * MNR_STEP_SPANS * 2, 0);
     p->prof_slots = n_slots;
     return MNR_OK;
 }
@@ -1111,7 +1119,8 @@ extern "C" int mnr_step_profile(mnr_step_plan *p, int n_slots) {
 extern "C" int mnr_step_kernel_times(mnr_step_plan *p, int slot, float *ms_out) {
     MNR_REQUIRE(p && ms_out && slot >= 0 && slot < p->prof_slots, "bad arguments to mnr_step_kernel_times");
     for (int i = 0; i < MNR_STEP_SPANS; ++i) {
-        const hipEvent_t a = p->events[(size_t)(slot * MNR_STEP_SPANS + i) * 2], b = p->events[(size_t)(slot * MNR_STEP_SPANS + i) * 2 + 1];
+        const size_t base = (size_t)slot * MNR_STEP_SPANS * 2;
+        const hipEvent_t a = p->events[base + p->ev_alias[base + 2 * i]], b = p->events[base + p->ev_alias[base + 2 * i + 1]];
         if (hipEventElapsedTime(&ms_out[i], a, b) != hipSuccess) { (void)hipGetLastError(); ms_out[i] = -1.f; }
     }
     return MNR_OK;
@@ -1135,7 +1144,19 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     int32_t *scal = I(L.scal);
     // profiling (mnr_step_profile): span i of this step's slot
     const long slot = p->prof_slots ? p->prof_step++ % p->prof_slots : -1;
-    auto mark = [&](int span, int end) { if (slot >= 0) (void)hipEventRecord(p->events[(size_t)(slot * MNR_STEP_SPANS + span) * 2 + end], s); };
+    const size_t ev0 = slot >= 0 ? (size_t)slot * MNR_STEP_SPANS * 2 : 0;
+    auto mark = [&](int span, int end) {
+        if (slot < 0) return;
+        p->ev_alias[ev0 + 2 * span + end] = (uint8_t)(2 * span + end);
+        (void)hipEventRecord(p->events[ev0 + 2 * span + end], s);
+    };
+    // the end of span `a` and the beginning of span `b` with nothing enqueued between them: ONE record (every record is a packet the GPU's
+    // command processor works through between two kernels)
+    auto mark2 = [&](int a, int b) {
+        if (slot < 0) return;
+        p->ev_alias[ev0 + 2 * a + 1] = p->ev_alias[ev0 + 2 * b] = (uint8_t)(2 * b);
+        (void)hipEventRecord(p->events[ev0 + 2 * b], s);
+    };
     mark(0, 0);
     // ---- begin ----
     {
@@ -1164,7 +1185,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         int rc = check_launch("k_step_samples");
         if (rc) return rc;
     }
-    mark(0, 1);
+    if (p->side) mark(0, 1);          // (one stream: shared with the coarse pass's opening record below)
     // ---- MLP passes: segment descriptions over the cell-major arrays ----
     const mnr_step_model &M0f = p->models[0], &M0b = p->models[1];
     const bool split = p->cfg.split_precision != 0;
@@ -1257,19 +1278,20 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         if (hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)
             return set_err(MNR_E_LAUNCH, "mnr_train_step: stream join failed: %s", hipGetErrorString(hipGetLastError()));
     } else {
-        mark(1, 0);
+        mark2(0, 1);
         if ((rc = fwd_pass(0, 0, s))) return rc;
-        mark(1, 1);
         // ---- coarse weights -> fine samples ----
-        mark(2, 0);
+        mark2(1, 2);
         if ((rc = mid(0, 2 * CN, s))) return rc;
-        mark(2, 1);
-        mark(3, 0);
+        mark2(2, 3);
         if ((rc = fwd_pass(1, 0, s))) return rc;
         mark(3, 1);
     }
     // ---- merge, compositing, blend, loss and their adjoints ----
-    mark(4, 0);
+    if (slot >= 0) {               // (one stream: shares the fine pass's closing record; the two-stream schedules joined in between)
+        if (p->side) mark(4, 0);
+        else p->ev_alias[ev0 + 2 * 4] = p->ev_alias[ev0 + 2 * 3 + 1];
+    }
     {
         TailArgs a{};
         a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb;
@@ -1316,9 +1338,8 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
             rc = sh_head_bwd_jobs(jobs.data() + i, (int)std::min<size_t>(SH_HEAD_MAX_JOBS, jobs.size() - i), s);
         if (rc) return rc;
     }
-    mark(4, 1);
+    mark2(4, 5);
     // ---- data-gradient chains: fg coarse, fg fine, bg coarse, bg fine (all cells each) ----
-    mark(5, 0);
     {
         mnr_mlp_grad_io g[4] = {};
         mnr_mlp_grad_launch seg[4] = {};
@@ -1344,9 +1365,8 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         rc = split ? mlp_backward_chain_multi_h2_impl(seg, 4, ct, s) : mlp_backward_chain_multi_impl(seg, 4, ct, s);
         if (rc) return rc;
     }
-    mark(5, 1);
+    mark2(5, 6);
     // ---- head gradients: per cell one dense foreground job + two device-counted background jobs ----
-    mark(6, 0);
     {
         const TapeLayout tlf = tape_layout(ArchDims{M0f.desc.xyz_dim, M0f.desc.pos_xyz_dim, M0f.desc.pos_dir_dim, M0f.desc.layers, M0f.desc.skip_mask,
                                                     M0f.desc.layer_dim, M0f.desc.appearance_dim, M0f.desc.rgb_dim, M0f.desc.mfma_tile});
@@ -1368,9 +1388,8 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
             rc = head_grads_jobs(jobs.data() + i, (int)std::min<size_t>(HEAD_MAX_JOBS, jobs.size() - i), 256, s);
         if (rc) return rc;
     }
-    mark(6, 1);
+    mark2(6, 7);
     // ---- weight gradients, cell by cell (persistent launches: no tail to share between cells) ----
-    mark(7, 0);
     for (int c = 0; c < C; ++c) {
         mnr_wgrad_region rg[2] = {};
         const mnr_step_model &Mf = p->models[2 * c], &Mb = p->models[2 * c + 1];
@@ -1387,10 +1406,9 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
                                   split && !getenv("MNR_STEP_F32_WGRAD") ? zexp : nullptr);
         if (rc) return rc;
     }
-    mark(7, 1);
-    if (flags & MNR_STEP_NO_OPTIMIZER) return MNR_OK;
+    if (flags & MNR_STEP_NO_OPTIMIZER) { mark(7, 1); return MNR_OK; }
     // ---- Adam (torch.optim.Adam defaults of runner.py:169-171) + re-pack ----
-    mark(8, 0);
+    mark2(7, 8);
     {
         // the hyper-parameters as the Python doubles the caller typed (0.9, 0.999, 1e-8), not as the widened floats of the cfg struct
         hipLaunchKernelGGL(k_step_adam, dim3((unsigned)p->adam_blocks), dim3(256), 0, s, reinterpret_cast<const AdamTensor *>(ws + L.tab_adam),
