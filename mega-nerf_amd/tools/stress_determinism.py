@@ -71,6 +71,27 @@ def main():
                           'finite': bool(torch.isfinite(first[0]).all())}), flush=True)
         del fg, bg
         torch.cuda.empty_cache()
+    # the TRAINING forward (tape-writing kernels, feature-split tail included): the same step -- same weights (no optimiser), same Philox
+    # counter -- again and again; its colours and depth variances depend on the forward only and must not move by a bit
+    from mega_nerf.training import FusedTrainStep
+    hp = get_opts_base().parse_args(['--coarse_samples', '64', '--fine_samples', '128'])
+    (fg, _, _), (bg, _, _) = bench.build_models(hp, dev, 1000, 256)
+    fg.train(), bg.train()
+    fs = FusedTrainStep([(fg, bg)], hp, sc, sr, 1024)
+    r = rays_all[sel[:1024].to(dev)].contiguous()
+    batch = (r, torch.randint(0, s['appearance_count'], (1024,), generator=g).float().to(dev), torch.rand(1024, 3, generator=g).to(dev))
+    first, bad = None, torch.zeros((), device=dev, dtype=torch.int64)
+    for it in range(a.iters):
+        fs.step_count = 0
+        fs([batch], optimize=False)
+        out = torch.cat([fs.rgb.reshape(-1), fs.depth_variance.reshape(-1)])
+        if first is None:
+            first = out.clone()
+        else:
+            bad += (out.view(torch.int32) != first.view(torch.int32)).any().long()
+    torch.cuda.synchronize()
+    print(json.dumps({'config': 'default 8x256, training forward (mnr_train_step without the optimiser)', 'steps': a.iters,
+                      'steps_differing_from_the_first': int(bad), 'finite': bool(torch.isfinite(first).all())}), flush=True)
 
 
 if __name__ == '__main__':
