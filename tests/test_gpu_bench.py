@@ -63,11 +63,14 @@ def test_evaluation_renders_are_bit_reproducible():
     """Race hunt for the software-pipelined forward kernels (chunk barriers taken two batches early, LDS-DMA'd bias rows, LDS stashes:
     DESIGN 3a): evaluation renders are deterministic, so any run-to-run difference is an LDS / barrier hazard.  `tools/stress_determinism.py`
     renders the benchmark batch (and a ragged one in between) 200 times for the default architecture, the SH head, the 512-wide pair kernel
-    and a routed 8-cell container: every render bit-identical to the first (3 000 renders each were run when the kernels were written)."""
+    and a routed 8-cell container, and steps the training forward 200 times: every output bit-identical to the first (1 500-3 000 repetitions
+    each were run when the kernels were written)."""
     r = subprocess.run([sys.executable, str(ROOT / 'mega-nerf_amd' / 'tools' / 'stress_determinism.py'), '--iters', '200'], cwd=str(ROOT),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 4, r.stdout
-    for ln in lines:
+    assert len(lines) == 5, r.stdout
+    for ln in lines[:4]:
         assert ln['renders'] == 200 and ln['renders_differing_from_the_first'] == 0 and ln['finite'], ln
+    # ... and the TRAINING forward (tape-writing kernels, the feature-split tail): the same step without its optimiser, 200 times
+    assert lines[4]['steps'] == 200 and lines[4]['steps_differing_from_the_first'] == 0 and lines[4]['finite'], lines[4]
