@@ -332,9 +332,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('MNR_BENCH_FORCE_DIST'):      # (FORCE_DIST: the RCCL branch with ONE rank -- what a 1-GPU box can execute of it)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
+        os.environ.setdefault('RANK', '0'), os.environ.setdefault('WORLD_SIZE', '1')
         if os.environ.get('MNR_BENCH_SHARE_GPU'):
             dist.init_process_group('gloo')                       # (RCCL refuses two ranks on one device)
         else:

@@ -34,6 +34,42 @@ def test_two_ranks_step_the_fixed_eight_cell_set():
     assert line['host']['launches_per_step'] == 11 + 2 * 4            # each rank: its four cells in one fused call
 
 
+_RCCL_ONE_RANK = """
+import os, torch, torch.distributed as dist
+dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', device_id=dev)
+t = torch.tensor([1.5, 2.0, 7.0], dtype=torch.float64, device=dev)          # distributed.all_reduce_metrics: packed fp64 sums + count
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+m = torch.tensor([3.25], dtype=torch.float64, device=dev)                    # bench.py: max-over-ranks step time
+dist.all_reduce(m, op=dist.ReduceOp.MAX)
+flat = torch.arange(1 << 20, dtype=torch.float32, device=dev)                # distributed.gather_submodule_weights: flat fp32 weights
+bufs = [torch.empty_like(flat) for _ in range(dist.get_world_size())]
+dist.all_gather(bufs, flat)
+dist.barrier()
+torch.cuda.synchronize()
+print('RCCL_OK', t.tolist(), m.item(), bool((bufs[0] == flat).all()), dist.get_backend(), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_runs_the_paths_collectives_with_one_rank():
+    """A one-GPU box cannot run two RCCL ranks (one communicator per device), and the driver's scaling runs were skipped every round: what CAN
+    be executed here of the `nccl` branches is executed -- communicator bound to the device, the packed fp64 all_reduce (SUM / MAX), the flat
+    fp32 all_gather and the barrier with ONE rank, then bench.py's own RCCL branch under torch.distributed.run (MNR_BENCH_FORCE_DIST)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    run = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1']
+    r = subprocess.run(run + ['--master-port', '29537', '--no-python', sys.executable, '-c', _RCCL_ONE_RANK], cwd=str(ROOT), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_OK [1.5, 2.0, 7.0] 3.25 True nccl' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    r = subprocess.run(run + ['--master-port', '29539', str(ROOT / 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                              '--no-extras', '--no-config-sweep'], cwd=str(ROOT), env=dict(env, MNR_BENCH_FORCE_DIST='1'),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line['n_gpus'] == 1 and line['steps'] == 3 and line['value'] > 0
+
+
 def test_default_line_carries_every_baseline_config():
     """The driver's command (short timed region): headline = configs[1] train rays/s; `baseline_configs` = the 8-cell set, the 8- and
     25-cell containers, W = 512 and the SH shape, each with its own ms_per_step / rays/s / roofline fraction (none above 1: the round-3
