@@ -480,17 +480,23 @@ int mnr_route(const float *pos_dev, int64_t pos_stride, int64_t B, const int32_t
               const float *centroids_host, int n_sub, int cluster_dim_start, float boundary_margin,
               float *weights_out_dev, int32_t *lists_out_dev, int32_t *counts_out_dev, void *stream);
 
+/* mnr_route + the INVERSE of the lists: inverse_out [n_sub][B], inverse[i][row] = position of `row` in cell i's list, -1 where the row
+ * was not routed to cell i (written for every row below the device-side count) -- what mnr_route_combine_indexed reads. */
+int mnr_route_indexed(const float *pos_dev, int64_t pos_stride, int64_t B, const int32_t *n_units_dev, int rows_per_unit,
+                      const float *centroids_host, int n_sub, int cluster_dim_start, float boundary_margin,
+                      float *weights_out_dev, int32_t *lists_out_dev, int32_t *counts_out_dev, int32_t *inverse_out_dev, void *stream);
+
 /* out[list[r]][c] (+)= sub_out[r][c] * (weights ? weights[list[r]] : 1) for r < *count  (mega_nerf.py:45-49). */
 int mnr_route_accumulate(float *out_dev, int64_t out_stride, const float *sub_out_dev, int64_t sub_stride, int n_cols,
                          const int32_t *list_dev, const int32_t *count_dev, int64_t B_max, const float *weights_dev,
                          int assign, void *stream);
-/* All cells at once: out[row] = sum_i w_i[row] * sub_i[position of row in list_i] in cell order (identical roundings to
- * n_sub mnr_route_accumulate calls on a zeroed output).  sub_all: cell i's compact outputs start at sub_all + i*cell_stride,
- * rows sub_stride apart; lists / weights [n_sub][B] as written by mnr_route (weights NULL = hard routing);
- * pos_scratch: [n_sub][B] int32 work buffer; rows >= *n_dev * rows_per_unit (when n_dev is given) are left untouched. */
-int mnr_route_combine(float *out_dev, int64_t out_stride, const float *sub_all_dev, int64_t cell_stride, int64_t sub_stride,
-                      int n_cols, const int32_t *lists_dev, const int32_t *counts_dev, const float *weights_dev, int n_sub,
-                      int64_t B, const int32_t *n_units_dev, int rows_per_unit, int32_t *pos_scratch_dev, void *stream);
+/* All cells at once: out[row] = sum_i w_i[row] * sub_i[inverse_i[row]] in cell order (identical roundings to n_sub
+ * mnr_route_accumulate calls on a zeroed output: mega_nerf.py:43-49).  sub_all: cell i's compact outputs start at
+ * sub_all + i * cell_stride, rows sub_stride apart; inverse / weights [n_sub][B] as written by mnr_route_indexed (weights NULL = hard
+ * routing).  One launch; rows at or past *n_units_dev * rows_per_unit are ZEROED (the caller need not clear `out`). */
+int mnr_route_combine_indexed(float *out_dev, int64_t out_stride, const float *sub_all_dev, int64_t cell_stride, int64_t sub_stride,
+                              int n_cols, const int32_t *inverse_dev, const float *weights_dev, int n_sub, int64_t B,
+                              const int32_t *n_units_dev, int rows_per_unit, void *stream);
 
 /* fg/bg blend (rendering.py:102-139): for every ray, slot = bg_slot[ray]:
  *   bg_rgb = slot>=0 ? lambda*bg_rgb_c[slot] : 0;  rgb = fg + bg_rgb  (same for depth).

@@ -730,14 +730,33 @@ struct Centroids {
     int n;
 };
 
-__global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, long pos_stride, long B,
-                                               const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
-                                               float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
-                                               int32_t *__restrict__ counts) {
+// Block = 1024 rows (16 wavefronts).  The append to the cells' row lists is aggregated per BLOCK: pass 1 leaves every wavefront's count of
+// rows routed to cell i in LDS, one thread per cell turns them into offsets and takes the block's range with ONE atomic on counts[i]
+// (round 4 took one per wavefront: 1 024 same-address atomics per cell for a coarse pass -- 48-71 us of a routed render), pass 2
+// writes the row ids.  `inverse` (optional) [n_sub][B]: the position of `row` in cell i's list, -1 where it was not routed there -- what
+// k_route_combine needs (round 4 built it with a fill + an inversion launch per evaluation).
+constexpr int ROUTE_BLOCK = 1024;
+__global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__ pos, long pos_stride, long B,
+                                                       const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
+                                                       float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
+                                                       int32_t *__restrict__ counts, int32_t *__restrict__ inverse) {
+    __shared__ int wcnt[ROUTE_MAX_SUB][ROUTE_BLOCK / 64];
+    __shared__ int base[ROUTE_MAX_SUB];
+    __shared__ float4 sc[ROUTE_MAX_SUB];                                   // (c_x, c_y, c_z, |c|^2 over the clustered axes)
     const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((long)blockIdx.x * ROUTE_BLOCK >= n) return;                       // (uniform: the whole block is past the device-side count)
+    // The centroids go through LDS once: read from the kernel-argument block inside the three loops below, every cell cost a chain of
+    // dependent scalar loads -- ~15 us per launch whatever the row count (round 5 trace: 20 us for 4 416 rows and for 65 536).
+    if ((int)threadIdx.x < cen.n) {
+        const int i = threadIdx.x;
+        float cn = 0.f;
+        for (int k = d0; k < 3; ++k) cn = k == d0 ? cen.c[i][k] * cen.c[i][k] : cn + cen.c[i][k] * cen.c[i][k];
+        sc[i] = make_float4(cen.c[i][0], cen.c[i][1], cen.c[i][2], cn);
+    }
+    __syncthreads();
+    const long row = (long)blockIdx.x * ROUTE_BLOCK + threadIdx.x;
     const bool valid = row < n;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float p[3] = {0.f, 0.f, 0.f};
     if (valid) { p[0] = pos[row * pos_stride]; p[1] = pos[row * pos_stride + 1]; p[2] = pos[row * pos_stride + 2]; }
     // distances: torch.cdist(x[:, d0:3], centroids[:, d0:]) (mega_nerf.py:22,31).  ATen takes its MATMUL formulation whenever either side
@@ -750,16 +769,17 @@ __global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, lo
     float xn = 0.f;
     for (int k = d0; k < 3; ++k) xn = k == d0 ? p[k] * p[k] : xn + p[k] * p[k];
     auto dist = [&](int i) {
+        const float4 c4 = sc[i];
+        const float c[3] = {c4.x, c4.y, c4.z};
         if (!mm) {
             float s = 0.f;
-            for (int k = d0; k < 3; ++k) { const float t = p[k] - cen.c[i][k]; s += t * t; }
+            for (int k = d0; k < 3; ++k) { const float t = p[k] - c[k]; s += t * t; }
             return sqrtf(s);
         }
-        float cn = 0.f, acc = 0.f;
-        for (int k = d0; k < 3; ++k) cn = k == d0 ? cen.c[i][k] * cen.c[i][k] : cn + cen.c[i][k] * cen.c[i][k];
-        for (int k = d0; k < 3; ++k) acc = k == d0 ? (-2.f * p[k]) * cen.c[i][k] : fmaf(-2.f * p[k], cen.c[i][k], acc);
+        float acc = 0.f;
+        for (int k = d0; k < 3; ++k) acc = k == d0 ? (-2.f * p[k]) * c[k] : fmaf(-2.f * p[k], c[k], acc);
         acc = fmaf(xn, 1.f, acc);
-        acc = fmaf(1.f, cn, acc);
+        acc = fmaf(1.f, c4.w, acc);
         return sqrtf(fmaxf(acc, 0.f));
     };
     float dmin = INFINITY;
@@ -775,6 +795,8 @@ __global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, lo
             wsum += d > margin * dmin ? 0.f : 1.f / (d + 1e-8f);
         }
     }
+    // pass 1: weights out; which cells take this row (bit i of rmask); per-wavefront counts
+    unsigned long long rmask = 0ull;
     for (int i = 0; i < cen.n; ++i) {
         float w;
         if (margin > 1.f) {
@@ -785,14 +807,24 @@ __global__ __launch_bounds__(256) void k_route(const float *__restrict__ pos, lo
         }
         const bool routed = valid && w > 0.f;
         if (valid) weights[(long)i * B + row] = w;
-        // wave-aggregated append to cell i's row list
+        if (routed) rmask |= 1ull << i;
         const unsigned long long m = __ballot(routed);
-        if (m) {
-            int base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counts + i, __popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (routed) lists[(long)i * B + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)row;
-        }
+        if (lane == 0) wcnt[i][wave] = __popcll(m);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cen.n) {
+        int total = 0;
+        for (int w = 0; w < ROUTE_BLOCK / 64; ++w) { const int c = wcnt[threadIdx.x][w]; wcnt[threadIdx.x][w] = total; total += c; }
+        base[threadIdx.x] = total ? atomicAdd(counts + threadIdx.x, total) : 0;
+    }
+    __syncthreads();
+    // pass 2: row ids into the block's range of every list, positions into the inverse map
+    for (int i = 0; i < cen.n; ++i) {
+        const bool routed = (rmask >> i) & 1ull;
+        const unsigned long long m = __ballot(routed);
+        const int slot = base[i] + wcnt[i][wave] + __popcll(m & ((1ull << lane) - 1ull));
+        if (routed) lists[(long)i * B + slot] = (int32_t)row;
+        if (inverse && valid) inverse[(long)i * B + row] = routed ? slot : -1;
     }
 }
 
@@ -811,23 +843,19 @@ __global__ void k_route_accumulate(float *__restrict__ out, long out_stride, con
 }
 
 // ---- one-pass blend of all cells (replaces n_sub k_route_accumulate launches) ----------------------------------------
-// pos[i][row] = index of `row` in cell i's compact list (or -1): the inverse of the lists k_route appended
-__global__ void k_route_invert(int32_t *__restrict__ pos, const int32_t *__restrict__ lists, const int32_t *__restrict__ counts,
-                               long B, int n_sub) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(t / B);
-    const long k = t % B;
-    if (i >= n_sub || k >= counts[i]) return;
-    pos[(long)i * B + lists[(long)i * B + k]] = (int32_t)k;
-}
+// pos[i][row] = index of `row` in cell i's compact list (or -1): k_route's inverse map
 // out[row] = sum over the cells in index order of w_i[row] * sub_i[pos_i[row]]  (same order and roundings as applying
 // k_route_accumulate cell after cell to a zeroed output: mega_nerf.py:43-49)
 __global__ void k_route_combine(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long cell_stride,
                                 long sub_stride, int n_cols, const int32_t *__restrict__ pos, const float *__restrict__ weights,
-                                int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit) {
+                                int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit, int zero_rest) {
     const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
+    if (row >= n) {
+        if (zero_rest && row < B)
+            for (int c = 0; c < n_cols; ++c) out[row * out_stride + c] = 0.f;
+        return;
+    }
     float acc[32];
     for (int c = 0; c < n_cols; ++c) acc[c] = 0.f;
     for (int i = 0; i < n_sub; ++i) {
@@ -842,23 +870,45 @@ __global__ void k_route_combine(float *__restrict__ out, long out_stride, const 
 
 }  // namespace mnr
 
-extern "C" int mnr_route(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
-                         const float *centroids, int n_sub, int d0, float margin, float *weights, int32_t *lists,
-                         int32_t *counts, void *stream) {
+namespace mnr {
+__global__ void k_zero_i32(int32_t *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+}  // namespace mnr
+
+static int route_impl(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit, const float *centroids, int n_sub,
+                      int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, void *stream) {
     MNR_REQUIRE(pos && centroids && weights && lists && counts && B >= 0, "bad arguments to mnr_route");
     MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
     MNR_REQUIRE(d0 == 0 || d0 == 1, "cluster_dim_start must be 0 or 1");
     MNR_REQUIRE(margin >= 1.f, "boundary_margin must be >= 1");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * n_sub, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(counts)");
+    // (a kernel, not hipMemsetAsync: the runtime's fill leaves a ~6 us bubble in front of it on the stream, four times per routed render)
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, counts, n_sub);
+    int rc = check_launch("k_zero_i32");
+    if (rc) return rc;
     if (B == 0) return MNR_OK;
     Centroids cen;
     cen.n = n_sub;
     for (int i = 0; i < n_sub; ++i)
         for (int k = 0; k < 3; ++k) cen.c[i][k] = centroids[3 * i + k];
-    hipLaunchKernelGGL(k_route, dim3(nblk(B, 256)), dim3(256), 0, s, pos, (long)pos_stride, (long)B, n_dev, rows_per_unit, cen,
-                       d0, margin, weights, lists, counts);
+    hipLaunchKernelGGL(k_route, dim3(nblk(B, ROUTE_BLOCK)), dim3(ROUTE_BLOCK), 0, s, pos, (long)pos_stride, (long)B, n_dev, rows_per_unit, cen,
+                       d0, margin, weights, lists, counts, inverse);
     return check_launch("k_route");
+}
+
+extern "C" int mnr_route(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
+                         const float *centroids, int n_sub, int d0, float margin, float *weights, int32_t *lists,
+                         int32_t *counts, void *stream) {
+    return route_impl(pos, pos_stride, B, n_dev, rows_per_unit, centroids, n_sub, d0, margin, weights, lists, counts, nullptr, stream);
+}
+
+extern "C" int mnr_route_indexed(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
+                                 const float *centroids, int n_sub, int d0, float margin, float *weights, int32_t *lists,
+                                 int32_t *counts, int32_t *inverse, void *stream) {
+    MNR_REQUIRE(inverse, "bad arguments to mnr_route_indexed");
+    return route_impl(pos, pos_stride, B, n_dev, rows_per_unit, centroids, n_sub, d0, margin, weights, lists, counts, inverse, stream);
 }
 
 extern "C" int mnr_route_accumulate(float *out, int64_t out_stride, const float *sub, int64_t sub_stride, int n_cols,
@@ -871,20 +921,13 @@ extern "C" int mnr_route_accumulate(float *out, int64_t out_stride, const float 
     return check_launch("k_route_accumulate");
 }
 
-extern "C" int mnr_route_combine(float *out, int64_t out_stride, const float *sub_all, int64_t cell_stride, int64_t sub_stride,
-                                 int n_cols, const int32_t *lists, const int32_t *counts, const float *weights, int n_sub, int64_t B,
-                                 const int32_t *n_dev, int rows_per_unit, int32_t *pos_scratch, void *stream) {
-    MNR_REQUIRE(out && sub_all && lists && counts && pos_scratch && n_cols > 0 && n_cols <= 32 && B >= 0,
-                "bad arguments to mnr_route_combine");
+extern "C" int mnr_route_combine_indexed(float *out, int64_t out_stride, const float *sub_all, int64_t cell_stride, int64_t sub_stride,
+                                         int n_cols, const int32_t *inverse, const float *weights, int n_sub, int64_t B,
+                                         const int32_t *n_dev, int rows_per_unit, void *stream) {
+    MNR_REQUIRE(out && sub_all && inverse && n_cols > 0 && n_cols <= 32 && B >= 0, "bad arguments to mnr_route_combine_indexed");
     MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
     if (B == 0) return MNR_OK;
-    hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(pos_scratch, 0xFF, sizeof(int32_t) * (size_t)n_sub * (size_t)B, s) != hipSuccess)
-        return set_err(MNR_E_LAUNCH, "hipMemsetAsync(pos)");
-    hipLaunchKernelGGL(k_route_invert, dim3(nblk((long)n_sub * B, 256)), dim3(256), 0, s, pos_scratch, lists, counts, (long)B, n_sub);
-    int rc = check_launch("k_route_invert");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_route_combine, dim3(nblk(B, 256)), dim3(256), 0, s, out, (long)out_stride, sub_all, (long)cell_stride,
-                       (long)sub_stride, n_cols, pos_scratch, weights, n_sub, (long)B, n_dev, rows_per_unit);
+    hipLaunchKernelGGL(k_route_combine, dim3(nblk(B, 256)), dim3(256), 0, as_stream(stream), out, (long)out_stride, sub_all, (long)cell_stride,
+                       (long)sub_stride, n_cols, inverse, weights, n_sub, (long)B, n_dev, rows_per_unit, 1);
     return check_launch("k_route_combine");
 }

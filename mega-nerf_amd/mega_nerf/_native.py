@@ -190,9 +190,9 @@ EXPORTS = [
     'mnr_sample_fine', 'mnr_merge_sorted', 'mnr_sort_rows', 'mnr_composite', 'mnr_bg_blend',
     'mnr_tape_floats_per_row', 'mnr_mlp_forward_train', 'mnr_packed_bwd_bytes', 'mnr_pack_model_bwd',
     'mnr_mlp_backward_data', 'mnr_mlp_backward_weights', 'mnr_composite_backward', 'mnr_merge_backward',
-    'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
+    'mnr_bg_blend_backward', 'mnr_route', 'mnr_route_indexed', 'mnr_route_combine_indexed', 'mnr_route_accumulate', 'mnr_embed', 'mnr_gather_rows', 'mnr_linear',
     'mnr_fused_supported', 'mnr_cluster_min_ratios', 'mnr_gemm', 'mnr_act_grad', 'mnr_col_sum', 'mnr_scatter_rows',
-    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_route_combine', 'mnr_tape_plane_offset',
+    'mnr_sh_apply', 'mnr_sh_backward', 'mnr_fused_train_supported', 'mnr_image_metrics', 'mnr_get_rays_indexed', 'mnr_mlp_forward_cells', 'mnr_tape_plane_offset',
     'mnr_wgrad_workspace_bytes', 'mnr_mlp_backward_weights_multi', 'mnr_mlp_forward_multi', 'mnr_mlp_backward_data_multi', 'mnr_affine_apply', 'mnr_affine_backward',
     'mnr_tgemm_run', 'mnr_wgrad_jobs', 'mnr_mlp_backward_chain_multi', 'mnr_mlp_head_grads_multi',
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
@@ -276,11 +276,13 @@ def lib() -> C.CDLL:
                                             C.c_void_p, C.c_void_p]
         _lib.mnr_route.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int,
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_route_indexed.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int,
+                                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mnr_route_combine_indexed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib.mnr_route_accumulate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         _lib.mnr_fused_supported.argtypes = [C.POINTER(ModelDesc)]
-        _lib.mnr_route_combine.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
-                                           C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.mnr_mlp_forward_cells.argtypes = [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.POINTER(MlpIO), C.c_void_p]
         _lib.mnr_mlp_forward_cells_h2.argtypes = [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.POINTER(MlpIO), C.c_void_p]
         _lib.mnr_mlp_forward_cells_multi.argtypes = [C.POINTER(MlpCellsLaunch), C.c_int, C.c_void_p]

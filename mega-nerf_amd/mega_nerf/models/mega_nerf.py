@@ -36,7 +36,7 @@ class RoutedTape:
 
 class _RoutedJob:
     """State of one routed evaluation between MegaNeRF._route_begin and ._route_finish."""
-    __slots__ = ('args', 'out', 'B', 'ncol', 'n_units', 'rows_per_unit', 'weights', 'lists', 'counts', 'cells', 'split', 'sub_out',
+    __slots__ = ('args', 'out', 'B', 'ncol', 'n_units', 'rows_per_unit', 'weights', 'lists', 'counts', 'inverse', 'cells', 'split', 'sub_out',
                  'desc', 'io', 'default_arch')
 
 
@@ -128,6 +128,24 @@ class MegaNeRF(nn.Module):
         cache[key] = table
         return table
 
+    def _route_ws(self, B: int, ncol: int, dev: torch.device) -> dict:
+        """The buffers of a routed evaluation of B rows (blend weights, row lists, counts, inverse map, the cells' compact outputs), kept
+        per (stream, B, ncol): a render evaluates the same row counts every time, and fresh ``torch.empty`` buffers each time moved the
+        pointers of the launch's cell table -- a table upload per evaluation.  One evaluation of a given size is in flight per container
+        and stream (the next one's kernels are ordered behind the previous one's on that stream); at most four sizes are kept."""
+        cache = self.__dict__.setdefault('_route_buffers', {})
+        key = (torch.cuda.current_stream(dev).cuda_stream, B, ncol)
+        ws = cache.get(key)
+        if ws is None:
+            n_sub = len(self.sub_modules)
+            ws = dict(weights=torch.empty(n_sub, B, device=dev, dtype=torch.float32), lists=torch.empty(n_sub, B, device=dev, dtype=torch.int32),
+                      counts=torch.empty(n_sub, device=dev, dtype=torch.int32), inverse=torch.empty(n_sub, B, device=dev, dtype=torch.int32),
+                      sub_out=None)
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            cache[key] = ws
+        return ws
+
     def _routed(self, pos: torch.Tensor, pos_stride: int, xyz: torch.Tensor, xyz_stride: int,
                 dirs: Optional[torch.Tensor], dir_stride: int, idx: Optional[torch.Tensor], idx_stride: int,
                 rows_per_ray: int, B: int, out: torch.Tensor, noise: Optional[torch.Tensor], sigma_only: bool, sh_deg: int,
@@ -159,28 +177,29 @@ class MegaNeRF(nn.Module):
         job.split = job.default_arch = False
         job.args = (xyz, xyz_stride, dirs, dir_stride, idx, idx_stride, rows_per_ray, B, noise, sigma_only, sh_deg)
         job.out, job.B, job.ncol, job.n_units, job.rows_per_unit = out, B, ncol, n_units, rows_per_unit
-        job.weights = weights = torch.empty(n_sub, B, device=dev, dtype=torch.float32)
-        job.lists = lists = torch.empty(n_sub, B, device=dev, dtype=torch.int32)
-        job.counts = counts = torch.empty(n_sub, device=dev, dtype=torch.int32)
-        N.check(lib.mnr_route(pos.data_ptr(), pos_stride, B, N.ptr(n_units), rows_per_unit, self._centroids_host(), n_sub,
-                              self.cluster_dim_start, float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(),
-                              counts.data_ptr(), N.stream_ptr()))
+        ws = self._route_ws(B, ncol, dev)
+        job.weights, job.lists, job.counts, job.inverse = weights, lists, counts, inverse = ws['weights'], ws['lists'], ws['counts'], ws['inverse']
+        N.check(lib.mnr_route_indexed(pos.data_ptr(), pos_stride, B, N.ptr(n_units), rows_per_unit, self._centroids_host(), n_sub,
+                                      self.cluster_dim_start, float(self.boundary_margin), weights.data_ptr(), lists.data_ptr(),
+                                      counts.data_ptr(), inverse.data_ptr(), N.stream_ptr()))
         rr = getattr(self, 'routed_rows', None)        # optional device-side tally of routed rows (bench.py: FLOPs of a routed step)
         if rr is not None:
             rr.add_(counts.sum())
-        out.zero_()
         kids = list(self.sub_modules)
         # (mnr_mlp_forward_cells takes at most 64 cells per launch: larger grids go cell by cell)
         same_arch = n_sub <= 64 and all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) for c in kids)
         job.cells = None
         if not same_arch:
+            out.zero_()                                # (the cell-by-cell fallback accumulates into `out`)
             return job
         from mega_nerf import rendering as R
         # opt-in split precision (rendering.SPLIT_PRECISION; csrc/mlp_fwd_h2.hip): inference of the default 8x256 cells
         split = (R.SPLIT_PRECISION and not torch.is_grad_enabled() and not sigma_only and sh_deg < 0 and dirs is not None and
                  idx is not None and all(c.is_default_arch() for c in kids))
         self._last_routed_split = job.split = split       # (tests: which kernel family served the last routed evaluation)
-        job.sub_out = sub_out = torch.empty(n_sub, B, ncol, device=dev, dtype=torch.float32)
+        if ws['sub_out'] is None:
+            ws['sub_out'] = torch.empty(n_sub, B, ncol, device=dev, dtype=torch.float32)
+        job.sub_out = sub_out = ws['sub_out']
         rows = []
         for i, child in enumerate(kids):
             _, packed = child.packed_h2() if split else child.packed()
@@ -199,12 +218,10 @@ class MegaNeRF(nn.Module):
     def _route_finish(self, job: '_RoutedJob') -> None:
         """Blend the cells' outputs in cell order (k_route_combine: the reference loop's summation order, mega_nerf.py:28-49)."""
         n_sub = len(self.sub_modules)
-        dev = job.out.device
-        pos_scratch = torch.empty(n_sub, job.B, device=dev, dtype=torch.int32)
-        N.check(N.lib().mnr_route_combine(job.out.data_ptr(), job.ncol, job.sub_out.data_ptr(), job.B * job.ncol, job.ncol, job.ncol,
-                                          job.lists.data_ptr(), job.counts.data_ptr(),
-                                          job.weights.data_ptr() if self.boundary_margin > 1 else None, n_sub, job.B,
-                                          N.ptr(job.n_units), job.rows_per_unit, pos_scratch.data_ptr(), N.stream_ptr()))
+        # (the inverse map came out of the routing kernel: one launch, and rows past the device-side count are zeroed by it)
+        N.check(N.lib().mnr_route_combine_indexed(job.out.data_ptr(), job.ncol, job.sub_out.data_ptr(), job.B * job.ncol, job.ncol, job.ncol,
+                                                  job.inverse.data_ptr(), job.weights.data_ptr() if self.boundary_margin > 1 else None,
+                                                  n_sub, job.B, N.ptr(job.n_units), job.rows_per_unit, N.stream_ptr()))
 
     def _routed_cell_by_cell(self, job: '_RoutedJob') -> None:
         lib = N.lib()
