@@ -383,11 +383,6 @@ SWEEP = [
 def config_sweep(args, dev):
     import gc
     out = {}
-    # The headline's cpu_baseline leg ran torch on every host thread the process may use; its OpenMP workers keep spinning for a while after
-    # every later CPU-side tensor op, next to the one Python thread that enqueues the launches -- the routed-container entry (36 launches
-    # per 3.5 ms render) then measured 3.69 ms here against 3.56 ms on its own.  The GPU path needs one host thread.
-    host_threads = torch.get_num_threads()
-    torch.set_num_threads(1)
     for name, flags, steps in SWEEP:
         a = parse_args(flags + ['--steps', str(steps), '--warmup', '3', '--no-cpu-baseline', '--no-extras', '--rays', str(args.rays), '--samples', args.samples])
         t0 = time.perf_counter()
@@ -401,7 +396,6 @@ def config_sweep(args, dev):
             for k in ('step_spans_ms',):
                 if k in ln:
                     out[name][k] = ln[k]
-            out[name]['host_enqueue_ms_per_step'] = (ln.get('host') or {}).get('host_enqueue_ms_per_step')
             if 'routed_rows_per_step' in r:
                 out[name]['routed_rows_per_step'] = r['routed_rows_per_step']
         except Exception as e:                      # a side line must never take the headline down
@@ -416,7 +410,6 @@ def config_sweep(args, dev):
             out[name] = {'flags': 'configs/nerf/*.yaml', 'error': '%s: %s' % (type(e).__name__, e)}
         gc.collect()
         torch.cuda.empty_cache()
-    torch.set_num_threads(host_threads)
     return out
 
 
@@ -594,8 +587,8 @@ def run_config(args, rank, world, dev, dist):
         sub = [build_models(hp, dev, 1000 * (rank + 1) + 7 * j, args.layer_dim) for j in range(n)]
         work[0]['fg'] = MegaNeRF([c[0][0] for c in sub], cent, hp.boundary_margin, False, False).to(dev)
         work[0]['bg'] = MegaNeRF([c[1][0] for c in sub], cent, hp.boundary_margin, True, False).to(dev)
-        for k in ('fg', 'bg'):               # device-side tally of the rows the router hands to cells (a row near a boundary goes to two):
-            work[0][k].routed_rows = None    # switched on for ONE render behind the timed region (three small kernels per routed evaluation)
+        for k in ('fg', 'bg'):               # device-side tally of the rows the router hands to cells (a row near a boundary goes to two)
+            work[0][k].routed_rows = torch.zeros((), device=dev, dtype=torch.int64)
         work[0]['cells_np'] = dict(cent=cent.numpy(), fg=[c[0][2] for c in sub], bg=[c[1][2] for c in sub], fcfg=sub[0][0][1], bcfg=sub[0][1][1])
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
 
@@ -644,6 +637,8 @@ def run_config(args, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.container:
+        work[0]['fg'].routed_rows.zero_(), work[0]['bg'].routed_rows.zero_()
     ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -654,12 +649,8 @@ def run_config(args, rank, world, dev, dist):
         dist.barrier()
     dt = time.perf_counter() - t0
     rendering.KERNEL_EVENTS = None
-    if args.container:      # the router's device-side tally: the batch is fixed, so one more render of it counts what every timed one routed
-        for k in ('fg', 'bg'):
-            work[0][k].routed_rows = torch.zeros((), device=dev, dtype=torch.int64)
-        step()
-        routed_timed = (int(work[0]['fg'].routed_rows) * args.steps, int(work[0]['bg'].routed_rows) * args.steps)
-        work[0]['fg'].routed_rows = work[0]['bg'].routed_rows = None
+    if args.container:      # the router's device-side tally of the TIMED steps only (every later render of this function adds to it)
+        routed_timed = (int(work[0]['fg'].routed_rows), int(work[0]['bg'].routed_rows))
     if args.mode == 'eval' and not ev and not args.container:
         # the timed steps went through mnr_render_fwd (six launches, no Python between them): take the kernel-level timings of
         # the MLP launches -- the same kernel over the same rows -- from the stage-by-stage sequencing of the same render

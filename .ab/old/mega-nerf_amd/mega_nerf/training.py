@@ -1123,29 +1123,15 @@ class CellTrainer:
         loss = torch.nn.functional.mse_loss(results['rgb_' + typ], rgbs, reduction='mean')
         if self.hparams.use_cascade and typ != 'coarse':
             loss = (loss + torch.nn.functional.mse_loss(results['rgb_coarse'], rgbs, reduction='mean')) / 2
-        # What the reference checks every iteration (camera inside the sphere: rendering.py:412-414; finite loss: runner.py:260-261) and
-        # what gates the background optimiser (runner.py:268-272) are three scalars the FORWARD pass has produced.  They go to pinned host
-        # memory behind the forward; the backward pass is enqueued meanwhile, and the host waits for that copy only -- the GPU is then
-        # busy with the backward, so neither the check nor the optimisers' enqueue leaves it idle (two full synchronisations per step
-        # before: one mid-step, one in front of the optimisers).  Still BEFORE Adam can write a non-finite update into the weights.
-        dev = loss.device
-        zero = torch.zeros((), device=dev)
-        stats = torch.stack([err.max().float() if err is not None else zero, torch.isfinite(loss.detach()).float(),
-                             n_bg.reshape(-1)[0].float() if n_bg is not None else zero])
-        if getattr(self, '_host_stats', None) is None:
-            self._host_stats = torch.empty(3, dtype=torch.float32).pin_memory()
-            self._stats_ready = torch.cuda.Event()
-        self._host_stats.copy_(stats, non_blocking=True)
-        self._stats_ready.record()
-        loss.backward()
-        self._stats_ready.synchronize()
-        h_err, h_finite, h_nbg = (float(v) for v in self._host_stats)
-        if h_err != 0:
+        # this path synchronises anyway (n_bg below), so it checks what the reference checks every iteration (rendering.py:412-414,
+        # runner.py:260-261) BEFORE Adam can write a non-finite update into the weights
+        if err is not None and int(err.max().item()) != 0:
             from mega_nerf.rendering import _ERR_TEXT
             raise Exception(_ERR_TEXT)
-        if h_finite == 0:
+        if not math.isfinite(float(loss.detach())):
             raise Exception('Train metrics not finite: {}'.format({'loss': float(loss.detach())}))
-        bg_present = n_bg is not None and h_nbg > 0
+        loss.backward()
+        bg_present = n_bg is not None and int(n_bg.item()) > 0          # runner.py:268-272 (this path synchronises, like the reference)
         for key, o in self.optimizers.items():
             if key == 'bg_nerf' and not bg_present:
                 continue
