@@ -146,6 +146,12 @@ class MegaNeRF(nn.Module):
             cache[key] = ws
         return ws
 
+    def release_buffers(self) -> None:
+        """Drop the cached routing buffers and cell tables (n_sub x rows x 28 bytes + the cells' outputs per kept size: ~9 GB for a
+        25-cell container after 65 536-ray x 192-sample evaluations); the next evaluation re-allocates."""
+        self.__dict__.pop('_route_buffers', None)
+        self.__dict__.pop('_cell_tables', None)
+
     def _routed(self, pos: torch.Tensor, pos_stride: int, xyz: torch.Tensor, xyz_stride: int,
                 dirs: Optional[torch.Tensor], dir_stride: int, idx: Optional[torch.Tensor], idx_stride: int,
                 rows_per_ray: int, B: int, out: torch.Tensor, noise: Optional[torch.Tensor], sigma_only: bool, sh_deg: int,

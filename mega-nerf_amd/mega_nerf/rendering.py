@@ -397,9 +397,13 @@ _render_ws: Dict[tuple, torch.Tensor] = {}
 _render_side: Dict[tuple, C.c_void_p] = {}     # (device, stream) -> mnr_side handle (host object: stream + two events), created on first use
 
 
-def release_render_workspaces() -> None:
-    """Drop the cached scratch of the one-call render (~2.7 GB after 65 536-ray batches at 256 + 512 samples); the next render re-allocates."""
+def release_render_workspaces(*models) -> None:
+    """Drop the cached scratch of the one-call render (~2.7 GB after 65 536-ray batches at 256 + 512 samples) and, for merged containers
+    passed in, their routing buffers (``MegaNeRF.release_buffers``); the next render re-allocates."""
     _render_ws.clear()
+    for m in models:
+        if hasattr(m, 'release_buffers'):
+            m.release_buffers()
 
 
 
