@@ -20,7 +20,7 @@ file-based gather, runner.py:495-510).
     through its cells one after the other (``"scaling": "strong"``; --gpus 1 = one GPU trains all S).
 
 The line also carries: ``roofline`` (dominant kernel: live HIP-event duration of its launches, algorithmic FLOPs,
-MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r03_pmc_summary.json``), ``cpu_baseline`` (the
+MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r05_pmc_summary.json``), ``cpu_baseline`` (the
 torch-CPU restatement of the reference on this box's host cores, bounded sample), the north-star PSNR check
 (``psnr``: a student model trained for a few steps here and by the CPU restatement on identical batches and
 random numbers, both evaluated against a fixed teacher field), and (N = 1) short extra measurements: 65 536-ray

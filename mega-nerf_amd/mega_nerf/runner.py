@@ -152,12 +152,12 @@ class Runner:
                                        last_epoch=train_iterations - 1) for k, o in optimizers.items()}
         # One rank per submodule (the Mega-NeRF layout): the iteration is ONE native call (training.CellTrainer -> mnr_train_step)
         # whenever the configuration has a fused step, on the SAME optimiser / scheduler objects (their moment tensors become views
-        # of the step's buffers, so checkpoints keep the reference's `optimizers` entry); anything else, and ragged last batches,
-        # take the stage-by-stage autograd path inside the same trainer.  MNR_RUNNER_AUTOGRAD=1 keeps the reference-shaped loop below.
-        from mega_nerf.training import CellTrainer, GatheredBatch, fused_step_supported
+        # of the step's buffers, so checkpoints keep the reference's `optimizers` entry); anything else (512-wide cells, other sample
+        # counts, ragged last batches) takes the stage-by-stage autograd path inside the same trainer, whose per-iteration host checks
+        # ride behind the forward pass instead of idling the GPU twice per step.  MNR_RUNNER_AUTOGRAD=1 keeps the reference-shaped loop below.
+        from mega_nerf.training import CellTrainer, GatheredBatch
         trainer = None
-        if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD') and \
-                fused_step_supported(self.nerf, self.bg_nerf, hp, hp.batch_size):
+        if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD'):
             trainer = CellTrainer(self.nerf, self.bg_nerf, hp, self.sphere_center, self.sphere_radius, optimizers, schedulers,
                                   seed=int(hp.random_seed), iteration=train_iterations, plan_rays=int(hp.batch_size))
         self.trainer = trainer
