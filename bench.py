@@ -291,6 +291,165 @@ def cpu_baseline_container(hp, rays_np, idx_np, cells):
                       'x (%d+%d) samples of the same batch, one run after a 16-ray probe' % (len(cells['fg']), n, hp.coarse_samples, hp.fine_samples)}
 
 
+
+# ---- self-diagnosis: device calibration, clocks, timed regions -------------------------------------------------------
+
+def _hwmon_dir(dev):
+    """sysfs hwmon directory of the torch device (read-only probes: clocks, power, temperatures), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        hw = sorted(Path('/sys/bus/pci/devices/%s/hwmon' % bdf).glob('hwmon*'))
+        return hw[0] if hw else None
+    except Exception:
+        return None
+
+
+def read_clocks(hw):
+    """One sample of {sclk_mhz, mclk_mhz, power_w, temp_*_c} from the device's hwmon files (what rocm-smi prints), or {}."""
+    out = {}
+    if hw is None:
+        return out
+    try:
+        for f in hw.glob('*_input'):
+            stem = f.name[:-6]
+            try:
+                v = float(f.read_text())
+            except Exception:
+                continue
+            lab = hw / (stem + '_label')
+            name = lab.read_text().strip() if lab.exists() else stem
+            if stem.startswith('freq'):
+                out['%s_mhz' % name] = round(v / 1e6)
+            elif stem.startswith('power'):
+                out['power_w'] = round(v / 1e6)
+            elif stem.startswith('temp'):
+                out['temp_%s_c' % name] = round(v / 1e3)
+    except Exception:
+        pass
+    return out
+
+
+class ClockSampler:
+    """Samples the hwmon files every `period` seconds on a host thread while a timed region runs (under load the files show what the
+    chip actually holds; an idle read shows 95 MHz)."""
+
+    def __init__(self, dev, period=0.04):
+        import threading
+        self.hw, self.period, self.samples, self._stop = _hwmon_dir(dev), period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = read_clocks(self.hw)
+            if c:
+                self.samples.append(c)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.hw is not None:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.hw is not None:
+            self._t.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        out = {'n': len(self.samples)}
+        for k in self.samples[0]:
+            v = [s_[k] for s_ in self.samples if k in s_]
+            out[k] = {'min': min(v), 'mean': round(sum(v) / len(v), 1), 'max': max(v)}
+        return out
+
+
+def xcd_clocks_under_load(step, seconds=1.2):
+    """Per-XCD graphics clocks while the step keeps running (amd-smi on a host thread; the hwmon files give one sclk only): a chip whose
+    XCDs do not hold the same clock shows here.  None when amd-smi is missing."""
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which('amd-smi') is None:
+        return None
+    res = {}
+
+    def probe():
+        try:
+            res['txt'] = subprocess.run(['amd-smi', 'metric', '--clock', '--power', '--json'], capture_output=True, text=True, timeout=20).stdout
+        except Exception as e:
+            res['err'] = str(e)
+    th = threading.Thread(target=probe, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while th.is_alive() or time.perf_counter() - t0 < seconds:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 > 15:
+            break
+    th.join(timeout=20)
+    try:
+        d = json.loads(res['txt'])
+        g = d[0] if isinstance(d, list) else (d.get('gpu_data') or [d])[0]
+        clk = g.get('clock', {})
+        out = {'gfx_mhz': [clk[k]['clk']['value'] if isinstance(clk[k].get('clk'), dict) else clk[k].get('clk') for k in sorted(clk) if k.startswith('gfx_')],
+               'mem_mhz': [clk[k]['clk']['value'] if isinstance(clk[k].get('clk'), dict) else clk[k].get('clk') for k in sorted(clk) if k.startswith('mem_')]}
+        pw = g.get('power', {})
+        sp = pw.get('socket_power')
+        out['socket_power_w'] = sp.get('value') if isinstance(sp, dict) else sp
+        out['throttle_status'] = pw.get('throttle_status')
+        return out
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e), 'raw': (res.get('txt') or res.get('err') or '')[:200]}
+
+
+def calibrate(dev):
+    """mnr_calibrate: fp32-MFMA rate, L2 -> LDS weight-stream shape, dependent-load latencies, HBM streams, single-wavefront clock
+    (csrc/calibrate.hip).  ~30 ms; its 1 GiB scratch is released again."""
+    from mega_nerf import _native
+    try:
+        scr = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        _native.calibrate(dev, scr)                       # (first call: code load)
+        c = _native.calibrate(dev, scr)
+        del scr
+        return {k: v for k, v in c.items() if k not in ('cu_count', 'nominal_sclk_mhz', 'nominal_mclk_mhz', 'l2_bytes')}, {
+            k: c[k] for k in ('cu_count', 'nominal_sclk_mhz', 'nominal_mclk_mhz', 'l2_bytes')}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}, {}
+
+
+def rank_devices(dev, dist, world):
+    """What each rank runs on (answers "did RCCL see N ranks on N GPUs" from the record)."""
+    pr = torch.cuda.get_device_properties(dev)
+    me = {'rank': int(os.environ.get('RANK', 0)), 'device': dev.index, 'name': pr.name,
+          'pci': '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', 0), getattr(pr, 'pci_device_id', 0)),
+          'uuid': str(getattr(pr, 'uuid', '')), 'cus': pr.multi_processor_count}
+    if dist is None:
+        return {'world': 1, 'backend': None, 'ranks': [me]}
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    return {'world': world, 'backend': dist.get_backend(), 'ranks': got}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves, exactly the way the driver does
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
+
+
 # ---- main ------------------------------------------------------------------------------------------------------------
 
 def parse_args(argv=None):
@@ -322,6 +481,8 @@ def parse_args(argv=None):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -341,7 +502,8 @@ def main():
             dist.init_process_group('gloo')                       # (RCCL refuses two ranks on one device)
         else:
             dist.init_process_group('nccl', device_id=dev)        # RCCL on ROCm, communicator bound to this rank's GPU
-    assert args.gpus == world, '--gpus must equal WORLD_SIZE (launch with torch.distributed.run)'
+    if args.gpus != world:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d (start it as `python bench.py --gpus N` or under torch.distributed.run with N ranks)' % (args.gpus, world))
     line = run_config(args, rank, world, dev, dist)
     headline = (world == 1 and args.mode == 'train' and not args.submodules and not args.container and args.layer_dim == 256 and
                 args.sh_deg is None and args.samples == '64,128' and args.rays == 1024)
@@ -357,6 +519,8 @@ def main():
         line['runner_loop'] = runner_loop(args, dev, line['value'])
         line['baseline_configs']['_seconds'] = round(time.perf_counter() - t0, 1)
     if rank == 0:
+        if 'diag' in line:
+            line['diag'] = line.pop('diag')          # last key of the line: the driver's record keeps the tail
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -390,6 +554,7 @@ def config_sweep(args, dev):
     torch.set_num_threads(1)
     for name, flags, steps in SWEEP:
         a = parse_args(flags + ['--steps', str(steps), '--warmup', '3', '--no-cpu-baseline', '--no-extras', '--rays', str(args.rays), '--samples', args.samples])
+        a.no_diag = True                      # (no device calibration per side line; their three timed regions are reported)
         t0 = time.perf_counter()
         try:
             ln = run_config(a, 0, 1, dev, None)
@@ -402,6 +567,8 @@ def config_sweep(args, dev):
                 if k in ln:
                     out[name][k] = ln[k]
             out[name]['host_enqueue_ms_per_step'] = (ln.get('host') or {}).get('host_enqueue_ms_per_step')
+            out[name]['host_blocked_ms_per_step'] = (ln.get('host') or {}).get('host_blocked_ms_per_step')
+            out[name]['regions_ms_per_step'] = ((ln.get('diag') or {}).get('timing') or {}).get('regions_ms_per_step')
             if 'routed_rows_per_step' in r:
                 out[name]['routed_rows_per_step'] = r['routed_rows_per_step']
         except Exception as e:                      # a side line must never take the headline down
@@ -599,7 +766,7 @@ def run_config(args, rank, world, dev, dist):
         work[0]['cells_np'] = dict(cent=cent.numpy(), fg=[c[0][2] for c in sub], bg=[c[1][2] for c in sub], fcfg=sub[0][0][1], bcfg=sub[0][1][1])
         hp.container_path = 'bench'              # background points carry their world position for the router (quirk Q15)
 
-    steppers = []
+    steppers, trainers = [], []
     fused = None
     if args.mode == 'train' and not wide:
         # every cell this rank owns goes through ONE mnr_train_step call per step (csrc/step.hip): 12 kernel launches + a memset for the
@@ -619,6 +786,7 @@ def run_config(args, rank, world, dev, dist):
         if args.mode == 'train':
             w['fg'].train(), w['bg'].train()
             ts = TrainStep(w['fg'], w['bg'], hp, sc, sr)
+            trainers.append(ts)
             steppers.append(lambda ts=ts, b=w['batch']: ts(*b))
         else:
             w['fg'].eval(), w['bg'].eval()
@@ -636,24 +804,47 @@ def run_config(args, rank, world, dev, dist):
 
     for _ in range(args.warmup):
         step()
-    # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed region
+    torch.cuda.synchronize()
+    diagnose = rank == 0 and not getattr(args, 'no_diag', False)
+    cal_before, dev_info = calibrate(dev) if diagnose else (None, {})
+    # Clock-stabilised warm-up on top of the contract's `--warmup` steps: blocks of steps until two consecutive blocks agree to 1 % (cap
+    # 1 s).  A fresh process starts the timed region on a chip that idled at 95 MHz a few milliseconds earlier.
+    stab, t_stab0, blk = [], time.perf_counter(), max(2, min(10, args.steps))
+    while True:
+        t = time.perf_counter()
+        for _ in range(blk):
+            step()
+        torch.cuda.synchronize()
+        stab.append((time.perf_counter() - t) / blk * 1e3)
+        if (len(stab) >= 2 and abs(stab[-1] - stab[-2]) <= 0.01 * stab[-1]) or time.perf_counter() - t_stab0 > 1.0 or len(stab) >= 50:
+            break
+    # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed regions
+    REGIONS = 3
     rendering.KERNEL_EVENTS = ev = []
     if fused is not None:
-        fused.profile(args.steps)                # HIP events on the launch stream around every kernel group of the timed steps
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+        fused.profile(REGIONS * args.steps)      # HIP events on the launch stream around every kernel group of the timed steps
     ms0 = torch.cuda.memory_stats(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    t_enq = time.perf_counter() - t0               # host time to ENQUEUE the timed steps (diagnostic: host-bound when ~ total)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    wait0 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
+    region_s, enq_s = [], []
+    with ClockSampler(dev) as clocks:
+        for _r in range(REGIONS):
+            # EXACTLY `--steps` steps per region, a barrier + synchronize on both sides; three disjoint regions, `ms_per_step` = their median
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = step()
+            enq_s.append(time.perf_counter() - t0)     # host time to ENQUEUE the timed steps (diagnostic: host-bound when ~ total)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            region_s.append(time.perf_counter() - t0)
+    wait1 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
+    cal_after = calibrate(dev)[0] if diagnose else None
     rendering.KERNEL_EVENTS = None
+    xcd = xcd_clocks_under_load(step) if (diagnose and not args.no_extras) else None
     if args.container:      # the router's device-side tally: the batch is fixed, so one more render of it counts what every timed one routed
         for k in ('fg', 'bg'):
             work[0][k].routed_rows = torch.zeros((), device=dev, dtype=torch.int64)
@@ -668,22 +859,39 @@ def run_config(args, rank, world, dev, dist):
             step()
         torch.cuda.synchronize()
         rendering.FUSED_RENDER, rendering.KERNEL_EVENTS = True, None
-    span_ms = {}
+    span_ms, span_region = {}, []
     if fused is not None:
-        for i in range(args.steps):
+        for i in range(REGIONS * args.steps):
             for k, v in fused.kernel_times(i).items():
                 span_ms.setdefault(k, []).append(v)
+        for r_ in range(REGIONS):         # the MLP forward's two launches, region by region (does a slow region show in the kernel, or around it?)
+            sl = slice(r_ * args.steps, (r_ + 1) * args.steps)
+            span_region.append(round((sum(span_ms['fwd_c'][sl]) + sum(span_ms['fwd_f'][sl])) / (2 * args.steps), 4))
         fused.profile(0)
     ms1 = torch.cuda.memory_stats(dev)
-    host_diag = {'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
+    # max over ranks, region by region; the reported time is the MEDIAN region
+    tmax = torch.tensor(region_s, device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    region_s = [float(v) for v in tmax]
+    order = sorted(range(REGIONS), key=lambda i_: region_s[i_])
+    dt = region_s[order[REGIONS // 2]]
+    t_enq = enq_s[order[REGIONS // 2]]
+    timing = {'regions_ms_per_step': [round(v / args.steps * 1e3, 4) for v in region_s], 'min': round(min(region_s) / args.steps * 1e3, 4),
+              'median': round(dt / args.steps * 1e3, 4), 'max': round(max(region_s) / args.steps * 1e3, 4),
+              'spread': round((max(region_s) - min(region_s)) / dt, 4),
+              'stabilise_blocks_ms_per_step': [round(v, 4) for v in stab], 'stabilise_steps': blk * len(stab)}
+    if span_region:
+        timing['fwd_launch_ms_by_region'] = span_region
+    blocked = (wait1 - wait0) / (REGIONS * args.steps) * 1e3          # stage-by-stage trainer: the wait for the forward's three scalars
+    host_diag = {'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3 - blocked, 3),
                  'device_mallocs_in_timed_region': int(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)),
                  'alloc_retries_in_timed_region': int(ms1.get('num_alloc_retries', 0) - ms0.get('num_alloc_retries', 0)),
                  'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 1e9, 1)}
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    if blocked > 0:
+        host_diag['host_blocked_ms_per_step'] = round(blocked, 3)     # (not part of host_enqueue_ms_per_step)
     n_bg = int(out[1]) if out[1] is not None else -1          # background rays in the (last cell's) batch
+    rank_info = rank_devices(dev, dist, world)
 
     # eval metric all-reduce (packed [sum_psnr, count]) -- the only collective of the path.  The targets of the
     # throughput batches are random colours, so this number only exercises the reduction; the PSNR that means something is
@@ -1003,7 +1211,37 @@ def run_config(args, rank, world, dev, dist):
             mlp_ms = sum(line['step_spans_ms'][k] for k in ('fwd_c', 'fwd_f', 'bwd', 'wgrad'))
             line['step_spans_ms']['non_mlp_share_of_step'] = round(1.0 - mlp_ms / (dt / args.steps * 1e3), 4)
             line['host']['launches_per_step'] = 11 + 2 * len(work)      # memset + 10 kernels + (k_wgrad2 + reduce) per cell
+        # self-diagnosis: how the timed regions spread, what the box delivered right before / after them, what the clocks did meanwhile
+        diag = {'timing': timing}
+        if cal_before is not None:
+            diag['calibration'] = {'before': cal_before, 'after': cal_after, 'device': dev_info,
+                                   'nominal': {'mfma_f32_tflops': PEAK_F32_MFMA_TFLOPS, 'note': 'csrc/calibrate.hip; typical MI355X in this pool: mfma_f32_tflops ~145 '
+                                               '(1 ms probe incl. clock ramp), sclk_mhz_mfma_chain 2400, dma_chunk_round_trip_us ~0.49, chase_l2 / mall / hbm ns, hbm GB/s: see '
+                                               'profiles/r06_calibration_boxes.jsonl'}}
+        cl = clocks.summary()
+        if cl is not None:
+            diag['clocks_during_timed_regions'] = cl
+        if xcd is not None:
+            diag['xcd_clocks_under_load'] = xcd
+        diag['ranks'] = rank_info
+        line['diag'] = diag
+        if roof is not None:
+            # (the driver's record keeps `roofline` whole and only the tail of the rest of the line: the figures needed to tell a slow box
+            # from slow code ride inside it)
+            roof['timing'] = {k: timing[k] for k in ('regions_ms_per_step', 'min', 'median', 'max') if k in timing}
+            if 'fwd_launch_ms_by_region' in timing:
+                roof['timing']['fwd_launch_ms_by_region'] = timing['fwd_launch_ms_by_region']
+            if cal_before is not None:
+                keys = ('mfma_f32_tflops', 'sclk_mhz_mfma_chain', 'dma_stream_gbps', 'dma_chunk_round_trip_us', 'chase_l2_ns', 'chase_mall_ns', 'chase_hbm_ns',
+                        'hbm_read_gbps', 'hbm_write_gbps')
+                roof['box'] = {'before': {k: cal_before.get(k) for k in keys}, 'after': {k: (cal_after or {}).get(k) for k in keys}}
+                if cl is not None:
+                    roof['box']['sclk_mhz_during'] = next((v for k, v in cl.items() if k.startswith('sclk')), None)
+                    roof['box']['power_w_during'] = cl.get('power_w')
+            if span_ms:
+                roof['step_spans_ms'] = line['step_spans_ms']
         line.update(extras)
+        line['diag'] = line.pop('diag')          # last key of the line: the driver's record keeps the tail
         return line
     return None
 

@@ -689,6 +689,30 @@ int mnr_render_fwd(const mnr_render_io *io, void *stream);
 int mnr_step_profile(mnr_step_plan *plan, int n_slots);
 int mnr_step_kernel_times(mnr_step_plan *plan, int slot, float *ms_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device calibration (bench.py `calibration`; no reference counterpart: the reference has no kernels of its own).  What THIS GPU
+ * delivers, right now, on the resources the register-chained MLP kernels use -- so that a slow benchmark line can be told apart
+ * from a slow box.  The ONE entry point that synchronises the stream (it times its own launches).  scratch_dev: at least 64 MiB,
+ * mnr_calibrate_scratch_bytes() (1 GiB) for an HBM-resident pointer chase; contents are overwritten.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mnr_calibration {
+    int32_t cu_count;
+    float nominal_sclk_mhz, nominal_mclk_mhz;  /* hipDeviceProp */
+    int64_t l2_bytes;
+    float mfma_f32_tflops;                /* 512 workgroups x 4 wavefronts of v_mfma_f32_16x16x4_f32 (peak 157.3 at 2.4 GHz) */
+    float sclk_mhz_under_mfma_load;       /* ... = the clock the matrix pipes held with every CU busy */
+    float sclk_mhz_fma_chain;             /* ONE wavefront: dependent v_fma_f32 chain (4 cycles each) against the 100 MHz counter */
+    float sclk_mhz_mfma_chain;            /* ONE wavefront: dependent v_mfma_f32_32x32x2_f32 chain (64 cycles each) */
+    float dma_stream_gbps;                /* 512 workgroups streaming the same 2.4 MB image L2 -> LDS (global_load_lds_dwordx4, 32 KiB
+                                             chunks, two in flight): aggregate GB/s */
+    float dma_chunk_round_trip_us;        /* the same with ONE chunk in flight: request, vmcnt(0), barrier */
+    float dma_chunk_round_trip_alone_us;  /* ... with one workgroup on the chip */
+    float chase_l2_ns, chase_mall_ns, chase_hbm_ns;   /* dependent-load latency: 2 MiB / 64 MiB / whole-scratch line sets */
+    float hbm_read_gbps, hbm_write_gbps;  /* streaming, non-temporal, whole scratch */
+} mnr_calibration;
+size_t mnr_calibrate_scratch_bytes(void);
+int mnr_calibrate(mnr_calibration *out, void *scratch_dev, size_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

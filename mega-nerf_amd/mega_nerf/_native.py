@@ -183,6 +183,15 @@ class RenderIO(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('side', C.c_void_p)]
 
 
+class Calibration(C.Structure):
+    """struct mnr_calibration"""
+    _fields_ = [('cu_count', C.c_int32), ('nominal_sclk_mhz', C.c_float), ('nominal_mclk_mhz', C.c_float), ('l2_bytes', C.c_int64),
+                ('mfma_f32_tflops', C.c_float), ('sclk_mhz_under_mfma_load', C.c_float), ('sclk_mhz_fma_chain', C.c_float),
+                ('sclk_mhz_mfma_chain', C.c_float), ('dma_stream_gbps', C.c_float), ('dma_chunk_round_trip_us', C.c_float),
+                ('dma_chunk_round_trip_alone_us', C.c_float), ('chase_l2_ns', C.c_float), ('chase_mall_ns', C.c_float),
+                ('chase_hbm_ns', C.c_float), ('hbm_read_gbps', C.c_float), ('hbm_write_gbps', C.c_float)]
+
+
 EXPORTS = [
     'mnr_version', 'mnr_last_error', 'mnr_device_available', 'mnr_ray_directions', 'mnr_get_rays',
     'mnr_packed_model_bytes', 'mnr_pack_model', 'mnr_layout_src_col', 'mnr_layout_num_steps', 'mnr_layout_parts',
@@ -198,6 +207,7 @@ EXPORTS = [
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
     'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy', 'mnr_mlp_forward_cells_multi',
+    'mnr_calibrate', 'mnr_calibrate_scratch_bytes',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -332,6 +342,8 @@ def lib() -> C.CDLL:
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
         _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_double, C.c_int64, C.c_uint64, C.c_int,
                                         C.c_void_p]
+        _lib.mnr_calibrate_scratch_bytes.restype = C.c_size_t
+        _lib.mnr_calibrate.argtypes = [C.POINTER(Calibration), C.c_void_p, C.c_size_t, C.c_void_p]
     return _lib
 
 
@@ -376,3 +388,16 @@ def wgrad_workspace(dev):
     if ws is None:
         ws = _WGRAD_WS[key] = torch.empty(lib().mnr_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
     return ws
+
+
+def calibrate(dev, scratch: Optional[torch.Tensor] = None) -> dict:
+    """mnr_calibrate on the current stream of ``dev``: what this GPU delivers right now (fp32 MFMA rate, L2 -> LDS weight-stream shape,
+    dependent-load latencies, HBM streams, clocks).  Synchronises.  ``scratch``: a uint8 device tensor to reuse (>= 64 MiB)."""
+    dev = torch.device(dev)
+    if scratch is None:
+        scratch = torch.empty(lib().mnr_calibrate_scratch_bytes(), dtype=torch.uint8, device=dev)
+    require_device(scratch, 'scratch')
+    out = Calibration()
+    with torch.cuda.device(dev):
+        check(lib().mnr_calibrate(C.byref(out), scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream(dev).cuda_stream))
+    return {k: (round(getattr(out, k), 3) if isinstance(getattr(out, k), float) else int(getattr(out, k))) for k, _ in Calibration._fields_}

@@ -116,7 +116,7 @@ class MegaNeRF(nn.Module):
         # keyed by the STREAM as well: the upload is ordered on the stream that was current at first use, and a cache hit on another
         # stream (rendering._render_ws renders per (device, stream)) would launch against the table with nothing ordering it behind
         # that copy
-        key = (torch.cuda.current_stream(dev).cuda_stream,) + tuple(v for r in rows for v in r)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream) + tuple(v for r in rows for v in r)
         cache = self.__dict__.setdefault('_cell_tables', {})
         hit = cache.get(key)
         if hit is not None:
@@ -134,7 +134,9 @@ class MegaNeRF(nn.Module):
         pointers of the launch's cell table -- a table upload per evaluation.  One evaluation of a given size is in flight per container
         and stream (the next one's kernels are ordered behind the previous one's on that stream); at most four sizes are kept."""
         cache = self.__dict__.setdefault('_route_buffers', {})
-        key = (torch.cuda.current_stream(dev).cuda_stream, B, ncol)
+        # (the device is part of the key: the default stream's handle is 0 on every GPU, so after .to(other_device) a hit would hand
+        # back buffers of the old device)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, B, ncol)
         ws = cache.get(key)
         if ws is None:
             n_sub = len(self.sub_modules)

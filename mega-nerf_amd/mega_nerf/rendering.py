@@ -402,8 +402,9 @@ def release_render_workspaces(*models) -> None:
     passed in, their routing buffers (``MegaNeRF.release_buffers``); the next render re-allocates."""
     _render_ws.clear()
     for m in models:
-        if hasattr(m, 'release_buffers'):
-            m.release_buffers()
+        for sub in (m.modules() if isinstance(m, torch.nn.Module) else ()):       # (a Cascade may hold containers)
+            if hasattr(sub, 'release_buffers'):
+                sub.release_buffers()
 
 
 

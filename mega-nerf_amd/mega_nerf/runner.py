@@ -196,6 +196,10 @@ class Runner:
             # the one-call step gathers its batch itself from the resident arrays (training.GatheredBatch): the loop then enqueues NO torch
             # kernel per iteration; every other path gets materialised batches
             source = dataset.gather_source() if trainer is not None else None
+            if trainer is not None and trainer.fused is None:
+                # a cell whose usable pixels are fewer than --batch_size (small / cluster-masked cells, test datasets) takes every batch at
+                # that smaller size: plan the one-call step for it instead of never fusing
+                trainer.plan_rays = min(int(hp.batch_size), len(dataset))
             # the epoch as row selections: a rank materialises (gathers) only the batches it trains on
             for dataset_index, item in enumerate(dataset.index_batches(hp.batch_size, gen)):
                 if dataset_index < discard or dataset_index >= usable or dataset_index % world != rank:
@@ -210,7 +214,10 @@ class Runner:
                         if not math.isfinite(loss):
                             raise Exception('Train metrics not finite: {}'.format({'loss': loss}))
                         if self.is_master:
-                            main_print('iter {}: psnr {:.3f} loss {:.5f}'.format(train_iterations, -10 * math.log10(max(loss, 1e-30)), loss))
+                            # PSNR of rgb_fine as the reference logs it (runner.py:252-256); under --use_cascade the loss is the mean of the
+                            # fine and the coarse MSE, so it comes from the trainer's own fine-pass MSE, not from the loss
+                            mse = float(getattr(trainer, 'last_mse', loss_dev))
+                            main_print('iter {}: psnr {:.3f} loss {:.5f}'.format(train_iterations, -10 * math.log10(max(mse, 1e-30)), loss))
                     if self.is_master and train_iterations % hp.ckpt_interval == 0:
                         trainer.sync()
                         self._save_checkpoint(optimizers, None, train_iterations, dataset_index,
@@ -343,6 +350,10 @@ class Runner:
             self.nerf.train(was_training)
             if self.bg_nerf is not None:
                 self.bg_nerf.train(bg_was)
+        # validation renders 65 536-ray chunks: the one-call render's scratch (~2.7 GB) and, for containers / --train_mega_nerf, the routing
+        # buffers of both models (n_sub x rows x 28 bytes + the cells' outputs per kept size: GBs) must not stay pinned while training resumes
+        from mega_nerf.rendering import release_render_workspaces
+        release_render_workspaces(self.nerf, self.bg_nerf)
         sums.setdefault('val/psnr', 0.0)
         sums.setdefault('val/ssim', 0.0)
         total, _ = mdist.all_reduce_metrics(dict(sums), count, self.device)

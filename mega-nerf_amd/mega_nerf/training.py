@@ -26,6 +26,8 @@ import ctypes as C
 from argparse import Namespace
 from typing import NamedTuple, Dict, Optional
 
+import time
+
 import torch
 from torch import nn
 
@@ -1100,6 +1102,7 @@ class CellTrainer:
         assert all(v == lrs[0] for v in lrs), 'foreground and background optimisers on different learning rates'
         self.fused.step_count = self.iteration - 1
         loss, n_bg, err = self.fused([batch], lr=lrs[0])
+        self.last_mse = loss[0]
         self._steps_stale = True
         for s in self.schedulers.values():
             s.step()
@@ -1121,6 +1124,7 @@ class CellTrainer:
                                                False, True, False)
         typ = 'fine' if 'rgb_fine' in results else 'coarse'
         loss = torch.nn.functional.mse_loss(results['rgb_' + typ], rgbs, reduction='mean')
+        self.last_mse = loss.detach()          # MSE of rgb_{fine|coarse} alone: what the reference's logged PSNR is made of (runner.py:252-256)
         if self.hparams.use_cascade and typ != 'coarse':
             loss = (loss + torch.nn.functional.mse_loss(results['rgb_coarse'], rgbs, reduction='mean')) / 2
         # What the reference checks every iteration (camera inside the sphere: rendering.py:412-414; finite loss: runner.py:260-261) and
@@ -1138,7 +1142,9 @@ class CellTrainer:
         self._host_stats.copy_(stats, non_blocking=True)
         self._stats_ready.record()
         loss.backward()
+        t_wait = time.perf_counter()
         self._stats_ready.synchronize()
+        self.host_wait_s = getattr(self, 'host_wait_s', 0.0) + (time.perf_counter() - t_wait)       # (blocked, not enqueuing: bench.py's host figure excludes it)
         h_err, h_finite, h_nbg = (float(v) for v in self._host_stats)
         if h_err != 0:
             from mega_nerf.rendering import _ERR_TEXT

@@ -34,6 +34,24 @@ def test_two_ranks_step_the_fixed_eight_cell_set():
     assert line['host']['launches_per_step'] == 11 + 2 * 4            # each rank: its four cells in one fused call
 
 
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command): bench.py starts the two ranks itself
+    (torch.distributed.run on 127.0.0.1) and the line says which ranks ran where."""
+    env = dict(os.environ, MNR_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras'],
+                       cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['steps'] == 3
+    ranks = line['diag']['ranks']
+    assert ranks['world'] == 2 and ranks['backend'] == 'gloo' and sorted(r_['rank'] for r_ in ranks['ranks']) == [0, 1]
+    assert all(r_['cus'] > 0 and r_['pci'] for r_ in ranks['ranks'])
+    t = line['diag']['timing']
+    assert len(t['regions_ms_per_step']) == 3 and t['min'] <= t['median'] <= t['max'] and abs(t['median'] - line['ms_per_step']) < 1e-3
+
+
 _RCCL_ONE_RANK = """
 import os, torch, torch.distributed as dist
 dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
@@ -89,6 +107,18 @@ def test_default_line_carries_every_baseline_config():
     for key in ('kernel',):
         assert len(line['roofline'][key]) <= 120, line['roofline'][key]
     assert len(line['config']['workload']) <= 120
+    # self-diagnosis: three timed regions, the box's calibration before and after them -- inside `roofline` (which the driver's record keeps
+    # whole) and, in full, as the LAST key of the line
+    assert list(line)[-1] == 'diag'
+    t = line['diag']['timing']
+    assert len(t['regions_ms_per_step']) == 3 and t['min'] <= t['median'] <= t['max'] and abs(t['median'] - line['ms_per_step']) < 1e-3
+    assert line['roofline']['timing']['median'] == t['median']
+    for when in ('before', 'after'):
+        c = line['diag']['calibration'][when]
+        assert 'error' not in c, c
+        assert 100 < c['mfma_f32_tflops'] < 160 and 1500 < c['sclk_mhz_mfma_chain'] < 2600, c
+        assert 0 < c['chase_l2_ns'] <= c['chase_hbm_ns'] * 1.2 and c['hbm_read_gbps'] > 1000 and c['dma_stream_gbps'] > 1000, c
+        assert line['roofline']['box'][when]['mfma_f32_tflops'] == c['mfma_f32_tflops']
     rl = line['runner_loop']
     assert 'error' not in rl, rl
     assert rl['one_call_step'] is True and rl['fraction_of_value'] > 0.9, rl
