@@ -92,7 +92,7 @@ PSNR_STEPS, PSNR_BATCH, PSNR_TEST_RAYS = 24, 192, 512
 def _port_over_reference():
     """Speed of oracle/torch_oracle.py relative to the real reference, as measured by tools/cpu_port_vs_reference.py."""
     try:
-        d = json.loads((ROOT / 'profiles' / 'r05_cpu_port_vs_reference.json').read_text())
+        d = json.loads((ROOT / 'profiles' / 'r06_cpu_port_vs_reference.json').read_text())
         return {m: '%.2fx / %.2fx' % (d['threads_8'][m]['port_over_reference'], d['threads_16'][m]['port_over_reference']) for m in ('train', 'eval')}
     except Exception:
         return {}
@@ -251,7 +251,7 @@ def cpu_baseline(hp, rays_np, idx_np, tgt_np, fw, bw, fcfg, bcfg, n_sample, mode
            'sample': 'torch-CPU port of the reference %s, first %d rays of the batch, %d threads' % ('train step' if mode == 'train' else 'eval render', n, cores),
            'sample_detail': 'torch-CPU restatement of the reference (%s), first %d rays x (%d+%d) samples of the same batch, '
                      '%d threads, best of 2 after a 32-ray warm-up; the port runs at %s the speed of the REAL reference on this workload '
-                     '(8 / 16 threads, build container: profiles/r05_cpu_port_vs_reference.json)' % (
+                     '(8 / 16 threads, build container: profiles/r06_cpu_port_vs_reference.json)' % (
                          'fwd+bwd+2xAdam step' if mode == 'train' else 'render_rays fwd, eval flags', n, hp.coarse_samples, hp.fine_samples, cores,
                          PORT_OVER_REFERENCE.get(mode, '?'))}
     if psnr_job is not None:

@@ -638,6 +638,10 @@ typedef struct mnr_step_batch {      /* one cell's batch: device pointers, read 
     const int64_t *select;           /* [n_rays] row numbers, or NULL */
     const uint8_t *target_u8;        /* instead of `target`: uint8 colours [rows][3] (dataset_utils.py:30 keeps them as bytes) ... */
     const float *u8_table;           /* ... converted through this DEVICE table of 256 floats (the CPU's i / 255. values) */
+    /* Which random streams the cell draws from: 0 = keyed by its position in the plan (seed + position); k > 0 = seed + (k - 1).  A cell
+     * trained in a plan of its own (position 0) and the same cell trained side by side with a rank's other cells then see the same
+     * numbers (tools/train_cells.py; the reference seeds every per-cell process alike, parscripts/run_8.txt + opts.py:101). */
+    int64_t rng_cell_plus1;
 } mnr_step_batch;
 typedef struct mnr_step_randoms {    /* optional injected uniforms of one cell (parity tests); NULL members are generated */
     const float *fg_perturb, *bg_perturb;            /* [n_rays][coarse], [n_bg][coarse / 2] */
@@ -701,17 +705,28 @@ typedef struct mnr_calibration {
     int64_t l2_bytes;
     float mfma_f32_tflops;                /* 512 workgroups x 4 wavefronts of v_mfma_f32_16x16x4_f32 (peak 157.3 at 2.4 GHz) */
     float sclk_mhz_under_mfma_load;       /* ... = the clock the matrix pipes held with every CU busy */
+    /* the same launch, workgroup by workgroup (wall_clock64 at both ends of each): a CU or an XCD that runs behind the others delays every
+     * launch whose workgroups are dealt statically -- the register-chained MLP kernels at 1024-ray sizes -- and none of the persistent,
+     * work-stealing ones (k_wgrad2, k_tgemm) */
+    float mfma_wg_ms_min, mfma_wg_ms_median, mfma_wg_ms_max;
+    float mfma_xcd_ms_fastest, mfma_xcd_ms_slowest;   /* mean workgroup duration of the fastest / slowest XCD */
+    int32_t mfma_slowest_wg_where;        /* (xcc_id << 16) | (HW_ID & 0xffff) of the slowest workgroup */
+    float mfma_start_skew_us;             /* last workgroup start - first workgroup start */
     float sclk_mhz_fma_chain;             /* ONE wavefront: dependent v_fma_f32 chain (4 cycles each) against the 100 MHz counter */
     float sclk_mhz_mfma_chain;            /* ONE wavefront: dependent v_mfma_f32_32x32x2_f32 chain (64 cycles each) */
     float dma_stream_gbps;                /* 512 workgroups streaming the same 2.4 MB image L2 -> LDS (global_load_lds_dwordx4, 32 KiB
                                              chunks, two in flight): aggregate GB/s */
     float dma_chunk_round_trip_us;        /* the same with ONE chunk in flight: request, vmcnt(0), barrier */
     float dma_chunk_round_trip_alone_us;  /* ... with one workgroup on the chip */
-    float chase_l2_ns, chase_mall_ns, chase_hbm_ns;   /* dependent-load latency: 2 MiB / 64 MiB / whole-scratch line sets */
+    float chase_l1_ns, chase_l2_ns, chase_mall_ns, chase_hbm_ns;   /* dependent-load latency: 8 KiB / 256 KiB / 64 MiB / half-scratch line sets */
     float hbm_read_gbps, hbm_write_gbps;  /* streaming, non-temporal, whole scratch */
 } mnr_calibration;
 size_t mnr_calibrate_scratch_bytes(void);
 int mnr_calibrate(mnr_calibration *out, void *scratch_dev, size_t scratch_bytes, void *stream);
+/* A memory hog for contention experiments (enqueue only, like every other entry point): `workgroups` workgroups stream-write, then
+ * stream-read `bytes` of scratch, `passes` times.  Launched on a side stream next to a training step it shows which kernels lose most
+ * when HBM / fabric latency rises (tools/probe_contention.py). */
+int mnr_calibrate_hog(void *scratch_dev, size_t bytes, int workgroups, int passes, void *stream);
 
 #ifdef __cplusplus
 }

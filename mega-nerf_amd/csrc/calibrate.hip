@@ -10,6 +10,9 @@
 //     MFMA probe, the clock the matrix pipes actually hold with every CU busy.
 // Diagnostics only: no kernel of the hot path calls anything here.  UNLIKE every other entry point mnr_calibrate synchronises (it
 // times its own launches with HIP events).
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace mnr {
@@ -24,7 +27,8 @@ constexpr int CAL_WGS = 512, CAL_NT = 256;
 constexpr int CHUNK_BYTES = 32768, IMAGE_CHUNKS = 75;            // 2.4 MB: one 8 x 256 model's packed weight image
 
 // ---- fp32 MFMA, chip full -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CAL_NT, 2) void k_cal_mfma(float *out, int iters) {
+__global__ __launch_bounds__(CAL_NT, 2) void k_cal_mfma(float *out, int iters, unsigned long long *wg_ticks, unsigned *wg_where) {
+    const unsigned long long t_begin = wall_clock64();
     floatx4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -38,6 +42,13 @@ __global__ __launch_bounds__(CAL_NT, 2) void k_cal_mfma(float *out, int iters) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678f) out[blockIdx.x * CAL_NT + threadIdx.x] = s;       // (never true: keeps the chain alive)
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_ticks) {
+        wg_ticks[2 * blockIdx.x] = t_begin;
+        wg_ticks[2 * blockIdx.x + 1] = wall_clock64();
+        // HW_REG_XCC_ID (20) and HW_REG_HW_ID (4), all 32 bits: which XCD / shader engine / CU the workgroup ran on
+        wg_where[blockIdx.x] = ((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | ((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu);
+    }
 }
 
 // ---- the weight stream: every workgroup streams the same image global -> LDS -------------------------------------------------------
@@ -145,7 +156,28 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 
 using namespace mnr;
 
+__global__ __launch_bounds__(256) void k_cal_hog(floatx4 *buf, size_t n4, int passes, float *out) {
+    float s = 0.f;
+    for (int p = 0; p < passes; ++p) {
+        const floatx4 v = floatx4{1.f + p, 2.f, 3.f, 4.f};
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, &buf[i]);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const floatx4 r = __builtin_nontemporal_load(&buf[i]);
+            s += r[0] + r[3];
+        }
+    }
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 extern "C" size_t mnr_calibrate_scratch_bytes(void) { return (size_t)1 << 30; }
+
+extern "C" int mnr_calibrate_hog(void *scratch_dev, size_t bytes, int workgroups, int passes, void *stream) {
+    MNR_REQUIRE(scratch_dev && bytes >= (1 << 20) && workgroups >= 1 && workgroups <= 4096 && passes >= 1, "bad arguments to mnr_calibrate_hog");
+    char *base = static_cast<char *>(scratch_dev);
+    hipLaunchKernelGGL(k_cal_hog, dim3(workgroups), dim3(256), 0, as_stream(stream), reinterpret_cast<floatx4 *>(base + (1 << 20)), (bytes - (1 << 20)) / 16,
+                       passes, reinterpret_cast<float *>(base));
+    return check_launch("k_cal_hog");
+}
 
 extern "C" int mnr_calibrate(mnr_calibration *out, void *scratch_dev, size_t scratch_bytes, void *stream) {
     MNR_REQUIRE(out && scratch_dev, "NULL argument to mnr_calibrate");
@@ -184,7 +216,39 @@ extern "C" int mnr_calibrate(mnr_calibration *out, void *scratch_dev, size_t scr
     // fp32 MFMA, chip full
     {
         const int iters = 1024;
-        const float ms = timed([&] { hipLaunchKernelGGL(k_cal_mfma, dim3(CAL_WGS), dim3(CAL_NT), 0, s, sink, iters); }, 2);
+        unsigned long long *wg_ticks = ticks + 64;                                  // [CAL_WGS][2]
+        unsigned *wg_where = reinterpret_cast<unsigned *>(wg_ticks + 2 * CAL_WGS);    // [CAL_WGS]
+        const float ms = timed([&] { hipLaunchKernelGGL(k_cal_mfma, dim3(CAL_WGS), dim3(CAL_NT), 0, s, sink, iters, wg_ticks, wg_where); }, 2);
+        {
+            std::vector<unsigned long long> ht(2 * CAL_WGS);
+            std::vector<unsigned> hw(CAL_WGS);
+            if (hipMemcpyAsync(ht.data(), wg_ticks, ht.size() * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                hipMemcpyAsync(hw.data(), wg_where, hw.size() * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+                std::vector<double> d(CAL_WGS);
+                unsigned long long t0 = ~0ull, t1 = 0;
+                double xs[64] = {0}; int xn[64] = {0};
+                int worst = 0;
+                for (int i = 0; i < CAL_WGS; ++i) {
+                    d[i] = (double)(ht[2 * i + 1] - ht[2 * i]) * tick_ns * 1e-6;
+                    t0 = ht[2 * i] < t0 ? ht[2 * i] : t0;
+                    t1 = ht[2 * i] > t1 ? ht[2 * i] : t1;
+                    const int x = (int)((hw[i] >> 16) & 63);
+                    xs[x] += d[i]; xn[x]++;
+                    if (d[i] > d[worst]) worst = i;
+                }
+                out->mfma_slowest_wg_where = (int32_t)hw[worst];
+                std::vector<double> sd(d);
+                std::sort(sd.begin(), sd.end());
+                out->mfma_wg_ms_min = (float)sd.front(); out->mfma_wg_ms_median = (float)sd[CAL_WGS / 2]; out->mfma_wg_ms_max = (float)sd.back();
+                double lo = 1e30, hi = 0;
+                for (int x = 0; x < 64; ++x)
+                    if (xn[x]) { const double m = xs[x] / xn[x]; lo = m < lo ? m : lo; hi = m > hi ? m : hi; }
+                out->mfma_xcd_ms_fastest = (float)lo; out->mfma_xcd_ms_slowest = (float)hi;
+                out->mfma_start_skew_us = (float)((double)(t1 - t0) * tick_ns * 1e-3);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         const double flop = (double)CAL_WGS * 4 * iters * 16 * 2048.0;
         out->mfma_f32_tflops = (float)(flop / (ms * 1e-3) / 1e12);
         // 64 FLOP per clock per SIMD: the clock the matrix pipes held while every CU was busy
@@ -206,12 +270,12 @@ extern "C" int mnr_calibrate(mnr_calibration *out, void *scratch_dev, size_t scr
     }
     // dependent-load latency: 2 MiB (L2), 64 MiB (MALL), the whole scratch (HBM)
     {
-        struct { unsigned lines; unsigned warm; float *dst; } sets[3] = {
-            {1u << 12, 1u << 12, &out->chase_l2_ns}, {1u << 19, 0, &out->chase_mall_ns}, {0, 0, &out->chase_hbm_ns}};
+        struct { unsigned lines; unsigned warm; float *dst; } sets[4] = {
+            {1u << 6, 1u << 6, &out->chase_l1_ns}, {1u << 11, 1u << 11, &out->chase_l2_ns}, {1u << 19, 0, &out->chase_mall_ns}, {0, 0, &out->chase_hbm_ns}};
         // HBM set: half of the scratch; the other half is streamed over afterwards so that the memory-side cache holds none of it
         unsigned hb = 1u << 19;
         while ((size_t)hb * 2 * 128 <= big_bytes / 2 && hb < (1u << 24)) hb *= 2;
-        sets[2].lines = hb;
+        sets[3].lines = hb;
         for (auto &st : sets) {
             if ((size_t)st.lines * 128 > big_bytes) continue;
             hipLaunchKernelGGL(k_cal_chase_init, dim3((st.lines + 255) / 256), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(big), st.lines);

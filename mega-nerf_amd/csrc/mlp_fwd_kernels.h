@@ -452,9 +452,6 @@ struct MlpFwdMulti {
     const MlpCellSeg *split_dcells;    // its cell table (one cell), or NULL
     long split_fixed;                  // the row count when neither holds a device-side count
     int32_t nseg;
-    // experiment (MNR_FWD_STAGGER): the workgroups of a launch's first resident set that share a CU with an earlier one start `stagger`
-    // sleeps late, so that the two residents of a CU do not hit their chunk barriers and layer boundaries at the same instant
-    int32_t stagger, stagger_mode;
 };
 }  // namespace mnr
 #include "mlp_fwd_split.h"
@@ -466,9 +463,6 @@ constexpr bool split_capable() { return C::TILE == 16 && C::HAS_FINAL && C::NOB 
 template <class CA, class CB, bool TRAIN, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_mlp_fwd_multi(MlpFwdMulti m) {
     const int blk = blockIdx.x;
-    if (m.stagger > 0 && blockIdx.y == 0 && blk < 512 && (m.stagger_mode ? (blk & 1) : ((blk >> 8) & 1))) {
-        for (int i = 0; i < m.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int s = (blk >= m.wg0[1]) + (blk >= m.wg0[2]) + (blk >= m.wg0[3]);
     if (m.is_b[s]) {
         if constexpr (split_capable<CB>() && NW == 4) {

@@ -85,8 +85,6 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;
     mm.nseg = n_segs;
-    if (const char *e = getenv("MNR_FWD_STAGGER")) mm.stagger = atoi(e);
-    if (const char *e = getenv("MNR_FWD_STAGGER_MODE")) mm.stagger_mode = atoi(e);
     if (wg == 0) return MNR_OK;
     const unsigned ny = cells ? (unsigned)n_cells_of(segs[0], cells[0]) : 1u;
     constexpr size_t LDS = fwd_lds_bytes<CfgFG, NW>() > fwd_lds_bytes<CfgBG, NW>() ? fwd_lds_bytes<CfgFG, NW>() : fwd_lds_bytes<CfgBG, NW>();

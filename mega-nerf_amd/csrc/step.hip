@@ -274,6 +274,7 @@ struct SamplesArgs {
     float perturb;
     int noise, has_inj;
     unsigned seed_lo, seed_hi, step_lo, step_hi;
+    unsigned long long cell_key[MAXC];       // added to the seed: the cell's position in the plan, or mnr_step_batch::rng_cell_plus1 - 1
     SSphere sp;
     const float *rays, *far, *rays_bg, *t_c, *t_bc;
     const int32_t *scal;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void k_step_samples(SamplesArgs a) {
         const long cell = t / per_cell, local = t - cell * per_cell;
         const float *p = a.has_inj ? a.inj[cell].*member : nullptr;
         if (!p) {
-            const unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + (unsigned long long)cell;
+            const unsigned long long sd = (((unsigned long long)a.seed_hi << 32) | a.seed_lo) + a.cell_key[cell];
             return u01(philox4x32(make_uint4((unsigned)local, (unsigned)((unsigned long long)local >> 32), stream, a.step_lo),
                                   make_uint2((unsigned)sd, (unsigned)(sd >> 32) ^ a.step_hi)).x);
         }
@@ -1174,6 +1175,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         if (randoms) { for (int c = 0; c < C; ++c) a.inj[c] = randoms[c]; a.has_inj = 1; }
         a.C = D.C; a.N = D.N; a.Nc = (int)D.Nc; a.Nf = (int)D.Nf; a.Sb = (int)D.Sb; a.Sfb = (int)D.Sfb;
         a.perturb = p->cfg.perturb; a.noise = noise ? 1 : 0;
+        for (int c = 0; c < C; ++c) a.cell_key[c] = batches[c].rng_cell_plus1 > 0 ? (unsigned long long)(batches[c].rng_cell_plus1 - 1) : (unsigned long long)c;
         a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step_lo = (unsigned)adam_step; a.step_hi = (unsigned)((uint64_t)adam_step >> 32);
         a.sp = p->sp;
         a.rays = F(L.rays); a.far = F(L.far); a.rays_bg = F(L.rays_bg); a.t_c = F(L.t_c); a.t_bc = F(L.t_bc); a.scal = scal;

@@ -162,7 +162,7 @@ class StepLayout(C.Structure):
 class StepBatch(C.Structure):
     """struct mnr_step_batch"""
     _fields_ = [('rays', C.c_void_p), ('idx', C.c_void_p), ('idx_is_float', C.c_int32), ('target', C.c_void_p),
-                ('select', C.c_void_p), ('target_u8', C.c_void_p), ('u8_table', C.c_void_p)]
+                ('select', C.c_void_p), ('target_u8', C.c_void_p), ('u8_table', C.c_void_p), ('rng_cell_plus1', C.c_int64)]
 
 
 class StepRandoms(C.Structure):
@@ -186,9 +186,11 @@ class RenderIO(C.Structure):
 class Calibration(C.Structure):
     """struct mnr_calibration"""
     _fields_ = [('cu_count', C.c_int32), ('nominal_sclk_mhz', C.c_float), ('nominal_mclk_mhz', C.c_float), ('l2_bytes', C.c_int64),
-                ('mfma_f32_tflops', C.c_float), ('sclk_mhz_under_mfma_load', C.c_float), ('sclk_mhz_fma_chain', C.c_float),
+                ('mfma_f32_tflops', C.c_float), ('sclk_mhz_under_mfma_load', C.c_float), ('mfma_wg_ms_min', C.c_float), ('mfma_wg_ms_median', C.c_float),
+                ('mfma_wg_ms_max', C.c_float), ('mfma_xcd_ms_fastest', C.c_float), ('mfma_xcd_ms_slowest', C.c_float), ('mfma_slowest_wg_where', C.c_int32),
+                ('mfma_start_skew_us', C.c_float), ('sclk_mhz_fma_chain', C.c_float),
                 ('sclk_mhz_mfma_chain', C.c_float), ('dma_stream_gbps', C.c_float), ('dma_chunk_round_trip_us', C.c_float),
-                ('dma_chunk_round_trip_alone_us', C.c_float), ('chase_l2_ns', C.c_float), ('chase_mall_ns', C.c_float),
+                ('dma_chunk_round_trip_alone_us', C.c_float), ('chase_l1_ns', C.c_float), ('chase_l2_ns', C.c_float), ('chase_mall_ns', C.c_float),
                 ('chase_hbm_ns', C.c_float), ('hbm_read_gbps', C.c_float), ('hbm_write_gbps', C.c_float)]
 
 
@@ -207,7 +209,7 @@ EXPORTS = [
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
     'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy', 'mnr_mlp_forward_cells_multi',
-    'mnr_calibrate', 'mnr_calibrate_scratch_bytes',
+    'mnr_calibrate', 'mnr_calibrate_scratch_bytes', 'mnr_calibrate_hog',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -344,6 +346,7 @@ def lib() -> C.CDLL:
                                         C.c_void_p]
         _lib.mnr_calibrate_scratch_bytes.restype = C.c_size_t
         _lib.mnr_calibrate.argtypes = [C.POINTER(Calibration), C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.mnr_calibrate_hog.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
 

@@ -158,8 +158,10 @@ class Runner:
         from mega_nerf.training import CellTrainer, GatheredBatch
         trainer = None
         if world == 1 and hp.appearance_dim > 0 and not os.environ.get('MNR_RUNNER_AUTOGRAD'):
-            trainer = CellTrainer(self.nerf, self.bg_nerf, hp, self.sphere_center, self.sphere_radius, optimizers, schedulers,
-                                  seed=int(hp.random_seed), iteration=train_iterations, plan_rays=int(hp.batch_size))
+            # (trainer_factory: tools/train_cells.py hands the cells of one rank members of a training.JointCells group -- one plan for all)
+            make = getattr(self, 'trainer_factory', None) or CellTrainer
+            trainer = make(self.nerf, self.bg_nerf, hp, self.sphere_center, self.sphere_radius, optimizers, schedulers,
+                           seed=int(hp.random_seed), iteration=train_iterations, plan_rays=int(hp.batch_size))
         self.trainer = trainer
         check_every = max(1, min(hp.ckpt_interval, 100))      # fused path: loss finiteness / sphere errors are checked at this interval
         filesystem = hp.dataset_type == 'filesystem'

@@ -768,9 +768,13 @@ class FusedTrainStep:
 
     def __init__(self, cells, hparams: Namespace, sphere_center, sphere_radius, n_rays: int, lr: float = 5e-4,
                  lr_decay_factor: float = 0.1, train_iterations: int = 500000, seed: Optional[int] = None, split_precision: bool = False,
-                 state=None):
+                 state=None, rng_cells: Optional[list] = None):
         lib = N.lib()
         self.cells = [(f, b) for f, b in cells]
+        # random streams of cell i: keyed seed + rng_cells[i] instead of seed + i (mnr_step_batch::rng_cell_plus1) -- JointCells passes
+        # zeros, so that every cell of a shared plan draws what it would draw in a plan of its own
+        self.rng_cells = None if rng_cells is None else [int(v) for v in rng_cells]
+        assert self.rng_cells is None or len(self.rng_cells) == len(self.cells)
         assert 1 <= len(self.cells) <= N.MNR_STEP_MAX_CELLS
         f0, b0 = self.cells[0]
         dev = next(f0.parameters()).device
@@ -952,6 +956,8 @@ class FusedTrainStep:
         arr = (N.StepBatch * nc)()
         keep = []
         for i, batch in enumerate(batches):
+            if self.rng_cells is not None:
+                arr[i].rng_cell_plus1 = self.rng_cells[i] + 1
             if isinstance(batch, GatheredBatch):
                 N.require_device(batch.rays, 'rays')
                 ok = (batch.rays.dtype == torch.float32 and batch.rays.is_contiguous() and batch.rays.shape[1:] == (8,) and
@@ -1036,6 +1042,7 @@ class CellTrainer:
         for o in optimizers.values():
             o._opt_called = True             # (ExponentialLR warns when its first step() precedes optimizer.step(): the fused step IS that step)
         self.fused: Optional[FusedTrainStep] = None
+        self.cell = 0                        # this trainer's cell inside `fused` (a rank's cells may share ONE plan: JointCells)
         self.iteration = iteration           # keys the fused step's random streams: continues across a resume
         self._steps_stale = False            # torch's per-parameter `step` tensors lag behind the device counters
 
@@ -1048,12 +1055,18 @@ class CellTrainer:
         self.fused = FusedTrainStep([(self.nerf, self.bg_nerf)], self.hparams, self.sc, self.sr, n_rays, lr, seed=self._seed,
                                     split_precision=self._split)
         self.fused.step_count = self.iteration
+        self._adopt_into_plan()
+
+    def _adopt_into_plan(self) -> None:
+        """This cell's torch.optim.Adam state goes into cell ``self.cell`` of ``self.fused``; from here on torch's state tensors ARE the
+        plan's buffers."""
+        ci = self.cell
         for key, m, k in self._models():
             opt = self.optimizers[key]
-            self.fused.adopt(opt, 0, k)
-            mv, vv = self.fused.m_views[k], self.fused.v_views[k]
-            t = float(self.fused.adam_t[0, k].item())
-            for name, p in m.named_parameters():      # from here on torch's state tensors are the plan's buffers
+            self.fused.adopt(opt, ci, k)
+            mv, vv = self.fused.m_views[2 * ci + k], self.fused.v_views[2 * ci + k]
+            t = float(self.fused.adam_t[ci, k].item())
+            for name, p in m.named_parameters():
                 opt.state[p] = {'step': torch.tensor(t, dtype=torch.float32), 'exp_avg': mv[name], 'exp_avg_sq': vv[name]}
 
     def sync(self) -> None:
@@ -1061,7 +1074,7 @@ class CellTrainer:
         ``optimizers[k].state_dict()`` (checkpoints) -- the moments and the learning rate are shared and always current."""
         if self.fused is None or not self._steps_stale:
             return
-        t = self.fused.adam_t[0].tolist()
+        t = self.fused.adam_t[self.cell].tolist()
         for key, m, k in self._models():
             for p in m.parameters():
                 self.optimizers[key].state[p]['step'] = torch.tensor(float(t[k]), dtype=torch.float32)
@@ -1072,7 +1085,7 @@ class CellTrainer:
             return
         for key, m, k in self._models():
             st = self.optimizers[key].state
-            self.fused.adam_t[0, k] = int(float(st[next(iter(m.parameters()))]['step']))
+            self.fused.adam_t[self.cell, k] = int(float(st[next(iter(m.parameters()))]['step']))
         self.fused.repack()                   # the plan's weight images must follow the parameters
 
     def health(self) -> None:
@@ -1185,3 +1198,165 @@ class TrainStep(CellTrainer):
 
     def __call__(self, rays: torch.Tensor, image_indices: Optional[torch.Tensor], rgbs: torch.Tensor):
         return self.step(rays, image_indices, rgbs)
+
+
+class JointCells:
+    """Several cells of ONE rank trained side by side through one plan (``mnr_train_step`` with ``n_cells`` > 1: the cells' rows share
+    the MLP launches and fill each other's launch tails), each cell still driven by its own, unchanged ``Runner.train()`` loop -- own
+    cluster-masked dataset, own epochs, own checkpoints and logs (parscripts/run_8.txt: one trainer per cell; Building has 25 cells on
+    8 GPUs: 4,3,3,...).
+
+    Every cell's loop runs on a host thread of its own; ``member(i)`` is the trainer factory handed to cell i's Runner
+    (``Runner.trainer_factory``).  A loop calls ``step_gathered(batch)`` once per iteration: the call parks the thread until every cell
+    of the rank has brought its batch, the last one to arrive enqueues ONE joint step, and all resume with their own loss.  Exactly one
+    thread runs at any time (the ``baton``: held while a loop executes Python, handed over while it waits), so nothing of the loops --
+    validation renders, checkpoints, dataset chunk loads -- interleaves.  An iteration in which some cell brings a batch the plan does
+    not take (the ragged last batch of an epoch) is stepped cell by cell on the stage-by-stage path, on the same optimiser state.
+
+    Every cell draws its random numbers as it would alone (``rng_cells`` = 0): a joint job and a one-cell-after-the-other job see the
+    same batches and the same random numbers; their weights then differ only by the summation order of atomically accumulated and
+    dynamically scheduled partial sums (tests/test_gpu_runner.py)."""
+
+    def __init__(self, n_cells: int):
+        import threading
+        assert 1 <= n_cells <= N.MNR_STEP_MAX_CELLS
+        self.n = n_cells
+        self.baton = threading.Condition(threading.Lock())
+        self.members: list = [None] * n_cells
+        self.pending: dict = {}
+        self.results: dict = {}
+        self.generation = 0
+        self.active = n_cells
+        self.plan: Optional[FusedTrainStep] = None
+        self.error: Optional[BaseException] = None
+        self.joint_steps = self.separate_steps = 0
+
+    def member(self, index: int):
+        """The ``trainer_factory`` of cell ``index``: called by its Runner with CellTrainer's arguments."""
+        def make(*args, **kwargs):
+            m = _JointMember(self, index, *args, **kwargs)
+            self.members[index] = m
+            return m
+        return make
+
+    def run(self, loops) -> None:
+        """Run one loop (a callable, e.g. ``runner.train``) per cell to the end, each on its own thread under the baton; re-raises the
+        first exception any of them raised."""
+        import threading
+        assert len(loops) == self.n
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def body(fn):
+            with self.baton:
+                try:
+                    if dev is not None:
+                        torch.cuda.set_device(dev)          # (a new thread starts on device 0)
+                    fn()
+                except BaseException as e:          # noqa: BLE001  (re-raised on the caller's thread)
+                    if self.error is None:
+                        self.error = e
+                finally:
+                    self.active -= 1
+                    self.baton.notify_all()
+        threads = [threading.Thread(target=body, args=(fn,), daemon=True) for fn in loops]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if self.error is not None:
+            raise self.error
+
+    # ---- called by a member, baton held --------------------------------------------------------------------------------------------
+    def submit(self, index: int, batch: 'GatheredBatch'):
+        if self.error is not None:
+            raise RuntimeError('another cell of this rank failed') from self.error
+        self.pending[index] = batch
+        gen = self.generation
+        if len(self.pending) == self.n:
+            try:
+                self._step_all()
+            except BaseException as e:
+                self.error = e
+                self.baton.notify_all()
+                raise
+            self.pending = {}
+            self.generation += 1
+            self.baton.notify_all()
+        else:
+            while self.generation == gen and self.error is None:
+                if self.active < self.n:
+                    self.error = RuntimeError('a cell of this rank ended its loop while the others still train: joint training needs '
+                                              'every cell to run the same number of iterations')
+                    self.baton.notify_all()
+                    break
+                self.baton.wait()
+            if self.error is not None:
+                raise RuntimeError('another cell of this rank failed') from self.error
+        return self.results.pop(index)
+
+    def _make_plan(self) -> None:
+        ms = self.members
+        n_rays = ms[0].plan_rays
+        hp = ms[0].hparams
+        lr = float(ms[0].optimizers['nerf'].param_groups[0]['lr'])
+        self.plan = FusedTrainStep([(m.nerf, m.bg_nerf) for m in ms], hp, ms[0].sc, ms[0].sr, n_rays, lr, seed=ms[0]._seed,
+                                   split_precision=ms[0]._split, rng_cells=[0] * self.n)
+        for i, m in enumerate(ms):
+            m.fused, m.cell = self.plan, i
+            m._adopt_into_plan()
+
+    def _joinable(self) -> bool:
+        ms = self.members
+        if any(m is None for m in ms) or ms[0].plan_rays is None:
+            return False
+        if self.plan is not None:
+            n = self.plan.n_rays
+        else:
+            n = ms[0].plan_rays
+            if any(m.plan_rays != n or m.iteration != ms[0].iteration for m in ms):
+                return False
+            if not all(fused_step_supported(m.nerf, m.bg_nerf, m.hparams, n) for m in ms):
+                return False
+        return all(self.pending[i].select.numel() == n for i in range(self.n)) and len({m.iteration for m in ms}) == 1
+
+    def _step_all(self) -> None:
+        ms = self.members
+        if self._joinable():
+            if self.plan is None:
+                self._make_plan()
+            lrs = {float(o.param_groups[0]['lr']) for m in ms for o in m.optimizers.values()}
+            assert len(lrs) == 1, 'the cells of a rank must be on the same learning-rate schedule'
+            for m in ms:
+                m.iteration += 1
+            self.plan.step_count = ms[0].iteration - 1
+            loss, n_bg, err = self.plan([self.pending[i] for i in range(self.n)], lr=lrs.pop())
+            for i, m in enumerate(ms):
+                m.last_mse = loss[i]
+                m._steps_stale = True
+                for s_ in m.schedulers.values():
+                    s_.step()
+                self.results[i] = (loss[i], n_bg[i:i + 1], err[i:i + 1])
+            self.joint_steps += 1
+            return
+        for i, m in enumerate(ms):          # this iteration cell by cell, stage by stage, on the same optimiser state
+            b = self.pending[i]
+            sel = b.select
+            self.results[i] = CellTrainer.step(m, b.rays[sel], b.img_indices[sel], b.u8_table[b.rgbs_u8[sel].long()])
+        self.separate_steps += 1
+
+
+class _JointMember(CellTrainer):
+    """What the Runner of one cell of a :class:`JointCells` group holds as its trainer."""
+
+    def __init__(self, joint: JointCells, index: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.joint, self.cell = joint, index
+
+    def step_gathered(self, batch: 'GatheredBatch'):
+        return self.joint.submit(self.cell, batch)
+
+    def _plan_takes(self, n: int) -> bool:      # (CellTrainer.step from JointCells._step_all: never the one-cell fused call on the shared plan)
+        return False
+
+    def _make_plan(self, n_rays: int) -> None:
+        raise AssertionError('the shared plan belongs to JointCells')

@@ -14,8 +14,11 @@ replaces the reference's three hand-offs through the filesystem:
     flat fp32 weight buffers straight from the trainers' memory; rank 0 writes the TorchScript container (`--output`, default $EXP-merged.pt).
   * runner.py:495-510 -- validation metrics through temp files.  Here `Runner` evaluates the container with image i on rank i % world and
     ONE all_reduce of the packed metric vector (`distributed.all_reduce_metrics`); every rank ends with the same totals.
-`$MASKS` is the output of scripts/create_cluster_masks.py (params.pt + one directory per cell).  A rank that owns several cells trains
-them one after the other.  Runs single-process too (world 1).  MNR_SHARE_GPU=1: all ranks on device 0 over gloo -- the code-path check on
+`$MASKS` is the output of scripts/create_cluster_masks.py (params.pt + one directory per cell).  A rank that owns several cells (Building:
+25 cells on 8 GPUs = 4,3,3,...) trains them SIDE BY SIDE through one plan -- `training.JointCells`: every cell keeps its own `Runner.train()`
+loop, dataset, epochs, checkpoints and random streams, their iterations meet in one `mnr_train_step` call whose MLP launches carry all the
+cells' rows (the cells fill each other's launch tails: 0.83 of the fp32-MFMA peak instead of 0.76 for one cell at a time, bench.py
+`--submodules`).  `--sequential_cells` trains them one after the other instead (same batches, same random numbers).  Runs single-process too (world 1).  MNR_SHARE_GPU=1: all ranks on device 0 over gloo -- the code-path check on
 a one-GPU box (RCCL refuses two ranks on one device); unmeasured on a multi-GPU node: the driver's 8-GPU runs use bench.py.
 """
 import json
@@ -42,6 +45,8 @@ def _options() -> Namespace:
     parser.add_argument('--mask_path', type=str, required=True, help='output directory of scripts/create_cluster_masks.py')
     parser.add_argument('--output', type=str, default=None, help='merged container (default <exp_name>-merged.pt)')
     parser.add_argument('--skip_eval', default=False, action='store_true')
+    parser.add_argument('--sequential_cells', default=False, action='store_true',
+                        help='a rank that owns several cells trains them one after the other instead of side by side in one plan')
     return parser.parse_args()
 
 
@@ -59,19 +64,35 @@ def main(hp: Namespace) -> None:
     mine = assign_submodules(n_cells, world)[rank]
     output = hp.output or '{}-merged.pt'.format(hp.exp_name)
 
-    # ---- train: one independent single-process Runner per owned cell (the reference's one-process-per-cell layout) --------------
+    # ---- train: one independent single-process Runner per owned cell (the reference's one-process-per-cell layout); the cells of a rank
+    # side by side in ONE plan (training.JointCells) unless --sequential_cells -------------------------------------------------------
     job_env = {k: os.environ.pop(k) for k in ('RANK', 'WORLD_SIZE') if k in os.environ}      # Runner: no DDP, this rank is its own master
     local = {}
     try:
-        for j in mine:
+        def make_runner(j):
             cell_hp = Namespace(**vars(hp))
             cell_hp.cluster_mask_path = str(Path(hp.mask_path) / str(j))
             cell_hp.exp_name = '{}-{}'.format(hp.exp_name, j)
-            runner = Runner(cell_hp)
-            runner.train()
-            local[j] = (runner.nerf, runner.bg_nerf)
-            print('rank {} trained cell {} ({} train images)'.format(rank, j, len(runner.train_items)), flush=True)
-            del runner
+            return Runner(cell_hp)
+        if len(mine) > 1 and not hp.sequential_cells:
+            from mega_nerf.training import JointCells
+            runners = [make_runner(j) for j in mine]
+            joint = JointCells(len(mine))
+            for i, r in enumerate(runners):
+                r.trainer_factory = joint.member(i)
+            joint.run([r.train for r in runners])
+            for j, r in zip(mine, runners):
+                local[j] = (r.nerf, r.bg_nerf)
+            print('rank {} trained cells {} side by side: {} joint steps, {} cell-by-cell iterations'.format(
+                rank, mine, joint.joint_steps, joint.separate_steps), flush=True)
+            del runners, joint
+        else:
+            for j in mine:
+                runner = make_runner(j)
+                runner.train()
+                local[j] = (runner.nerf, runner.bg_nerf)
+                print('rank {} trained cell {} ({} train images)'.format(rank, j, len(runner.train_items)), flush=True)
+                del runner
     finally:
         os.environ.update(job_env)
 

@@ -49,14 +49,14 @@ class TorchNeRF(torch.nn.Module):
         for i, enc in enumerate(self.xyz_encodings):
             if i in cfg.skip_layers:
                 h = torch.cat([inp, h], -1)
-            h = torch.relu(enc(h))
+            h = torch.relu_(enc(h))            # (in place, as the reference's nn.ReLU(True): nerf.py:70)
         sigma = self.sigma(h)
         if sigma_noise is not None:
             sigma = sigma + sigma_noise
         sigma = F.softplus(sigma - 1, 1, 20) if cfg.shifted_softplus else torch.relu(sigma)
         f = self.xyz_encoding_final(h)
         d_in = torch.cat([f, embedding(x[:, -4:-1], cfg.pos_dir_dim), self.embedding_a(x[:, -1].long())], -1)
-        rgb = torch.sigmoid(self.rgb(torch.relu(self.dir_a_encoding(d_in))))
+        rgb = torch.sigmoid(self.rgb(torch.relu_(self.dir_a_encoding(d_in))))
         return torch.cat([rgb, sigma], -1)
 
 

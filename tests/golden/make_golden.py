@@ -249,7 +249,7 @@ def gen_mlp():
 
 
 def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train=False, cascade=False,
-               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256, joint=False, cluster_2d=False):
+               container=None, all_rays=None, with_grad=False, layer_dim=256, bg_layer_dim=256, joint=False, cluster_2d=False, gstride=37):
     s = common.SCENE
     hp = Namespace(**vars(make_hparams(layer_dim=layer_dim, bg_layer_dim=bg_layer_dim, **hp_kw)))
     rays, idx = common.pick_rays(all_rays, N, seed)
@@ -321,6 +321,8 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
         loss.backward()
         out['target'] = target
         out['loss'] = loss.detach().numpy()
+        if gstride != 37:
+            out['gstride'] = np.array(gstride)
         for tag, m in (('fg', nerf), ('bg', bg_nerf)):
             if m is None:
                 continue
@@ -329,8 +331,8 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
                 out['gnorm_%s_%s' % (tag, pn)] = g.norm().numpy()
                 if g.numel() <= 2048 or pn.startswith('sigma') or pn.startswith('rgb'):
                     out['grad_%s_%s' % (tag, pn)] = g.numpy()
-                else:   # big matrices: keep a strided sample (every 37th element of the flat grad)
-                    out['gsub_%s_%s' % (tag, pn)] = g.reshape(-1)[::37].numpy().copy()
+                else:   # big matrices: keep a strided sample (every `gstride`-th element of the flat grad; 37 unless the fixture says otherwise)
+                    out['gsub_%s_%s' % (tag, pn)] = g.reshape(-1)[::gstride].numpy().copy()
         # The same render + loss + backward by the reference in DOUBLE precision on the replayed random numbers: the
         # reference's fp32 gradients carry their own rounding noise (ReLU units whose pre-activation sits within an ulp of 0
         # switch side between implementations; trunk gradients of a sharpened field are sums of a few dominant rows), so
@@ -356,7 +358,7 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
                 for pn, p in m.named_parameters():
                     g = p.grad if p.grad is not None else torch.zeros_like(p)
                     full = g.numel() <= 2048 or pn.startswith('sigma') or pn.startswith('rgb')
-                    out['g64_%s_%s' % (tag, pn)] = (g if full else g.reshape(-1)[::37]).numpy().copy()
+                    out['g64_%s_%s' % (tag, pn)] = (g if full else g.reshape(-1)[::gstride]).numpy().copy()
         finally:
             torch.set_default_dtype(torch.float32)
     save(name, **out)
@@ -522,6 +524,11 @@ def main(only=None):
     case('render_container_2d_eval', dict(base, container_path='dummy', cluster_2d=True), 48, 28, E, container=4, cluster_2d=True)
     case('render_joint_2d_train', dict(base, train_mega_nerf='dummy', cluster_2d=True), 64, 29, TR, container=4, joint=True, cluster_2d=True,
          fg_train=True, bg_train=True, with_grad=True, layer_dim=64, bg_layer_dim=64)
+    # round 6: BASELINE configs[0] at its REAL width -- configs/nerf/*.yaml:1-4 (use_cascade, layer_dim 2048, appearance_dim 0, no_bg_nerf) at 8
+    # rays x (64 + 128): 512 rows through the coarse and 1 536 through the fine 8 x 2048 model, the reference's gradients in fp32 and fp64
+    # (every 1049th element of the 2048 x 2048 matrices: 3 999 samples per tensor)
+    case('render_nerf_w2048_train', dict(base, use_cascade=True, appearance_dim=0), 8, 30, TR, bg=False, cascade=True, fg_train=True,
+         with_grad=True, layer_dim=2048, gstride=1049)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

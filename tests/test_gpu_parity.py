@@ -6,6 +6,7 @@ Tolerances (north star): rgb/depth within 1e-4 relative; sample indices bit-exac
 (bins, weights, u); pure elementwise fp32 chains (z values, sample positions) bit-exact.
 """
 import ctypes as C
+import os
 from argparse import Namespace
 from pathlib import Path
 
@@ -527,10 +528,22 @@ def test_train_render_and_gradients_match_reference():
     loss = torch.nn.functional.mse_loss(res['rgb_fine'], T(g['target']))
     np.testing.assert_allclose(float(loss.detach()), float(g['loss']), rtol=1e-4)
     loss.backward()
-    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)))
+    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)), 'stagewise:' + name)
 
 
-def check_gradients_against_reference(g, models):
+# How many tensors of each training fixture needed the one-in-ten allowance below when the check last ran on the MI355X (a flipped ReLU
+# unit on a dominant row: discrete events, so the count is a property of fixture + kernels).  A fixture may not need MORE than recorded
+# here: a regression can no longer hide in the allowance.  Keys: '<caller>:<fixture>'.  MNR_RECORD_ALLOWANCE=<file>
+# appends the measured counts as JSON lines instead of asserting (to re-record after a deliberate kernel change).
+ALLOWANCE_USED = {}
+try:
+    import json as _json
+    ALLOWANCE_USED = _json.loads((Path(__file__).resolve().parent / 'golden' / 'gradient_allowance.json').read_text())
+except Exception:        # (file absent: every fixture must then pass without the allowance)
+    pass
+
+
+def check_gradients_against_reference(g, models, key=None):
     """Parameter gradients against the golden file's two recordings of the reference's own gradients: fp32 autograd
     (``grad_*`` / ``gsub_*`` = every 37th element) and the same reference run in fp64 on the same random numbers (``g64_*``).
     The fp32 reference is itself off the fp64 one by up to 7e-2 of a tensor's scale: a ReLU unit whose pre-activation lies
@@ -553,7 +566,7 @@ def check_gradients_against_reference(g, models):
             if 'grad_%s_%s' % (tag, pn) in g:
                 r32 = g['grad_%s_%s' % (tag, pn)]
             else:
-                r32, got = g['gsub_%s_%s' % (tag, pn)], got.reshape(-1)[::37]
+                r32, got = g['gsub_%s_%s' % (tag, pn)], got.reshape(-1)[::int(g['gstride']) if 'gstride' in g else 37]
             r64 = g['g64_%s_%s' % (tag, pn)].reshape(r32.shape)
             scale = float(np.abs(r64).max())
             if scale == 0:
@@ -569,6 +582,12 @@ def check_gradients_against_reference(g, models):
     assert not norm_bad, norm_bad
     over = {k: v for k, v in errs.items() if not v[0] <= 2e-4 + 2 * v[1]}
     assert len(over) <= max(1, len(errs) // 10), over
+    rec = os.environ.get('MNR_RECORD_ALLOWANCE')
+    if rec and key is not None:
+        with open(rec, 'a') as f:
+            f.write(_json.dumps({key: len(over)}) + '\n')
+    elif key is not None:
+        assert len(over) <= ALLOWANCE_USED.get(key, 0), (key, 'tensors outside 2e-4 + 2 x reference error', over, 'recorded', ALLOWANCE_USED.get(key, 0))
     for (tag, pn), v in over.items():
         worst_ref = max(e[1] for (t, _), e in errs.items() if t == tag)
         assert v[0] <= worst_ref, ((tag, pn), v, worst_ref)

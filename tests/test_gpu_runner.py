@@ -1,5 +1,7 @@
 """End-to-end drop-in check on the GPU: synthetic dataset in the reference's on-disk layout -> train.main ->
 checkpoint with the reference's keys -> eval.main -> metrics.txt."""
+import os
+import re
 import subprocess
 import sys
 from pathlib import Path
@@ -274,3 +276,54 @@ def test_train_cells_job_two_ranks_merges_in_job_and_evaluates(tmp_path):
     solo = (tmp_path / 'solo' / '0' / 'metrics.txt').read_text()
     solo_psnr = float([ln for ln in solo.splitlines() if ln.startswith('Average val/psnr')][0].split(':')[1])
     assert abs(solo_psnr - lines[0]['val_psnr']) < 1e-4, (solo_psnr, lines[0]['val_psnr'])
+
+
+def test_a_ranks_cells_side_by_side_in_one_plan_train_like_one_after_the_other(tmp_path):
+    """tools/train_cells.py on ONE rank that owns all four cells of a 2 x 2 grid (Building: 25 cells on 8 GPUs = 4,3,3,...): the default --
+    the cells' unchanged Runner.train() loops on host threads, their iterations meeting in ONE `mnr_train_step` call per iteration
+    (training.JointCells), each cell on its own cluster-masked dataset with its own random streams -- against `--sequential_cells` (one
+    cell after the other, the reference's parscripts/run_8.txt layout on one GPU).  Same batches, same random numbers: the merged
+    containers agree to the summation order of the gradients' partial sums (a weight moves by at most lr per Adam step; two orders of a
+    noise-level gradient may disagree on its sign), and nearly all weights agree far better than that.  The joint job must actually have
+    taken joint steps, and its ragged last batches of an epoch the cell-by-cell path."""
+    data = tmp_path / 'data'
+    tools = ROOT / 'mega-nerf_amd' / 'tools'
+    scripts = ROOT / 'mega-nerf_amd' / 'scripts'
+    subprocess.run([sys.executable, str(tools / 'make_synthetic_dataset.py'), '--out', str(data), '--images', '8', '--val_every', '4',
+                    '--size', '32', '--samples', '32', '64'], check=True)
+    flags = ['--dataset_path', str(data), '--coarse_samples', '64', '--fine_samples', '128', '--near', '0.01', '--ray_altitude_range', '-0.5', '0.2',
+             '--val_scale_factor', '1', '--boundary_margin', '1.5']
+    masks = tmp_path / 'masks'
+    subprocess.run([sys.executable, str(scripts / 'create_cluster_masks.py'), '--output', str(masks), '--grid_dim', '2', '2', '--ray_samples', '64'] + flags,
+                   check=True)
+    iters = 8
+    env = dict(os.environ, MNR_NO_VAL_IMAGES='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    train_flags = flags + ['--train_iterations', str(iters), '--ckpt_interval', str(iters), '--val_interval', '1000', '--batch_size', '256', '--skip_eval']
+    outs = {}
+    for mode, extra in (('joint', []), ('seq', ['--sequential_cells'])):
+        r = subprocess.run([sys.executable, str(tools / 'train_cells.py'), '--mask_path', str(masks), '--exp_name', str(tmp_path / mode)] + train_flags + extra,
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        outs[mode] = r.stdout
+        for j in range(4):
+            assert (tmp_path / '{}-{}'.format(mode, j) / '0' / 'models' / '{}.pt'.format(iters)).exists(), (mode, j)
+    line = [ln for ln in outs['joint'].splitlines() if 'side by side' in ln]
+    assert len(line) == 1, outs['joint'][-2000:]
+    joint_steps, separate = [int(v) for v in re.findall(r'(\d+) joint steps, (\d+) cell-by-cell', line[0])[0]]
+    assert joint_steps + separate == iters and joint_steps >= iters - 2, line[0]
+    a = torch.jit.load(str(tmp_path / 'joint-merged.pt'), map_location='cpu').state_dict()
+    b = torch.jit.load(str(tmp_path / 'seq-merged.pt'), map_location='cpu').state_dict()
+    assert a.keys() == b.keys() and len(a) > 100
+    worst, close, total = 0.0, 0, 0
+    for k in a:
+        if not a[k].dtype.is_floating_point:
+            assert torch.equal(a[k], b[k]), k
+            continue
+        d = (a[k] - b[k]).abs()
+        worst = max(worst, float(d.max()))
+        close += int((d <= 1e-5).sum())
+        total += d.numel()
+    assert worst <= 2 * iters * 5e-4 + 1e-6, worst            # lr 5e-4: a weight moves by at most lr per step
+    assert close / total > 0.97, (close, total, worst)

@@ -63,7 +63,7 @@ def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
     worst = {k: float(np.abs(got[k] - ref[k]).max()) / max(float(np.abs(ref[k]).max()), 1e-30) for k in ref}
     print({k: '%.1e' % v for k, v in worst.items()})
     assert max(worst.values()) < 2e-5, {k: v for k, v in worst.items() if v >= 2e-5}
-    check_gradients_against_reference(g, (('fg', nerf2), ('bg', bg2)))
+    check_gradients_against_reference(g, (('fg', nerf2), ('bg', bg2)), 'fused:' + name)
 
 
 def _cell(seed, n_rays, sh=False):
@@ -311,7 +311,7 @@ def test_fused_step_gradients_against_fp64_with_the_kernels_own_relu_masks(split
     bad = {k: v for k, v in worst.items() if not v[0] <= 2e-4 + 2 * v[1]}
     assert not bad, bad
     assert sum(v[0] > 2e-4 for v in worst.values()) <= 2, worst
-    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)))
+    check_gradients_against_reference(g, (('fg', nerf), ('bg', bg_nerf)), 'fused-%s:render_fgbg_train' % ('split' if split else 'f32'))
 
 
 def test_split_precision_step_trains_like_the_fp32_step():
