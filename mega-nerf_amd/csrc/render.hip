@@ -7,6 +7,7 @@
 // Every stage takes an optional device-side unit count (`n_units_dev`): background-ray lists are
 // compacted on the device and never synchronise with the host.
 #include "common.h"
+#include "route_internal.h"
 
 namespace mnr {
 
@@ -739,7 +740,7 @@ constexpr int ROUTE_BLOCK = 1024;
 __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__ pos, long pos_stride, long B,
                                                        const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
                                                        float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
-                                                       int32_t *__restrict__ counts, int32_t *__restrict__ inverse) {
+                                                       int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows) {
     __shared__ int wcnt[ROUTE_MAX_SUB][ROUTE_BLOCK / 64];
     __shared__ int base[ROUTE_MAX_SUB];
     __shared__ float4 sc[ROUTE_MAX_SUB];                                   // (c_x, c_y, c_z, |c|^2 over the clustered axes)
@@ -758,7 +759,10 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__
     const bool valid = row < n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float p[3] = {0.f, 0.f, 0.f};
-    if (valid) { p[0] = pos[row * pos_stride]; p[1] = pos[row * pos_stride + 1]; p[2] = pos[row * pos_stride + 2]; }
+    // (pos_rows > 1: one position per pos_rows consecutive rows -- the background rows of a ray under 3-D clustering all carry the ray's
+    // sphere-exit point, rendering.py:463-464)
+    const long prow = pos_rows > 1 ? row / pos_rows : row;
+    if (valid) { p[0] = pos[prow * pos_stride]; p[1] = pos[prow * pos_stride + 1]; p[2] = pos[prow * pos_stride + 2]; }
     // distances: torch.cdist(x[:, d0:3], centroids[:, d0:]) (mega_nerf.py:22,31).  ATen takes its MATMUL formulation whenever either side
     // has more than 25 rows (cdist mode "use_mm_for_euclid_dist_if_necessary"; _euclidean_dist): [-2x, |x|^2, 1] . [c, 1, |c|^2] as one
     // sgemm -- an fma chain in column order (checked against torch / MKL: oracle/nerf_oracle.py cdist_mm) --, clamp_min(0), sqrt.  The two
@@ -878,25 +882,76 @@ __global__ void k_zero_i32(int32_t *p, int n) {
 }  // namespace mnr
 
 static int route_impl(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit, const float *centroids, int n_sub,
-                      int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, void *stream) {
+                      int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, void *stream, int pos_rows = 1,
+                      bool counts_are_zero = false) {
     MNR_REQUIRE(pos && centroids && weights && lists && counts && B >= 0, "bad arguments to mnr_route");
     MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
     MNR_REQUIRE(d0 == 0 || d0 == 1, "cluster_dim_start must be 0 or 1");
     MNR_REQUIRE(margin >= 1.f, "boundary_margin must be >= 1");
     hipStream_t s = as_stream(stream);
     // (a kernel, not hipMemsetAsync: the runtime's fill leaves a ~6 us bubble in front of it on the stream, four times per routed render)
-    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, counts, n_sub);
-    int rc = check_launch("k_zero_i32");
-    if (rc) return rc;
+    if (!counts_are_zero) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, counts, n_sub);
+        int rc = check_launch("k_zero_i32");
+        if (rc) return rc;
+    }
     if (B == 0) return MNR_OK;
     Centroids cen;
     cen.n = n_sub;
     for (int i = 0; i < n_sub; ++i)
         for (int k = 0; k < 3; ++k) cen.c[i][k] = centroids[3 * i + k];
     hipLaunchKernelGGL(k_route, dim3(nblk(B, ROUTE_BLOCK)), dim3(ROUTE_BLOCK), 0, s, pos, (long)pos_stride, (long)B, n_dev, rows_per_unit, cen,
-                       d0, margin, weights, lists, counts, inverse);
+                       d0, margin, weights, lists, counts, inverse, pos_rows);
     return check_launch("k_route");
 }
+
+// ---- the routed render as part of mnr_render_fwd (csrc/step.hip): internal entry points ----------------------------------------------
+namespace mnr {
+// sphere-exit point of every compacted background ray: the routing position of ALL its rows under 3-D clustering (rendering.py:463-464:
+// ray_o + ray_d * (d1 + d2), the `include_xyz_real` columns k_bg_samples writes per sample; same operations in the same order)
+__global__ void k_bg_exit_points(const float *__restrict__ rays_bg, const int32_t *__restrict__ n_bg, long N_max, Sphere sp, float *__restrict__ out) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= unit_limit(N_max, n_bg)) return;
+    const float *ray = rays_bg + k * 8;
+    float o[3], d[3];
+    normalise_ray(sp, ray, o, d);
+    const float dd = dot3(d, d);
+    const float d1 = -dot3(d, o) / dd;
+    const float pm[3] = {o[0] + d1 * d[0], o[1] + d1 * d[1], o[2] + d1 * d[2]};
+    const float pm_norm = sqrtf(dot3(pm, pm));
+    const float ray_d_cos = 1.f / sqrtf(dd);
+    const float d2 = sqrtf(1.f - pm_norm * pm_norm) * ray_d_cos;
+    const float dsum = d1 + d2;
+    out[3 * k] = ray[0] + ray[3] * dsum; out[3 * k + 1] = ray[1] + ray[4] * dsum; out[3 * k + 2] = ray[2] + ray[5] * dsum;
+}
+int bg_exit_points_launch(const float *rays_bg, const int32_t *n_bg, long N_max, const float *c, const float *r, float *out, hipStream_t s) {
+    if (N_max == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_bg_exit_points, dim3(nblk(N_max, 256)), dim3(256), 0, s, rays_bg, n_bg, N_max, make_sphere(c, r), out);
+    return check_launch("k_bg_exit_points");
+}
+// zero the row counts and write the device cell tables of up to two containers' routed evaluations (one launch per render pass)
+__global__ void k_route_prepare(RoutePrep a) {
+    const int t = threadIdx.x;
+    for (int q = 0; q < 2; ++q) {
+        const RoutePrepSeg &g = a.s[q];
+        if (t < g.n) {
+            g.counts[t] = 0;
+            mnr_mlp_cell c;
+            c.packed_dev = g.packed[t]; c.embedding_a = g.emb[t]; c.row_index = g.lists + (long)t * g.B; c.count = g.counts + t;
+            c.out = g.sub_out + (long)t * g.B * g.out_stride;
+            g.table[t] = c;
+        }
+    }
+}
+int route_prepare_launch(const RoutePrep &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_route_prepare, dim3(1), dim3(64), 0, s, a);
+    return check_launch("k_route_prepare");
+}
+int route_launch(const float *pos, long pos_stride, int pos_rows, long B, const int32_t *n_dev, int rows_per_unit, const float *centroids_host, int n_sub,
+                 int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, hipStream_t s) {
+    return route_impl(pos, pos_stride, B, n_dev, rows_per_unit, centroids_host, n_sub, d0, margin, weights, lists, counts, inverse, s, pos_rows, true);
+}
+}  // namespace mnr
 
 extern "C" int mnr_route(const float *pos, int64_t pos_stride, int64_t B, const int32_t *n_dev, int rows_per_unit,
                          const float *centroids, int n_sub, int d0, float margin, float *weights, int32_t *lists,

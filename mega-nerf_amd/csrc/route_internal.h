@@ -1,0 +1,24 @@
+// route_internal.h -- the routed render's internal entry points (csrc/render.hip), called by mnr_render_fwd (csrc/step.hip).
+#pragma once
+#include "common.h"
+
+namespace mnr {
+
+constexpr int ROUTE_PREP_MAX = 64;
+struct RoutePrepSeg {
+    mnr_mlp_cell *table;           // device table to write [n]
+    int32_t *lists, *counts;       // [n][B], [n]
+    float *sub_out;                // [n][B][out_stride]
+    long B;
+    int n, out_stride;
+    const void *packed[ROUTE_PREP_MAX];
+    const float *emb[ROUTE_PREP_MAX];
+};
+struct RoutePrep { RoutePrepSeg s[2]; };
+int route_prepare_launch(const RoutePrep &a, hipStream_t s);
+int route_launch(const float *pos, long pos_stride, int pos_rows, long B, const int32_t *n_dev, int rows_per_unit, const float *centroids_host, int n_sub,
+                 int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, hipStream_t s);
+int bg_exit_points_launch(const float *rays_bg, const int32_t *n_bg, long N_max, const float *center, const float *radius, float *out, hipStream_t s);
+
+
+}  // namespace mnr

@@ -1458,6 +1458,33 @@ extern "C" size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples,
 
 extern "C" int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, void *stream);
 
+// routing buffers of a routed render (mnr_render_io::route_workspace): per container the blend weights, row lists, inverse lists and the
+// cells' compact outputs of ONE pass (the coarse and the fine pass follow each other and share them), the row counts, the device cell table
+struct RouteWs {
+    struct Part { size_t weights, lists, inverse, sub_out, counts, table; long cap; } fg, bg;
+    size_t exit_pts, total;
+};
+static void route_layout(long N, long Nc, long Nf, int n_cells, RouteWs &L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    auto part = [&](RouteWs::Part &P, long cap) {
+        P.cap = cap;
+        P.weights = take((size_t)n_cells * cap * 4); P.lists = take((size_t)n_cells * cap * 4); P.inverse = take((size_t)n_cells * cap * 4);
+        P.sub_out = take((size_t)n_cells * cap * 16); P.counts = take(ROUTE_PREP_MAX * 4); P.table = take(ROUTE_PREP_MAX * sizeof(mnr_mlp_cell));
+    };
+    part(L.fg, N * (Nc > Nf ? Nc : Nf));
+    part(L.bg, N * ((Nc > Nf ? Nc : Nf) / 2));
+    L.exit_pts = take((size_t)N * 12);
+    L.total = off;
+}
+extern "C" size_t mnr_render_route_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples, int n_cells) {
+    if (render_dims_ok(n_rays, coarse_samples, fine_samples) != MNR_OK || n_cells < 1 || n_cells > ROUTE_PREP_MAX) return 0;
+    RouteWs L;
+    route_layout(n_rays, coarse_samples, fine_samples, n_cells, L);
+    return L.total;
+}
+extern "C" int mnr_mlp_forward_cells_multi(const mnr_mlp_cells_launch *segs, int n_segs, void *stream);
+
 // a side stream + fork / join events a caller may lend to mnr_render_fwd (mnr_render_io::side): the background branch then runs beside
 // the foreground's passes (the step plans own theirs)
 struct mnr_side {
@@ -1487,8 +1514,13 @@ extern "C" void mnr_side_destroy(mnr_side *sd) {
 }
 
 extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
-    MNR_REQUIRE(r && r->fg && r->bg && r->fg_packed && r->bg_packed && r->rays && r->idx && r->rgb && r->bg_lambda && r->n_bg && r->err &&
+    MNR_REQUIRE(r && r->fg && r->bg && r->rays && r->idx && r->rgb && r->bg_lambda && r->n_bg && r->err &&
                 r->workspace && r->t_coarse_dev && r->t_bg_coarse_dev && r->t_fine_dev && r->t_bg_fine_dev, "NULL argument to mnr_render_fwd");
+    const int n_cells = r->n_cells;
+    MNR_REQUIRE(n_cells >= 0 && n_cells <= ROUTE_PREP_MAX, "n_cells must be in 0..%d", ROUTE_PREP_MAX);
+    if (n_cells == 0) MNR_REQUIRE(r->fg_packed && r->bg_packed, "NULL weight image");
+    else MNR_REQUIRE(r->fg_cell_packed && r->bg_cell_packed && r->fg_cell_emb && r->bg_cell_emb && r->centroids_host && r->route_workspace &&
+                     r->boundary_margin >= 1.f && !r->side, "routed render: cell arrays, centroids, margin >= 1, routing workspace required (one stream)");
     const long N = r->n_rays, Nc = r->coarse_samples, Nf = r->fine_samples, Sb = Nc / 2, Sfb = Nf / 2;
     int rc = render_dims_ok(N, Nc, Nf);
     if (rc != MNR_OK) return rc;
@@ -1522,6 +1554,14 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         hipLaunchKernelGGL(k_step_samples, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
         if ((rc = check_launch("k_step_samples"))) return rc;
     }
+    RouteWs RL{};
+    if (n_cells > 0) {
+        MNR_REQUIRE(!r->split_precision, "routed render: fp32 kernels");
+        route_layout(N, Nc, Nf, n_cells, RL);
+        MNR_REQUIRE(r->route_workspace_bytes >= RL.total, "routing workspace too small: %zu < %zu", r->route_workspace_bytes, RL.total);
+        if ((rc = bg_exit_points_launch(F(L.rays_bg), r->n_bg, N, r->sphere_center, r->sphere_radius,
+                                        reinterpret_cast<float *>(reinterpret_cast<char *>(r->route_workspace) + RL.exit_pts), s))) return rc;
+    }
     auto fwd_pass = [&](int pass, int branch, hipStream_t st) -> int {
         mnr_mlp_io io[2] = {};
         const long Sf = pass ? Nf : Nc, Sbb = pass ? Sfb : Sb;
@@ -1536,6 +1576,47 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         seg[0].packed_dev = r->fg_packed; seg[0].desc = r->fg; seg[0].io = &io[0];
         seg[1].packed_dev = r->bg_packed; seg[1].desc = r->bg; seg[1].io = &io[1];
         const int first = branch == 2 ? 1 : 0, n = branch == 0 ? 2 : 1;
+        if (n_cells > 0) {
+            // ---- merged containers: route -> all cells of both containers in one gather-mode launch -> blend (mega_nerf.py:19-61) ----
+            MNR_REQUIRE(branch == 0, "routed render: both branches on one stream");
+            char *rw = reinterpret_cast<char *>(r->route_workspace);
+            auto RF = [&](size_t off) { return reinterpret_cast<float *>(rw + off); };
+            auto RI = [&](size_t off) { return reinterpret_cast<int32_t *>(rw + off); };
+            const long B[2] = {N * Sf, N * Sbb};
+            const RouteWs::Part *P[2] = {&RL.fg, &RL.bg};
+            RoutePrep prep{};
+            for (int q = 0; q < 2; ++q) {
+                RoutePrepSeg &g = prep.s[q];
+                g.table = reinterpret_cast<mnr_mlp_cell *>(rw + P[q]->table); g.lists = RI(P[q]->lists); g.counts = RI(P[q]->counts);
+                g.sub_out = RF(P[q]->sub_out); g.B = B[q]; g.n = n_cells; g.out_stride = 4;
+                for (int c = 0; c < n_cells; ++c) {
+                    g.packed[c] = (q ? r->bg_cell_packed : r->fg_cell_packed)[c];
+                    g.emb[c] = (q ? r->bg_cell_emb : r->fg_cell_emb)[c];
+                }
+            }
+            int rc2 = route_prepare_launch(prep, st);
+            if (rc2) return rc2;
+            // foreground rows route on their own position; a background ray's rows all on its sphere-exit point
+            if ((rc2 = route_launch(io[0].xyz, 3, 1, B[0], nullptr, 0, r->centroids_host, n_cells, 0, r->boundary_margin, RF(RL.fg.weights), RI(RL.fg.lists),
+                                    RI(RL.fg.counts), RI(RL.fg.inverse), st))) return rc2;
+            if ((rc2 = route_launch(RF(RL.exit_pts), 3, (int)Sbb, B[1], r->n_bg, (int)Sbb, r->centroids_host, n_cells, 0, r->boundary_margin, RF(RL.bg.weights),
+                                    RI(RL.bg.lists), RI(RL.bg.counts), RI(RL.bg.inverse), st))) return rc2;
+            float *outs[2] = {io[0].out, io[1].out};
+            mnr_mlp_cells_launch cl[2] = {};
+            for (int q = 0; q < 2; ++q) {
+                io[q].n_rows = B[q]; io[q].out = nullptr; io[q].n_units_dev = nullptr;
+                cl[q].desc = q ? r->bg : r->fg; cl[q].cells_dev = reinterpret_cast<const mnr_mlp_cell *>(rw + P[q]->table); cl[q].n_cells = n_cells; cl[q].io = &io[q];
+            }
+            // (the smaller segment -- the background's -- first: its workgroups start at once and the foreground's fill the chip behind them)
+            const mnr_mlp_cells_launch ordered[2] = {cl[1], cl[0]};
+            rc2 = mnr_mlp_forward_cells_multi(ordered, 2, st);
+            if (rc2 == MNR_E_UNSUPPORTED)          // (other architectures -- 512-wide cells, spherical-harmonics heads: one launch per container)
+                for (int q = 0; q < 2 && (q == 0 || rc2 == MNR_OK); ++q) rc2 = mnr_mlp_forward_cells(ordered[q].desc, ordered[q].cells_dev, n_cells, ordered[q].io, st);
+            if (rc2) return rc2;
+            const float *wts[2] = {r->boundary_margin > 1.f ? RF(RL.fg.weights) : nullptr, r->boundary_margin > 1.f ? RF(RL.bg.weights) : nullptr};
+            if ((rc2 = mnr_route_combine_indexed(outs[0], 4, RF(RL.fg.sub_out), B[0] * 4, 4, 4, RI(RL.fg.inverse), wts[0], n_cells, B[0], nullptr, 0, st))) return rc2;
+            return mnr_route_combine_indexed(outs[1], 4, RF(RL.bg.sub_out), B[1] * 4, 4, 4, RI(RL.bg.inverse), wts[1], n_cells, B[1], r->n_bg, (int)Sbb, st);
+        }
         if (r->split_precision) return mnr_mlp_forward_multi_h2(seg + first, n, st);
         if (r->fg->layer_dim == 512 || r->bg->layer_dim == 512) {
             // 512-wide models (Building): one launch per model -- the wavefront-pair kernel for a 512-wide one, the two-model kernel

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "mlp_device.h"
+#include "route_internal.h"
 
 namespace mnr {
 

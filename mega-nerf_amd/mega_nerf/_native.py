@@ -180,7 +180,10 @@ class RenderIO(C.Structure):
                 ('t_coarse_dev', C.c_void_p), ('t_bg_coarse_dev', C.c_void_p), ('t_fine_dev', C.c_void_p), ('t_bg_fine_dev', C.c_void_p),
                 ('rgb', C.c_void_p), ('depth', C.c_void_p), ('fg_rgb', C.c_void_p), ('bg_rgb', C.c_void_p), ('fg_depth', C.c_void_p),
                 ('bg_depth', C.c_void_p), ('bg_lambda', C.c_void_p), ('n_bg', C.c_void_p), ('err', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('side', C.c_void_p)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('side', C.c_void_p),
+                ('n_cells', C.c_int32), ('fg_cell_packed', C.POINTER(C.c_void_p)), ('bg_cell_packed', C.POINTER(C.c_void_p)),
+                ('fg_cell_emb', C.POINTER(C.c_void_p)), ('bg_cell_emb', C.POINTER(C.c_void_p)), ('centroids_host', c_float_p),
+                ('boundary_margin', C.c_float), ('route_workspace', C.c_void_p), ('route_workspace_bytes', C.c_size_t)]
 
 
 class Calibration(C.Structure):
@@ -209,7 +212,7 @@ EXPORTS = [
     'mnr_step_query', 'mnr_step_create', 'mnr_step_destroy', 'mnr_step_repack', 'mnr_train_step', 'mnr_step_profile', 'mnr_step_kernel_times',
     'mnr_packed_model_h2_bytes', 'mnr_pack_model_h2', 'mnr_mlp_forward_multi_h2', 'mnr_render_workspace_bytes', 'mnr_render_fwd', 'mnr_packed_bwd_h2_bytes', 'mnr_pack_model_bwd_h2',
     'mnr_mlp_backward_weights_multi_h2', 'mnr_mlp_forward_cells_h2', 'mnr_side_create', 'mnr_side_destroy', 'mnr_mlp_forward_cells_multi',
-    'mnr_calibrate', 'mnr_calibrate_scratch_bytes', 'mnr_calibrate_hog',
+    'mnr_calibrate', 'mnr_calibrate_scratch_bytes', 'mnr_calibrate_hog', 'mnr_render_route_workspace_bytes',
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -340,6 +343,8 @@ def lib() -> C.CDLL:
         _lib.mnr_render_workspace_bytes.restype = C.c_size_t
         _lib.mnr_render_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
         _lib.mnr_render_fwd.argtypes = [C.POINTER(RenderIO), C.c_void_p]
+        _lib.mnr_render_route_workspace_bytes.restype = C.c_size_t
+        _lib.mnr_render_route_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
         _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
         _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_double, C.c_int64, C.c_uint64, C.c_int,

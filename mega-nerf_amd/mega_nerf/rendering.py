@@ -401,6 +401,7 @@ def release_render_workspaces(*models) -> None:
     """Drop the cached scratch of the one-call render (~2.7 GB after 65 536-ray batches at 256 + 512 samples) and, for merged containers
     passed in, their routing buffers (``MegaNeRF.release_buffers``); the next render re-allocates."""
     _render_ws.clear()
+    _route_ws.clear()
     for m in models:
         for sub in (m.modules() if isinstance(m, torch.nn.Module) else ()):       # (a Cascade may hold containers)
             if hasattr(sub, 'release_buffers'):
@@ -408,12 +409,33 @@ def release_render_workspaces(*models) -> None:
 
 
 
+def _routed_pair(nerf, bg_nerf) -> bool:
+    """Both models are merged containers (MegaNeRF routers) the one-call render covers: the same centroids and margin, 3-D clustering, the
+    foreground routed on its points and the background on its rays' sphere-exit points (mega_nerf.py:19-61)."""
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    if not (isinstance(nerf, MegaNeRF) and isinstance(bg_nerf, MegaNeRF)):
+        return False
+    if nerf.cluster_dim_start or bg_nerf.cluster_dim_start or nerf.xyz_real or not bg_nerf.xyz_real or nerf.joint_training or bg_nerf.joint_training:
+        return False
+    if len(nerf.sub_modules) != len(bg_nerf.sub_modules) or not 1 <= len(nerf.sub_modules) <= 64:
+        return False
+    # (host copies, cached on the modules: no device read per render)
+    if float(nerf.boundary_margin) != float(bg_nerf.boundary_margin) or list(nerf._centroids_host()) != list(bg_nerf._centroids_host()):
+        return False
+    from mega_nerf.models.mega_nerf import _arch_key
+    for m in (nerf, bg_nerf):
+        kids = list(m.sub_modules)
+        if not all(c.fused_supported() and _arch_key(c) == _arch_key(kids[0]) and c.embedding_a is not None for c in kids):
+            return False
+    return True
+
+
 def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_depth_variance, rnd) -> bool:
     import os
     from mega_nerf.models.nerf import NeRF
     if not FUSED_RENDER or os.environ.get('MNR_NO_FUSED_RENDER') or bg_nerf is None or image_indices is None or sphere_radius is None:
         return False
-    if get_depth_variance or rnd or hparams.use_cascade or hparams.container_path is not None or hparams.train_mega_nerf is not None:
+    if get_depth_variance or rnd or hparams.use_cascade or hparams.train_mega_nerf is not None:
         return False
     if (hparams.coarse_samples, hparams.fine_samples) not in ((64, 128), (256, 512)):
         return False
@@ -421,14 +443,27 @@ def _fused_render_ok(nerf, bg_nerf, hparams, image_indices, sphere_radius, get_d
     sh = hparams.sh_deg is not None and hparams.pos_dir_dim == 0
     if sh and (hparams.sh_deg not in (2, 3) or SPLIT_PRECISION):
         return False
-    for m in (nerf, bg_nerf):
-        if not isinstance(m, NeRF) or m.training:
+    routed = hparams.container_path is not None
+    if routed:
+        # merged containers: route -> all cells of both containers in one launch -> blend, inside the same call (fp32 kernels)
+        if SPLIT_PRECISION or os.environ.get('MNR_NO_FUSED_ROUTED_RENDER') or nerf.training or bg_nerf.training or not _routed_pair(nerf, bg_nerf):
+            return False
+        if getattr(nerf, 'routed_rows', None) is not None or getattr(bg_nerf, 'routed_rows', None) is not None:
+            return False               # (bench.py's device-side tally of routed rows lives in the stage-by-stage path)
+        models = (nerf.sub_modules[0], bg_nerf.sub_modules[0])
+    else:
+        models = (nerf, bg_nerf)
+    for m in models:
+        if not isinstance(m, NeRF) or (not routed and m.training):
             return False
         # default 8 x 256, its sh_deg 2 form, or (fp32 kernels only) the 512-wide Building shape on the wavefront-pair kernel
         wide = m.is_wide_default_arch() and not sh and not SPLIT_PRECISION and os.environ.get('MNR_NO_PAIR_KERNEL') is None
         if not ((m.is_sh_arch(hparams.sh_deg) if sh else m.is_default_arch()) or wide):
             return False
-    return nerf.xyz_dim == 3 and bg_nerf.xyz_dim == 4
+    return models[0].xyz_dim == 3 and models[1].xyz_dim == 4
+
+
+_route_ws: Dict[tuple, torch.Tensor] = {}
 
 
 def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sphere_radius, get_depth, get_bg_fg_rgb):
@@ -447,9 +482,31 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
     scal = torch.empty(2, device=dev, dtype=torch.int32)
     io = N.RenderIO()
     split = 1 if SPLIT_PRECISION else 0
-    fd, fp = nerf.packed_h2() if split else nerf.packed()
-    bd, bp = bg_nerf.packed_h2() if split else bg_nerf.packed()
-    io.fg, io.bg, io.fg_packed, io.bg_packed = C.pointer(fd), C.pointer(bd), fp.data_ptr(), bp.data_ptr()
+    keep = []
+    if hparams.container_path is not None:
+        # merged containers: the cells' weight images / appearance tables as host pointer arrays, the routing buffers as one workspace
+        nc = len(nerf.sub_modules)
+        arrs = []
+        for m in (nerf, bg_nerf):
+            packs = [c.packed() for c in m.sub_modules]
+            keep.append(packs)
+            arrs.append((C.c_void_p * nc)(*[pk.data_ptr() for _, pk in packs]))
+            arrs.append((C.c_void_p * nc)(*[c.embedding_a.weight.data_ptr() for c in m.sub_modules]))
+        fd, bd = keep[0][0][0], keep[1][0][0]
+        io.fg, io.bg = C.pointer(fd), C.pointer(bd)
+        io.n_cells, io.fg_cell_packed, io.fg_cell_emb, io.bg_cell_packed, io.bg_cell_emb = nc, arrs[0], arrs[1], arrs[2], arrs[3]
+        cent = nerf._centroids_host()
+        io.centroids_host, io.boundary_margin = cent, float(nerf.boundary_margin)
+        rneed = lib.mnr_render_route_workspace_bytes(n, Nc, Nf, nc)
+        rws = _route_ws.get(key)
+        if rws is None or rws.numel() < rneed:
+            rws = _route_ws[key] = torch.empty(rneed, dtype=torch.uint8, device=dev)
+        io.route_workspace, io.route_workspace_bytes = rws.data_ptr(), rws.numel()
+        keep += [arrs, cent]
+    else:
+        fd, fp = nerf.packed_h2() if split else nerf.packed()
+        bd, bp = bg_nerf.packed_h2() if split else bg_nerf.packed()
+        io.fg, io.bg, io.fg_packed, io.bg_packed = C.pointer(fd), C.pointer(bd), fp.data_ptr(), bp.data_ptr()
     io.rays, io.idx, io.idx_is_float, io.n_rays = rays.data_ptr(), image_indices.data_ptr(), 1 if image_indices.dtype == torch.float32 else 0, n
     io.coarse_samples, io.fine_samples, io.split_precision = Nc, Nf, split
     c, r = _host_vec(sphere_center), _host_vec(sphere_radius)
@@ -468,7 +525,7 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
             io.fg_depth, io.bg_depth = v['fg_depth'].data_ptr(), v['bg_depth'].data_ptr()
     io.n_bg, io.err = scal[0:1].data_ptr(), scal[1:2].data_ptr()
     io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
-    if os.environ.get('MNR_RENDER_TWO_STREAMS'):
+    if os.environ.get('MNR_RENDER_TWO_STREAMS') and hparams.container_path is None:
         # opt-in: the background branch beside the foreground's passes on a side stream (the foreground's passes are whole rounds of
         # workgroups, the background's partial rounds run inside them).  Measured at 1024 rays: fp32 render 488 K -> 508 K rays/s, the
         # split-precision render unchanged (1.27 M).  Off by default: with it every per-launch duration of the MLP kernel is an

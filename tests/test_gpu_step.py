@@ -191,10 +191,13 @@ def test_generated_random_numbers_are_uniform_and_keyed():
 
 @pytest.mark.parametrize('name,split', [('render_fgbg_eval', False), ('render_fgbg_eval', True), ('render_default_samples_eval', False),
                                         ('render_default_samples_eval', True), ('render_sh2_eval', False), ('render_sh3_eval', False),
-                                        ('render_w512_eval', False)])
+                                        ('render_w512_eval', False),
+                                        # merged containers: route -> all cells in one launch -> blend inside the same call (mega_nerf.py:19-61)
+                                        ('render_container_eval', False), ('render_container8_eval', False), ('render_container25_eval', False),
+                                        ('render_container_w512_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
-    """mnr_render_fwd (six launches) against the stage-by-stage render -- identical outputs, bit for bit, for the fp32 kernels --
-    and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
+    """mnr_render_fwd (six launches; routed containers: seventeen) against the stage-by-stage render -- identical outputs, bit for bit, for
+    the fp32 kernels -- and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
     from mega_nerf import rendering as R
     g = load(name)
     hp, nerf, bg_nerf = native_models(name)
@@ -215,6 +218,17 @@ def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
         a, b = fused[k].cpu().numpy(), g['res_' + k]
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-5, err_msg=k)
         np.testing.assert_array_equal(a, stage[k].cpu().numpy(), err_msg=k)
+
+
+def test_cluster_2d_containers_stay_on_the_stage_by_stage_path():
+    """Under cluster_2d the background is routed per SAMPLE on the true far-away point (rendering.py:459-461): not what the one-call
+    render's per-ray routing position covers, so it must decline (and the stage-by-stage render serves the fixture)."""
+    from mega_nerf import rendering as R
+    name = 'render_container_2d_eval'
+    g = load(name)
+    hp, nerf, bg_nerf = native_models(name)
+    hpn = Namespace(**vars(hp))
+    assert not R._fused_render_ok(nerf, bg_nerf, hpn, T(g['idx'].astype(f32)), T(common.SCENE['sphere_radius']), False, {})
 
 
 def test_fused_render_benchmark_shape_all_rays():
