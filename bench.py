@@ -768,7 +768,7 @@ def run_config(args, rank, world, dev, dist):
 
     steppers, trainers = [], []
     fused = None
-    if args.mode == 'train' and not wide:
+    if args.mode == 'train' and (not wide or (args.layer_dim == 512 and args.sh_deg is None)):
         # every cell this rank owns goes through ONE mnr_train_step call per step (csrc/step.hip): 12 kernel launches + a memset for the
         # whole iteration, the cells' rows side by side in the MLP launches
         from mega_nerf.training import FusedTrainStep, fused_step_supported

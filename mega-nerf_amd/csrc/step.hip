@@ -109,12 +109,18 @@ struct StepWs {
     size_t tab_cells, tab_pack, tab_adam, t_c, t_bc, t_f, t_bf;
     size_t dd_fc, dd_ff, dd_bc, dd_bf;        // spherical-harmonics models: dL/d(dir_a output) of the four (branch, pass) row sets [rows][W/2]
     size_t sticky;                            // int32 [MAXC]: health bits that survive the per-step memset (cleared by mnr_step_create)
+    // 512-wide foreground (Building, README "Larger models"): buffers of its tiled backward, one (cell, pass) at a time -- zero-padded
+    // [position embedding] / [direction | appearance] input planes, head / layer gradients, the zero-padded copies of the two weight
+    // matrices whose hidden-input columns do not start 16-byte aligned (skip layer, dir_a layer), the weight-gradient job workspace
+    size_t w_emb, w_side, w_grgb, w_dsrc, w_dapp, w_gsig, w_df, w_dh[8], w_wskip, w_wdir, w_wgws;
     size_t grad_stride, total;
 };
 struct StepDims {
     long C, N, Nc, Nf, Sb, Sfb, cap_f, cap_b, fpr_f, fpr_b;
     int sh_deg;        // >= 0: spherical-harmonics colour head (rgb_dim = 3 (sh_deg + 1)^2, no direction encoding); -1: the plain rgb head
+    int wide;          // foreground 8 x 512 (forward: the wavefront-pair kernel; backward: tiled GEMMs + weight-gradient jobs, csrc/tgemm.hip / wgrad.hip)
 };
+constexpr int WIDE_EP = 96, WIDE_SP = 96;       // pitches of the zero-padded [75 embedding] and [27 direction + 48 appearance] input planes
 
 static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mnr_model_desc *bg, StepDims &D) {
     MNR_REQUIRE(cfg && fg && bg, "NULL argument");
@@ -131,8 +137,9 @@ static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mn
     D.cap_f = D.N * (D.Nc + D.Nf); D.cap_b = D.N * (D.Sb + D.Sfb);
     D.fpr_f = mnr_tape_floats_per_row(fg); D.fpr_b = mnr_tape_floats_per_row(bg);
     if (D.fpr_f <= 0 || D.fpr_b <= 0) return set_err(MNR_E_UNSUPPORTED, "no training kernels for this architecture");
+    D.wide = fg->layer_dim == 512 ? 1 : 0;
     const bool trunk = fg->xyz_dim == 3 && bg->xyz_dim == 4 && fg->pos_xyz_dim == 12 && bg->pos_xyz_dim == 12 && fg->appearance_dim == 48 &&
-                       bg->appearance_dim == 48 && fg->layer_dim == 256 && bg->layer_dim == 256 && fg->layers == 8 && bg->layers == 8 &&
+                       bg->appearance_dim == 48 && (fg->layer_dim == 256 || fg->layer_dim == 512) && bg->layer_dim == 256 && fg->layers == 8 && bg->layers == 8 &&
                        fg->skip_mask == 16 && bg->skip_mask == 16 && (fg->mfma_tile == 0 || fg->mfma_tile == 16) &&
                        (bg->mfma_tile == 0 || bg->mfma_tile == 16);
     const bool plain = fg->pos_dir_dim == 4 && bg->pos_dir_dim == 4 && fg->rgb_dim == 3 && bg->rgb_dim == 3;
@@ -142,6 +149,7 @@ static int step_dims(const mnr_step_cfg *cfg, const mnr_model_desc *fg, const mn
     if (!trunk || !(plain || sh))
         return set_err(MNR_E_UNSUPPORTED, "the fused step covers the default 8x256 foreground / background models and their sh_deg 2 / 3 forms");
     if (sh && cfg->split_precision) return set_err(MNR_E_UNSUPPORTED, "no split-precision kernels for the spherical-harmonics colour head");
+    if (D.wide && (sh || cfg->split_precision)) return set_err(MNR_E_UNSUPPORTED, "the 512-wide foreground runs on the fp32 kernels with the plain rgb head");
     D.sh_deg = !sh ? -1 : (fg->rgb_dim == 27 ? 2 : 3);
     return MNR_OK;
 }
@@ -179,6 +187,16 @@ static void step_layout(const mnr_step_cfg *cfg, const StepDims &D, StepWs &L) {
     L.dd_fc = L.dd_ff = L.dd_bc = L.dd_bf = 0;
     if (D.sh_deg >= 0) {
         L.dd_fc = take(CN * D.Nc * 128 * 4); L.dd_ff = take(CN * D.Nf * 128 * 4); L.dd_bc = take(CN * D.Sb * 128 * 4); L.dd_bf = take(CN * D.Sfb * 128 * 4);
+    }
+    L.w_emb = L.w_side = L.w_grgb = L.w_dsrc = L.w_dapp = L.w_gsig = L.w_df = L.w_wskip = L.w_wdir = L.w_wgws = 0;
+    for (size_t &o : L.w_dh) o = 0;
+    if (D.wide) {
+        const size_t B = (size_t)N * (D.Nc > D.Nf ? D.Nc : D.Nf);
+        L.w_emb = take(B * WIDE_EP * 4); L.w_side = take(B * WIDE_SP * 4); L.w_grgb = take(B * 4 * 4); L.w_dsrc = take(B * 256 * 4);
+        L.w_dapp = take(B * 48 * 4); L.w_gsig = take(B * 4); L.w_df = take(B * 512 * 4);
+        for (size_t &o : L.w_dh) o = take(B * 512 * 4);
+        L.w_wskip = take((size_t)C * 512 * (WIDE_EP + 512) * 4); L.w_wdir = take((size_t)C * 256 * (512 + WIDE_SP) * 4);
+        L.w_wgws = take(mnr_wgrad_workspace_bytes());
     }
     L.total = off;
 }
@@ -955,11 +973,34 @@ static int adam_tensors_of(const mnr_step_model &M, const int32_t *gate, std::ve
     return MNR_OK;
 }
 
+// 512-wide foreground: the zero-padded copies of the two weight matrices whose hidden-input block does not start on a 16-byte boundary in
+// nn.Linear's layout -- skip layer [512][75 + 512] -> [512][96 + 512], dir_a layer [256][512 + 75] -> [256][512 + 96] -- which the tiled
+// data-gradient GEMMs address (models/layerwise.py keeps the same copies); refreshed behind every optimiser step
+static int wide_refresh_weights(mnr_step_plan *p, hipStream_t s) {
+    if (!p->D.wide) return MNR_OK;
+    const int C = (int)p->D.C;
+    bool ok = true;
+    for (int c = 0; c < C; ++c) {
+        const mnr_model_desc &d = p->models[2 * c].desc;
+        float *wskip = reinterpret_cast<float *>(p->ws + p->L.w_wskip) + (size_t)c * 512 * (WIDE_EP + 512);
+        float *wdir = reinterpret_cast<float *>(p->ws + p->L.w_wdir) + (size_t)c * 256 * (512 + WIDE_SP);
+        const float *w4 = d.layer_w[4];
+        const size_t dp = (size_t)(WIDE_EP + 512) * 4, sp = (size_t)(75 + 512) * 4;
+        ok = ok && hipMemcpy2DAsync(wskip, dp, w4, sp, 75 * 4, 512, hipMemcpyDeviceToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpy2DAsync(wskip + WIDE_EP, dp, w4 + 75, sp, 512 * 4, 512, hipMemcpyDeviceToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpy2DAsync(wdir, (size_t)(512 + WIDE_SP) * 4, d.dir_a_w, (size_t)(512 + 75) * 4, (512 + 75) * 4, 256, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    }
+    if (!ok) return set_err(MNR_E_LAUNCH, "wide_refresh_weights: %s", hipGetErrorString(hipGetLastError()));
+    return MNR_OK;
+}
+
 extern "C" int mnr_step_repack(mnr_step_plan *p, void *stream) {
     MNR_REQUIRE(p, "NULL plan");
     hipLaunchKernelGGL(k_step_pack, dim3((unsigned)p->pack_blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const PackJob *>(p->ws + p->L.tab_pack), p->n_pack_jobs, 0);
-    return check_launch("k_step_pack");
+    int rc = check_launch("k_step_pack");
+    if (rc) return rc;
+    return wide_refresh_weights(p, as_stream(stream));
 }
 
 extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, const mnr_step_model *models, void *workspace_dev,
@@ -998,7 +1039,8 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
                 return fail(set_err(MNR_E_INVALID, "mnr_step_create: every cell must have the architecture of cell 0"));
             const bool split = cfg->split_precision != 0;
             void *img_f = split ? M.packed_h2_dev : M.packed_dev, *img_b = split ? M.packed_bwd_h2_dev : M.packed_bwd_dev;
-            if (!img_f || !img_b || !d.embedding_a || !M.grad.embedding_a)
+            const bool wide_fg = D.wide && k == 0;          // (its backward reads the nn.Linear weights themselves: no transposed image)
+            if (!img_f || (!img_b && !wide_fg) || !d.embedding_a || !M.grad.embedding_a)
                 return fail(set_err(MNR_E_INVALID, "mnr_step_create: cell %d: packed image / embedding pointers missing", c));
             const char *g0 = ws + L.grads + (size_t)c * L.grad_stride;
             const char *ge = g0 + (size_t)cfg->grad_floats_per_cell * 4;
@@ -1006,7 +1048,7 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
             if (gp < g0 || gp >= ge) return fail(set_err(MNR_E_INVALID, "mnr_step_create: cell %d: gradients must live in the workspace's gradient area", c));
             ModelLayout ml;
             BwdLayout bl;
-            if ((rc = layout_from_desc(&d, ml)) != MNR_OK || (rc = bwd_layout_from_desc(&d, bl)) != MNR_OK) return fail(rc);
+            if ((rc = layout_from_desc(&d, ml)) != MNR_OK || (!wide_fg && (rc = bwd_layout_from_desc(&d, bl)) != MNR_OK)) return fail(rc);
             PackJob jf{};
             jf.m = ml; jf.chunks = reinterpret_cast<float4 *>(img_f);
             if (split) {
@@ -1021,18 +1063,22 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
             jf.block0 = pack_blocks;
             pack_blocks += jf.nblocks;
             jobs.push_back(jf);
-            PackJob jb{};
-            jb.kind = split ? 3 : 1; jb.b = bl; jb.chunks = reinterpret_cast<float4 *>(img_b);
-            jb.block0 = pack_blocks;
-            jb.nblocks = split ? ((long)h2b_total_chunks(bl) * H2_CHUNK_U4 + 255) / 256 : ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
-            pack_blocks += jb.nblocks;
-            jobs.push_back(jb);
+            const size_t jfi = jobs.size() - 1;
             // background models are stepped only on batches with background rays (runner.py:268-272): gated on the cell's device-side count
             const int32_t *gate = k == 1 ? reinterpret_cast<const int32_t *>(ws + L.scal) + c : nullptr;
-            jobs[jobs.size() - 2].gate = jobs[jobs.size() - 1].gate = gate;
-            jobs[jobs.size() - 2].steps = M.adam_steps_dev;
+            if (!wide_fg) {
+                PackJob jb{};
+                jb.kind = split ? 3 : 1; jb.b = bl; jb.chunks = reinterpret_cast<float4 *>(img_b);
+                jb.block0 = pack_blocks;
+                jb.nblocks = split ? ((long)h2b_total_chunks(bl) * H2_CHUNK_U4 + 255) / 256 : ((long)bl.total_chunks * CHUNK_F4 + 255) / 256;
+                pack_blocks += jb.nblocks;
+                jb.gate = gate;
+                jobs.push_back(jb);
+            }
+            jobs[jfi].gate = gate;
+            jobs[jfi].steps = M.adam_steps_dev;
             if (k == 0) {
-                PackJob &jf0 = jobs[jobs.size() - 2];
+                PackJob &jf0 = jobs[jfi];
                 jf0.loss = reinterpret_cast<const float *>(ws + L.loss) + c;
                 jf0.err = reinterpret_cast<const int32_t *>(ws + L.scal) + MAXC + c;
                 jf0.sticky = reinterpret_cast<int32_t *>(ws + L.sticky) + c;
@@ -1069,13 +1115,16 @@ extern "C" int mnr_step_create(mnr_step_plan **out, const mnr_step_cfg *cfg, con
     up(L.t_f, plan->tables.data() + D.Nc + D.Sb, D.Nf * 4);
     up(L.t_bf, plan->tables.data() + D.Nc + D.Sb + D.Nf, D.Sfb * 4);
     ok = ok && hipMemsetAsync(ws + L.sticky, 0, MAXC * 4, s) == hipSuccess;
+    if (D.wide)      // the pad columns of the weight copies and of the two input planes stay zero from here on (only valid columns are rewritten)
+        ok = ok && hipMemsetAsync(ws + L.w_emb, 0, L.w_grgb - L.w_emb, s) == hipSuccess &&
+             hipMemsetAsync(ws + L.w_wskip, 0, L.w_wgws - L.w_wskip, s) == hipSuccess;
     // the host vectors above die with this scope: the copies must have left them
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return fail(set_err(MNR_E_LAUNCH, "mnr_step_create: table upload failed: %s", hipGetErrorString(hipGetLastError())));
     // Measured on the benchmark step: split-precision step 3.36 -> 3.21 ms; fp32 step 6.39 -> 6.35 ms (its foreground passes are longer,
     // the partial rounds weigh less) -- within the box-to-box spread, and it would make every per-launch duration of the forward
     // kernel an overlapped one, so the fp32 step keeps one stream unless MNR_STEP_TWO_STREAMS is set.
-    if (C == 1 && !getenv("MNR_STEP_ONE_STREAM") && (cfg->split_precision || getenv("MNR_STEP_TWO_STREAMS"))) {
+    if (C == 1 && !D.wide && !getenv("MNR_STEP_ONE_STREAM") && (cfg->split_precision || getenv("MNR_STEP_TWO_STREAMS"))) {
         const char *mode = getenv("MNR_STEP_TWO_STREAMS");
         plan->fork_after_coarse = mode && mode[0] == '2';
         // (failure to get the side stream is not an error: the step then runs its two branches in one launch each, as multi-cell plans do)
@@ -1124,6 +1173,121 @@ extern "C" int mnr_step_kernel_times(mnr_step_plan *p, int slot, float *ms_out) 
         const hipEvent_t a = p->events[base + p->ev_alias[base + 2 * i]], b = p->events[base + p->ev_alias[base + 2 * i + 1]];
         if (hipEventElapsedTime(&ms_out[i], a, b) != hipSuccess) { (void)hipGetLastError(); ms_out[i] = -1.f; }
     }
+    return MNR_OK;
+}
+
+// Backward of the 512-wide foreground model over the rows of one (cell, pass): the adjoint of nerf.py:115-160 layer by layer, as
+// models/layerwise.py::LayerwiseTape.backward sequences it from Python -- head adjoints (k_act_grad / k_gemm / k_col_sum), the data
+// gradients as tiled GEMMs with the ReLU gate and the sigma head's rank-1 term fused (k_tgemm), every layer's weight gradient as jobs of
+// the batched kernel (k_wgrad2<1>, two launches per call), the appearance-embedding gradient scattered per ray -- all enqueued from here,
+// on the step's own workspace, with no host read.  Gradients ACCUMULATE into the cell's gradient area (zeroed by the step's memset).
+static int wide_fg_backward(mnr_step_plan *p, int c, int pass, int idx_is_float, hipStream_t s) {
+    const StepDims &D = p->D;
+    const StepWs &L = p->L;
+    char *ws = p->ws;
+    void *st = reinterpret_cast<void *>(s);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    const mnr_step_model &M = p->models[2 * c];
+    const mnr_model_desc &d = M.desc;
+    const mnr_model_grads &G = M.grad;
+    const long S = pass ? D.Nf : D.Nc, B = D.N * S, capT = D.C * D.cap_f, t0 = (long)c * D.cap_f + (pass ? D.N * D.Nc : 0);
+    constexpr int W = 512, H2 = 256, E = 75, ED = 27, A = 48, Ep = WIDE_EP, Sp = WIDE_SP;
+    const TapeLayout tl = tape_layout(ArchDims{d.xyz_dim, d.pos_xyz_dim, d.pos_dir_dim, d.layers, d.skip_mask, d.layer_dim, d.appearance_dim, d.rgb_dim, d.mfma_tile});
+    const float *tape = F(L.tape_f);
+    auto plane = [&](int off, int width) { return tape + (long)off * capT + t0 * width; };
+    const float *hs[8];
+    for (int l = 0; l < 8; ++l) hs[l] = plane(tl.act_off[l], W);
+    const float *fin = plane(tl.fin_off, W), *dact = plane(tl.dact_off, H2);
+    const float *out = F(pass ? L.raw_f : L.raw_c) + (long)c * B * 4, *d_out = F(pass ? L.draw_f : L.draw_c) + (long)c * B * 4;
+    float *emb = F(L.w_emb), *side = F(L.w_side), *g_rgb = F(L.w_grgb), *d_src = F(L.w_dsrc), *d_app = F(L.w_dapp), *g_sig = F(L.w_gsig), *d_f = F(L.w_df);
+    const float *xyz = F(pass ? L.xyz_f : L.xyz_c) + (long)c * B * 3, *dirs = F(L.rays) + (long)c * D.N * 8 + 3;
+    const void *idx = ws + L.idx + (size_t)c * D.N * 4;
+    const float *wskip = F(L.w_wskip) + (size_t)c * W * (Ep + W), *wdir = F(L.w_wdir) + (size_t)c * H2 * (W + Sp);
+    int rc;
+#define WIDE_OK(call) do { if ((rc = (call)) != MNR_OK) return rc; } while (0)
+    // the two zero-padded input planes the weight-gradient jobs read (pad columns were zeroed when the plan was made)
+    WIDE_OK(mnr_embed(emb, Ep, xyz, 3, 3, d.pos_xyz_dim, 1, B, st));
+    WIDE_OK(mnr_embed(side, Sp, dirs, 8, 3, d.pos_dir_dim, S, B, st));
+    WIDE_OK(mnr_gather_rows(side + ED, Sp, d.embedding_a, A, d.appearance_count, idx, 1, idx_is_float, S, B, st));
+    // weight-gradient jobs: dW[256 m .. ][col0 + 256 n ..] += dZ[:, 256 m ..]^T . X[:, 256 n ..] (+ db from the first job of an output half)
+    mnr_wgrad_job jobs[MNR_WGRAD_MAX_JOBS];
+    int nj = 0;
+    auto flush = [&]() -> int {
+        if (nj == 0) return MNR_OK;
+        const int r2 = mnr_wgrad_jobs(jobs, nj, B, ws + L.w_wgws, mnr_wgrad_workspace_bytes(), st);
+        nj = 0;
+        return r2;
+    };
+    struct Part { const float *x; long ldx; int cols, col0; };
+    auto wgrad = [&](float *gw, long ldw, float *gb, const float *dz, long ldz, int n_out, const Part *parts, int n_parts) -> int {
+        for (int mh = 0; mh < n_out / 256; ++mh) {
+            float *db = gb + 256 * mh;
+            for (int q = 0; q < n_parts; ++q) {
+                const Part &P = parts[q];
+                const bool wide_in = P.ldx > 128;
+                for (int nh = 0; nh < (wide_in ? P.cols / 256 : 1); ++nh) {
+                    if (nj == MNR_WGRAD_MAX_JOBS) { const int r2 = flush(); if (r2) return r2; }
+                    mnr_wgrad_job &j = jobs[nj++];
+                    j.dz = dz + 256 * mh; j.ldz = ldz;
+                    j.in = P.x + 256 * nh; j.ldin = P.ldx;
+                    j.in_cols = wide_in ? 256 : P.cols; j.in_block = wide_in ? 256 : (int)P.ldx;
+                    j.dw = gw + (long)256 * mh * ldw + P.col0 + 256 * nh; j.ldw = ldw;
+                    j.db = db; db = nullptr;
+                }
+            }
+        }
+        return MNR_OK;
+    };
+    auto dgrad_t = [&](float *dX, const float *Gz, long ldg, int n_out, const float *wt, long ldw, int k_in, const float *gate, const float *r1_row, const float *r1_col) -> int {
+        mnr_tgemm g{};
+        g.a[0] = Gz; g.lda[0] = ldg; g.b[0] = wt; g.ldb[0] = ldw; g.k[0] = n_out;
+        g.n_phases = 1; g.b_kslow = 1;
+        g.c = dX; g.ldc = k_in; g.m = B; g.n = k_in;
+        if (gate) { g.gate = gate; g.ldgate = k_in; }
+        if (r1_row) { g.r1_row = r1_row; g.r1_stride = 1; g.r1_col = r1_col; }
+        return mnr_tgemm_run(&g, st);
+    };
+    // ---- rgb head: sigmoid adjoint, weight / bias gradients, data gradient through rgb.weight, ReLU adjoint of the dir_a output ----
+    WIDE_OK(mnr_act_grad(g_rgb, 3, d_out, 4, out, 4, B, 3, 2, st));
+    WIDE_OK(mnr_gemm(G.rgb_w, H2, g_rgb, 1, 3, dact, 1, H2, 3, H2, B, 1, 0, st));
+    WIDE_OK(mnr_col_sum(G.rgb_b, g_rgb, 3, B, 3, st));
+    WIDE_OK(mnr_gemm(d_src, H2, g_rgb, 3, 1, d.rgb_w, 1, H2, B, H2, 3, 0, 1, st));
+    WIDE_OK(mnr_act_grad(d_src, H2, d_src, H2, dact, H2, B, H2, 1, st));
+    // ---- dir_a layer ----
+    {
+        const Part parts[2] = {{fin, W, W, 0}, {side, Sp, ED + A, W}};
+        WIDE_OK(wgrad(G.dir_a_w, W + ED + A, G.dir_a_b, d_src, H2, H2, parts, 2));
+    }
+    WIDE_OK(mnr_gemm(d_app, A, d_src, H2, 1, d.dir_a_w + W + ED, 1, W + ED + A, B, A, H2, 0, 1, st));
+    WIDE_OK(mnr_scatter_rows(G.embedding_a, A, d.appearance_count, idx, 1, idx_is_float, S, d_app, A, B, st));
+    WIDE_OK(dgrad_t(d_f, d_src, H2, H2, wdir, W + Sp, W, nullptr, nullptr, nullptr));
+    // ---- xyz_encoding_final + sigma head ----
+    {
+        const Part parts[1] = {{hs[7], W, W, 0}};
+        WIDE_OK(wgrad(G.final_w, W, G.final_b, d_f, W, W, parts, 1));
+    }
+    WIDE_OK(mnr_act_grad(g_sig, 1, d_out + 3, 4, out + 3, 4, B, 1, d.sigma_activation ? 3 : 1, st));
+    WIDE_OK(mnr_gemm(G.sigma_w, W, g_sig, 1, 1, hs[7], 1, W, 1, W, B, 1, 0, st));
+    WIDE_OK(mnr_col_sum(G.sigma_b, g_sig, 1, B, 1, st));
+    float *d_h = F(L.w_dh[0]);
+    WIDE_OK(dgrad_t(d_h, d_f, W, W, d.final_w, W, W, hs[7], g_sig, d.sigma_w));
+    // ---- trunk, last layer first: d_h already carries the ReLU adjoint of layer i's output ----
+    for (int i = 7; i >= 0; --i) {
+        const bool has_emb = i == 0 || ((d.skip_mask >> i) & 1);
+        Part parts[2];
+        int np = 0;
+        if (has_emb) parts[np++] = Part{emb, Ep, E, 0};
+        if (i > 0) parts[np++] = Part{hs[i - 1], W, W, has_emb ? E : 0};
+        WIDE_OK(wgrad(G.layer_w[i], (has_emb ? E : 0) + (i > 0 ? W : 0), G.layer_b[i], d_h, W, W, parts, np));
+        if (i > 0) {
+            float *nxt = F(L.w_dh[8 - i]);
+            const float *wt = has_emb ? wskip + Ep : d.layer_w[i];
+            WIDE_OK(dgrad_t(nxt, d_h, W, W, wt, has_emb ? Ep + W : W, W, hs[i - 1], nullptr, nullptr));
+            d_h = nxt;
+        }
+    }
+    WIDE_OK(flush());
+#undef WIDE_OK
     return MNR_OK;
 }
 
@@ -1218,6 +1382,23 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         seg[1].tape_dev = F(L.tape_b); seg[1].tape_rows = capT_b; seg[1].tape_row0 = 0;
         const CellTable ct[2] = {{tabs + (0 + pass) * C, D.N * Sf}, {tabs + (2 + pass) * C, D.N * Sbb}};
         const int first = branch == 2 ? 1 : 0, n = branch == 0 ? 2 : 1;
+        if (D.wide) {
+            // 512-wide foreground: the tape-writing wavefront-pair kernel, one launch per cell (csrc/mlp_fwd_pair.hip); the 256-wide
+            // background cells as the two-model kernel's background segment alone
+            int rc2 = mlp_forward_multi_impl(seg + 1, 1, ct + 1, st);
+            for (int c = 0; c < C && rc2 == MNR_OK; ++c) {
+                const mnr_step_model &Mc = p->models[2 * c];
+                mnr_mlp_io ic = io[0];
+                ic.xyz = io[0].xyz + (long)c * D.N * Sf * 3; ic.dir = io[0].dir + (long)c * D.N * 8;
+                ic.idx = reinterpret_cast<const char *>(io[0].idx) + (long)c * D.N * 4;
+                if (ic.sigma_noise) ic.sigma_noise = io[0].sigma_noise + (long)c * D.N * Sf;
+                ic.out = io[0].out + (long)c * D.N * Sf * 4; ic.n_rows = D.N * Sf;
+                ModelLayout ml;
+                if ((rc2 = layout_from_desc(&Mc.desc, ml)) != MNR_OK) break;
+                rc2 = mlp_forward_pair_dispatch(ml, Mc.packed_dev, &Mc.desc, &ic, st, nullptr, 0, F(L.tape_f), capT_f, (long)c * D.cap_f + (pass ? D.N * D.Nc : 0));
+            }
+            return rc2;
+        }
         return split ? mlp_forward_multi_h2_impl(seg + first, n, ct + first, st) : mlp_forward_multi_impl(seg + first, n, ct + first, st);
     };
     auto mid = [&](long unit0, long unit1, hipStream_t st) -> int {
@@ -1364,8 +1545,15 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
                 seg[i].desc = &M.desc; seg[i].io = &g[i];
                 ct[i] = CellTable{tabs + i * C, D.N * S};
             }
-        rc = split ? mlp_backward_chain_multi_h2_impl(seg, 4, ct, s) : mlp_backward_chain_multi_impl(seg, 4, ct, s);
-        if (rc) return rc;
+        if (D.wide) {
+            if ((rc = mlp_backward_chain_multi_impl(seg + 2, 2, ct + 2, s))) return rc;
+            for (int c = 0; c < C; ++c)
+                for (int pass = 0; pass < 2; ++pass)
+                    if ((rc = wide_fg_backward(p, c, pass, batches[0].idx_is_float, s))) return rc;
+        } else {
+            rc = split ? mlp_backward_chain_multi_h2_impl(seg, 4, ct, s) : mlp_backward_chain_multi_impl(seg, 4, ct, s);
+            if (rc) return rc;
+        }
     }
     mark2(5, 6);
     // ---- head gradients: per cell one dense foreground job + two device-counted background jobs ----
@@ -1378,6 +1566,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         for (int c = 0; c < C; ++c) {
             const mnr_model_grads &Gf = p->models[2 * c].grad, &Gb = p->models[2 * c + 1].grad;
             const long bf = (D.cap_f + 767) / 768;
+            if (!D.wide)      // (wide foreground: its head gradients are part of wide_fg_backward)
             jobs.push_back(HeadJob{F(L.dheads_f), F(L.tape_f) + (long)tlf.act_off[M0f.desc.layers - 1] * capT_f, F(L.tape_f) + (long)tlf.dact_off * capT_f,
                                    c * D.cap_f, D.cap_f, nullptr, 0, (int)(bf > 256 ? 256 : bf), Gf.sigma_w, Gf.sigma_b, D.sh_deg >= 0 ? nullptr : Gf.rgb_w,
                                    D.sh_deg >= 0 ? nullptr : Gf.rgb_b});
@@ -1404,7 +1593,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
         rg[1].grad = Mb.grad;
         int32_t *ctl = reinterpret_cast<int32_t *>(ws + L.wcount + (size_t)c * 256);
         const int32_t *zexp[2] = {ctl + 32, ctl + 48};
-        rc = wgrad_regions_launch(rg, 2, ctl, reinterpret_cast<int32_t *>(ws + L.ep_job + (size_t)c * wgrad_ep_job_bytes()), F(L.slab), s,
+        rc = wgrad_regions_launch(rg + (D.wide ? 1 : 0), D.wide ? 1 : 2, ctl, reinterpret_cast<int32_t *>(ws + L.ep_job + (size_t)c * wgrad_ep_job_bytes()), F(L.slab), s,
                                   split && !getenv("MNR_STEP_F32_WGRAD") ? zexp : nullptr);
         if (rc) return rc;
     }
@@ -1421,6 +1610,7 @@ extern "C" int mnr_train_step(mnr_step_plan *p, const mnr_step_batch *batches, c
     hipLaunchKernelGGL(k_step_pack, dim3((unsigned)p->pack_blocks), dim3(256), 0, s, reinterpret_cast<const PackJob *>(ws + L.tab_pack),
                        p->n_pack_jobs, 1);
     rc = check_launch("k_step_pack");
+    if (rc == MNR_OK) rc = wide_refresh_weights(p, s);
     mark(8, 1);
     return rc;
 }

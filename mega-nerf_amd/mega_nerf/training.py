@@ -733,7 +733,16 @@ def fused_step_supported(nerf, bg_nerf, hparams, n_rays: int, split_precision: b
     if sh:
         if hparams.sh_deg not in (2, 3) or split_precision or not (nerf.is_sh_arch(hparams.sh_deg) and bg_nerf.is_sh_arch(hparams.sh_deg)):
             return False
-    elif hparams.sh_deg is not None or not (_fast_path_ok(nerf, bg_nerf, hparams) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
+    elif hparams.sh_deg is not None:
+        return False
+    elif nerf.is_wide_default_arch():
+        # the Building shape (README "Larger models": 512-wide foreground, 256-wide background): forward on the wavefront-pair kernel, backward
+        # as tiled GEMMs + weight-gradient jobs sequenced inside the step (csrc/step.hip wide_fg_backward); fp32 kernels only
+        if split_precision or os.environ.get('MNR_NO_PAIR_KERNEL') or os.environ.get('MNR_NO_WIDE_FUSED_STEP'):
+            return False
+        if not (bg_nerf.is_default_arch() and bg_nerf.fused_train_supported() and nerf.affine is None and nerf.embedding_a is not None):
+            return False
+    elif not (_fast_path_ok(nerf, bg_nerf, hparams) and nerf.is_default_arch() and bg_nerf.is_default_arch()):
         return False
     if nerf.xyz_dim != 3 or bg_nerf.xyz_dim != 4 or hparams.container_path is not None or hparams.train_mega_nerf is not None:
         return False
@@ -839,6 +848,10 @@ class FusedTrainStep:
                     pk = torch.empty(lib.mnr_packed_model_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
                     pb = torch.empty(lib.mnr_packed_bwd_h2_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
                     sm.packed_h2_dev, sm.packed_bwd_h2_dev = pk.data_ptr(), pb.data_ptr()
+                elif k == 0 and m.layer_dim == 512:
+                    # 512-wide foreground: no transposed image (its data gradients are tiled GEMMs over the nn.Linear weights themselves)
+                    pk, pb = torch.empty(lib.mnr_packed_model_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev), None
+                    sm.packed_dev = pk.data_ptr()
                 else:
                     pk = torch.empty(lib.mnr_packed_model_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)
                     pb = torch.empty(lib.mnr_packed_bwd_bytes(C.byref(sm.desc)), dtype=torch.uint8, device=dev)

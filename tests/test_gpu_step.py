@@ -23,9 +23,11 @@ def _grads(models):
     return {'%s.%s' % (t, k): p.grad.detach().cpu().numpy().copy() for t, m in models for k, p in m.named_parameters()}
 
 
-@pytest.mark.parametrize('name', ['render_fgbg_train', 'render_sh2_256_train', 'render_sh3_256_train', 'render_default_samples_train'])
+@pytest.mark.parametrize('name', ['render_fgbg_train', 'render_sh2_256_train', 'render_sh3_256_train', 'render_default_samples_train', 'render_w512_train'])
 def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
-    """render_fgbg_train / render_sh2_256_train / render_sh3_256_train (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0, and the
+    """render_w512_train: the Building shape (512-wide foreground, README "Larger models") -- forward on the wavefront-pair kernel, backward as
+    tiled GEMMs + weight-gradient jobs sequenced inside the step, no host read;
+    render_fgbg_train / render_sh2_256_train / render_sh3_256_train (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0, and the
     degree-3 head BASELINE.json words -- the colour head's adjoint runs in
     k_sh_head_bwd inside the step; render_default_samples_train: the default models at the reference's 256 + 512 samples per ray, the
     other instantiation of the step's ray-stage kernels) on the reference's captured random draws: loss, rgb_fine, depth variance, bg_lambda and every parameter
