@@ -20,7 +20,7 @@ file-based gather, runner.py:495-510).
     through its cells one after the other (``"scaling": "strong"``; --gpus 1 = one GPU trains all S).
 
 The line also carries: ``roofline`` (dominant kernel: live HIP-event duration of its launches, algorithmic FLOPs,
-MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r05_pmc_summary.json``), ``cpu_baseline`` (the
+MFMA-busy / HBM traffic from the committed PMC summary ``profiles/r06_pmc_summary.json``, three timed regions, the box's calibration), ``cpu_baseline`` (the
 torch-CPU restatement of the reference on this box's host cores, bounded sample), the north-star PSNR check
 (``psnr``: a student model trained for a few steps here and by the CPU restatement on identical batches and
 random numbers, both evaluated against a fixed teacher field), and (N = 1) short extra measurements: 65 536-ray
@@ -46,7 +46,7 @@ FG_FLOP_PER_SAMPLE = 1211392      # 2 x 605 696 MAC
 BG_FLOP_PER_SAMPLE = 1236992
 HEAD_FLOP_PER_SAMPLE = 2 * (256 + 3 * 128)          # sigma / rgb heads: VALU, not part of the MFMA kernels' work
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
-PMC_FILE = ROOT / 'profiles' / 'r05_pmc_summary.json'
+PMC_FILE = ROOT / 'profiles' / 'r06_pmc_summary.json'
 
 
 def build_models(hp, dev, seed, layer_dim=256):
@@ -469,6 +469,8 @@ def parse_args(argv=None):
                     help='spherical-harmonics colour head (BASELINE configs[4], configs/mega-nerf-sh-3/*.yaml: sh_deg 2, pos_dir_dim 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the N = 1 side measurements and the PSNR check')
+    ap.add_argument('--no-diag', dest='no_diag', action='store_true',
+                    help='skip the device calibration probes around the timed regions (profiling passes: keeps their kernels out of the trace)')
     ap.add_argument('--no-config-sweep', action='store_true',
                     help='skip the compact lines of the other BASELINE configs (8-cell set, container, W=512, SH) in the default run')
     ap.add_argument('--only-split-extras', action='store_true',
@@ -534,6 +536,8 @@ SWEEP = [
     ('configs[2] Rubble merged 8-cell container, routed eval', ['--container', '8', '--mode', 'eval'], 90),
     ('configs[3] Building-shaped cell (fg 8x512), train', ['--layer-dim', '512', '--mode', 'train'], 15),
     ('configs[3] Building-shaped cell (fg 8x512), eval', ['--layer-dim', '512', '--mode', 'eval'], 50),
+    # 25 Building cells on 8 GPUs = 4,3,3,...: the busiest rank's four 512-wide cells in ONE plan (what tools/train_cells.py runs per rank)
+    ('configs[3] Building: four 512-wide cells of one rank in one plan (25 cells on 8 GPUs = 4,3,3,..), train', ['--layer-dim', '512', '--submodules', '4', '--mode', 'train'], 4),
     ('configs[3] Building merged 25-cell container of 512-wide cells, routed eval', ['--layer-dim', '512', '--container', '25', '--mode', 'eval'], 30),
     ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), train', ['--sh-deg', '2', '--mode', 'train'], 50),
     ('configs[4] Sci-Art-shaped cell (sh_deg 2, pos_dir_dim 0), eval', ['--sh-deg', '2', '--mode', 'eval'], 150),

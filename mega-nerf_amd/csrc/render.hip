@@ -769,6 +769,11 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__
     // formulations agree to rounding near the scene, but not for the background's routing points under cluster_2d (rendering.py:459-461:
     // o + d * depth_real with depth_real up to 1e8, quirk Q2): there |x|^2 swallows the centroid terms, every cell is equally far, hard
     // routing picks cell 0 and the blend weighs all cells alike.  That is what the reference computes, so it is what is computed here.
+    // (ASSUMPTION: `n` is this launch's whole row count.  The reference calls cdist once per model_chunk_size chunk (rendering.py:283-331), so a
+    // ragged LAST chunk of <= 25 rows with <= 25 centroids takes the direct formula there; a render's row counts are multiples of the samples
+    // per ray (>= 32), so the case cannot arise through render_rays -- only through MegaNeRF.forward on a hand-made batch of <= 25 rows,
+    // where this kernel takes the direct formula too.  The fma order of the matmul form is pinned against torch CPU / MKL, the parity
+    // target; cuBLAS sgemm on the reference's CUDA path may round differently.)
     const bool mm = n > 25 || cen.n > 25;
     float xn = 0.f;
     for (int k = d0; k < 3; ++k) xn = k == d0 ? p[k] * p[k] : xn + p[k] * p[k];

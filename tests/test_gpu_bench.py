@@ -98,7 +98,7 @@ def test_default_line_carries_every_baseline_config():
     line = _last_json(r.stdout)
     assert line['metric'].startswith('train rays/sec') and line['dtype'] == 'f32' and 0.3 < line['roofline']['frac'] < 1.0
     cfgs = {k: v for k, v in line['baseline_configs'].items() if not k.startswith('_')}
-    assert len(cfgs) == 11 and sum(k.startswith('configs[0]') for k in cfgs) == 2          # every BASELINE config, configs[0] (cascade, W = 2048) included
+    assert len(cfgs) == 12 and sum(k.startswith('configs[0]') for k in cfgs) == 2          # every BASELINE config, configs[0] (cascade, W = 2048) included
     for name, c in cfgs.items():
         assert 'error' not in c, (name, c)
         assert c['ms_per_step'] > 0 and c['rays_per_sec'] > 0 and c['frac'] is not None and 0.05 < c['frac'] < 1.0, (name, c)
