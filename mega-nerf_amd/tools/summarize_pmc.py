@@ -35,7 +35,7 @@ KERNELS = {      # summary key -> (pass mode, predicate on (kernel name, grid si
     'k_tgemm_forward_w512': ('w512', lambda n, g: 'k_tgemm<false' in n),
     'k_mlp_fwd_pair_train_w512': ('w512', lambda n, g: 'k_mlp_fwd_pair' in n and 'true>' in n),      # round 4: the one-launch forward of W = 512 training
     'k_tgemm_data_gradient_w512': ('w512', lambda n, g: 'k_tgemm<true' in n),
-    'k_wgrad2_jobs_w512': ('w512', lambda n, g: 'k_wgrad2<1>' in n),
+    'k_wgrad2_jobs_w512': ('w512', lambda n, g: 'k_wgrad2<1' in n),
     # opt-in split-precision kernels (16-bit matrix pipe, hi/lo operands)
     'k_mlp_fwd_h2_train': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'true>' in n),
     'k_mlp_fwd_h2_eval': ('split', lambda n, g: 'k_mlp_fwd_h2' in n and 'false>' in n),
