@@ -813,6 +813,14 @@ def run_config(args, rank, world, dev, dist):
     cal_before, dev_info = calibrate(dev) if diagnose else (None, {})
     # Clock-stabilised warm-up on top of the contract's `--warmup` steps: blocks of steps until two consecutive blocks agree to 1 % (cap
     # 1 s).  A fresh process starts the timed region on a chip that idled at 95 MHz a few milliseconds earlier.
+    # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed regions: one
+    # slot per step of a region, re-used by the next region (read out between regions); switched on BEFORE the stabilising steps, which
+    # then also pay every event's first-use cost (a fresh event's first record is ~1.5 us dearer: 1 % of a region when the events were made
+    # right in front of it)
+    REGIONS = 3
+    rendering.KERNEL_EVENTS = None
+    if fused is not None:
+        fused.profile(args.steps)
     stab, t_stab0, blk = [], time.perf_counter(), max(2, min(10, args.steps))
     while True:
         t = time.perf_counter()
@@ -820,16 +828,13 @@ def run_config(args, rank, world, dev, dist):
             step()
         torch.cuda.synchronize()
         stab.append((time.perf_counter() - t) / blk * 1e3)
-        if (len(stab) >= 2 and abs(stab[-1] - stab[-2]) <= 0.01 * stab[-1]) or time.perf_counter() - t_stab0 > 1.0 or len(stab) >= 50:
+        done = blk * len(stab) >= min(args.steps, 60) or fused is None          # (every profiling slot touched once)
+        if (done and len(stab) >= 2 and abs(stab[-1] - stab[-2]) <= 0.01 * stab[-1]) or time.perf_counter() - t_stab0 > 1.0 or len(stab) >= 50:
             break
-    # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed regions
-    REGIONS = 3
     rendering.KERNEL_EVENTS = ev = []
-    if fused is not None:
-        fused.profile(REGIONS * args.steps)      # HIP events on the launch stream around every kernel group of the timed steps
     ms0 = torch.cuda.memory_stats(dev)
     wait0 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
-    region_s, enq_s = [], []
+    region_s, enq_s, span_ms = [], [], {}
     with ClockSampler(dev) as clocks:
         for _r in range(REGIONS):
             # EXACTLY `--steps` steps per region, a barrier + synchronize on both sides; three disjoint regions, `ms_per_step` = their median
@@ -845,6 +850,10 @@ def run_config(args, rank, world, dev, dist):
             if dist is not None:
                 dist.barrier()
             region_s.append(time.perf_counter() - t0)
+            if fused is not None:             # this region's kernel spans (the slots are re-used by the next region)
+                for i in range(args.steps):
+                    for k, v in fused.kernel_times(i).items():
+                        span_ms.setdefault(k, []).append(v)
     wait1 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
     cal_after = calibrate(dev)[0] if diagnose else None
     rendering.KERNEL_EVENTS = None
@@ -863,11 +872,8 @@ def run_config(args, rank, world, dev, dist):
             step()
         torch.cuda.synchronize()
         rendering.FUSED_RENDER, rendering.KERNEL_EVENTS = True, None
-    span_ms, span_region = {}, []
+    span_region = []
     if fused is not None:
-        for i in range(REGIONS * args.steps):
-            for k, v in fused.kernel_times(i).items():
-                span_ms.setdefault(k, []).append(v)
         for r_ in range(REGIONS):         # the MLP forward's two launches, region by region (does a slow region show in the kernel, or around it?)
             sl = slice(r_ * args.steps, (r_ + 1) * args.steps)
             span_region.append(round((sum(span_ms['fwd_c'][sl]) + sum(span_ms['fwd_f'][sl])) / (2 * args.steps), 4))

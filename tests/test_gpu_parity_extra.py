@@ -110,6 +110,9 @@ def test_containers_of_a_pass_share_one_launch():
 
     lib = N.lib()
     try:
+        # (the stage-by-stage sequencing: the one-call routed render issues the same merged launch from inside mnr_render_fwd, where
+        # a Python-side call counter cannot see it -- tests/test_gpu_step.py compares the two paths bit for bit)
+        R.FUSED_RENDER = False
         lib.mnr_mlp_forward_cells_multi = Counting()
         merged = {k: v.cpu().numpy().copy() for k, v in render().items()}
         assert calls['n'] == 2                       # coarse pass + fine pass
@@ -118,6 +121,7 @@ def test_containers_of_a_pass_share_one_launch():
         assert calls['n'] == 2
     finally:
         R.MERGE_ROUTED = True
+        R.FUSED_RENDER = True
         lib.mnr_mlp_forward_cells_multi = real
     assert merged.keys() == single.keys()
     for k in merged:
