@@ -131,9 +131,56 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
     long m0 = (long)(t / a.n_tiles) * BM;
     int n0 = (t % a.n_tiles) * TG_BN;
     issue(0, m0, n0, 0);
+    bool landed = false;                             // the wait + barrier for this K tile was taken in front of the previous tile's epilogue
+    // ReLU gate of the tile, one bit per value (4 registers): its 8 x 16 bytes per lane and row block are REQUESTED during the tile's last
+    // RBW K tiles -- one row block per K tile, behind that K tile's DMA -- and compressed behind the next vmcnt(0) the loop takes anyway;
+    // the epilogue then starts with its stores instead of RBW dependent HBM round trips in front of them (measured at K = 512, where a
+    // tile is only 16 K tiles: see DESIGN 3c)
+    unsigned gm[RBW];
+    float4 gv[TG_FBW][4];
+    int gv_rb = -1;                                  // row block whose gate values are in flight in gv (-1: none)
+    // (the rank-1 form of the tall tile is at 256 registers without the 32 in flight: it keeps the epilogue-side loads)
+    constexpr bool CAN_AHEAD = GATE && !(R1 && RBW == 4);
+    const bool gate_ahead = CAN_AHEAD && nkt >= RBW;
+    auto gate_request = [&](int r) {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int ie = lane_e & 31, ke = lane_e >> 5;
+        const long rowc = min(m0 + (wr * RBW + r) * 32 + ie, a.M - 1);
+#pragma unroll
+        for (int f = 0; f < TG_FBW; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gv[f][g] = *reinterpret_cast<const float4 *>(a.gate + rowc * a.ldgate + n0 + (wf * TG_FBW + f) * 32 + 8 * g + 4 * ke);
+    };
+    auto gate_compress = [&]() {
+        unsigned m = 0u;
+#pragma unroll
+        for (int f = 0; f < TG_FBW; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int b0 = (f * 4 + g) * 4;
+                m |= (gv[f][g].x > 0.f ? 1u : 0u) << b0 | (gv[f][g].y > 0.f ? 1u : 0u) << (b0 + 1) |
+                     (gv[f][g].z > 0.f ? 1u : 0u) << (b0 + 2) | (gv[f][g].w > 0.f ? 1u : 0u) << (b0 + 3);
+            }
+        return m;
+    };
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) gm[r] = 0u;
     for (;;) {
-        wait_vm0();                                  // K tile (t, kti) has landed in stage s ...
-        __builtin_amdgcn_s_barrier();                // ... for every wave, and everyone is done reading stage s^1
+        if (!landed) {
+            wait_vm0();                              // K tile (t, kti) has landed in stage s ...
+            __builtin_amdgcn_s_barrier();            // ... for every wave, and everyone is done reading stage s^1
+        }
+        landed = false;
+        if constexpr (CAN_AHEAD) {
+            if (gv_rb >= 0) {                        // (uniform) the gate values requested during the previous K tile have landed
+                const unsigned m = gate_compress();
+#pragma unroll
+                for (int r = 0; r < RBW; ++r) gm[r] = r == gv_rb ? m : gm[r];
+                gv_rb = -1;
+            }
+        }
         int tn = t, ktn = kti + 1;
         const bool last_k = ktn == nkt;
         if (last_k) { tn = t + (int)gridDim.x; ktn = 0; }
@@ -141,6 +188,12 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
         const long m0n = have ? (long)(tn / a.n_tiles) * BM : m0;
         const int n0n = have ? (tn % a.n_tiles) * TG_BN : n0;
         if (have) issue(s ^ 1, m0n, n0n, ktn);
+        if constexpr (CAN_AHEAD) {
+            if (gate_ahead && kti >= nkt - RBW) {    // (uniform) behind the DMA: the loads of row block kti - (nkt - RBW)
+                gv_rb = kti - (nkt - RBW);
+                gate_request(gv_rb);
+            }
+        }
 
         const unsigned so = s ? (unsigned)TG_STAGE_BYTES : 0u;
         unsigned xs[4], ws[4];
@@ -203,6 +256,15 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
         });
 
         if (last_k) {
+            // The next tile's first K tile was requested a whole K tile ago: wait for it (and take its barrier) HERE, with nothing else
+            // outstanding, instead of at the top of the next iteration -- where the same s_waitcnt vmcnt(0) would also wait for the 32
+            // stores per lane the epilogue is about to issue (256 KB per workgroup, every CU at the same moment: the drain of that burst
+            // was exposed in front of every tile; now it hides behind the next tile's first 128 MFMAs per wavefront).
+            if (have) {
+                wait_vm0();
+                __builtin_amdgcn_s_barrier();
+                landed = true;
+            }
             // ---- epilogue: lane -> output row, register quad -> 4 consecutive features ----
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));         // keeps the address arithmetic of the epilogue out of the main loop
@@ -221,30 +283,27 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
                         colv[f][g] = *reinterpret_cast<const float4 *>(cp + n0 + (wf * TG_FBW + f) * 32 + 8 * g + 4 * ke);
             }
             float r1[RBW];
-            unsigned gm[RBW];
+            if constexpr (CAN_AHEAD) {
+                if (gate_ahead) {                    // the last row block's values were requested at the top of this K tile
+                    wait_vm0();
+                    const unsigned m = gate_compress();
+#pragma unroll
+                    for (int r = 0; r < RBW; ++r) gm[r] = r == gv_rb ? m : gm[r];
+                    gv_rb = -1;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < RBW; ++r) {
                 const long rowc = min(m0 + (wr * RBW + r) * 32 + ie, a.M - 1);
                 r1[r] = 0.f;
-                gm[r] = 0u;
                 if constexpr (R1) r1[r] = a.r1_row[rowc * a.r1_stride];
                 if constexpr (GATE) {
-                    float4 gv[TG_FBW][4];
-#pragma unroll
-                    for (int f = 0; f < TG_FBW; ++f)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            gv[f][g] = *reinterpret_cast<const float4 *>(a.gate + rowc * a.ldgate + n0 + (wf * TG_FBW + f) * 32 + 8 * g + 4 * ke);
-#pragma unroll
-                    for (int f = 0; f < TG_FBW; ++f)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int b0 = (f * 4 + g) * 4;
-                            gm[r] |= (gv[f][g].x > 0.f ? 1u : 0u) << b0 | (gv[f][g].y > 0.f ? 1u : 0u) << (b0 + 1) |
-                                     (gv[f][g].z > 0.f ? 1u : 0u) << (b0 + 2) | (gv[f][g].w > 0.f ? 1u : 0u) << (b0 + 3);
-                        }
-                    asm volatile("" : "+v"(gm[r]));          // materialise the mask HERE (LLVM would sink the compares into pass 2 and
-                    __builtin_amdgcn_sched_barrier(0);      //  keep all 128 loaded values alive); one row block's 8 loads in flight at a time
+                    if (!gate_ahead) {               // (fewer K tiles than row blocks: the gate is read here, one row block at a time)
+                        gate_request(r);
+                        gm[r] = gate_compress();
+                        asm volatile("" : "+v"(gm[r]));          // materialise the mask HERE (LLVM would sink the compares into pass 2 and
+                        __builtin_amdgcn_sched_barrier(0);      //  keep all 128 loaded values alive); one row block's 8 loads in flight at a time
+                    }
                 }
             }
             // Pass 2: arithmetic + 16-byte stores
@@ -266,6 +325,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void k_tgemm(TgArgs a) {
                                 v[c] = fmaxf(v[c], lo);
                                 if constexpr (GATE) v[c] = (gm[r] >> ((f * 4 + g) * 4 + c)) & 1u ? v[c] : 0.f;
                             }
+                            // (plain stores: the tile's 256 KB are absorbed by L2; non-temporal stores measured 0.565 -> 0.665 ms at 131072 x 512 x 512)
                             *reinterpret_cast<float4 *>(a.c + row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }
