@@ -876,6 +876,54 @@ __global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ j
     else pack_bwd_h2_thread(job.b, reinterpret_cast<uint4v *>(job.chunks), tid);
 }
 
+
+// ---- 512-wide foreground: the head adjoints of one (cell, pass) in ONE pass over its rows -------------------------------------------
+// per row r:  g_rgb = d_rgb * s (1 - s)  (sigmoid),  g_sig = d_sigma * act'(sigma)  (ReLU, or 1 - exp(-sigma) for the shifted softplus);
+//   d_src[r][j]  = dact[r][j] > 0 ? sum_c g_rgb[c] W_rgb[c][j] : 0        (data gradient through the rgb layer + ReLU adjoint of dir_a)
+//   dW_rgb[c][j] += g_rgb[c] dact[r][j],  db_rgb[c] += g_rgb[c],  dW_sigma[k] += g_sig hs7[r][k],  db_sigma += g_sig
+// (what k_act_grad x 3, k_gemm x 3 and k_col_sum x 2 did in eight launches, each re-reading a [rows][256 | 512] plane: 0.45 ms per fine
+// pass; here dact and hs7 are read once and d_src written once).  256 threads: thread j owns column j of dact / d_src and columns j,
+// j + 256 of hs7; few long blocks, one set of atomics per block (as k_head_grads).
+constexpr int WH_U = 4;              // rows in flight per iteration
+__global__ __launch_bounds__(256) void k_wide_head_adjoint(const float *__restrict__ d_out, const float *__restrict__ out, const float *__restrict__ dact,
+                                                           const float *__restrict__ hs7, const float *__restrict__ rgb_w, long B, int sigma_softplus,
+                                                           float *__restrict__ d_src, float *__restrict__ g_sig_out, float *__restrict__ d_rgb_w,
+                                                           float *__restrict__ d_rgb_b, float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b) {
+    const int j = threadIdx.x;
+    const long per = ((B + gridDim.x - 1) / gridDim.x + WH_U - 1) / WH_U * WH_U;
+    const long rb = (long)blockIdx.x * per, re = min(B, rb + per);
+    if (rb >= re) return;
+    const float w0 = rgb_w[j], w1 = rgb_w[256 + j], w2 = rgb_w[512 + j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, bs = 0.f;
+    for (long r0 = rb; r0 < re; r0 += WH_U) {
+        float4 go[WH_U], o[WH_U];
+        float x[WH_U], h0[WH_U], h1[WH_U];
+#pragma unroll
+        for (int u = 0; u < WH_U; ++u) {
+            const long r = min(r0 + u, re - 1);
+            go[u] = *reinterpret_cast<const float4 *>(d_out + r * 4);
+            o[u] = *reinterpret_cast<const float4 *>(out + r * 4);
+            x[u] = dact[r * 256 + j]; h0[u] = hs7[r * 512 + j]; h1[u] = hs7[r * 512 + 256 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < WH_U; ++u) {
+            if (r0 + u >= re) break;
+            const float g0 = go[u].x * (o[u].x * (1.f - o[u].x)), g1 = go[u].y * (o[u].y * (1.f - o[u].y)), g2 = go[u].z * (o[u].z * (1.f - o[u].z));
+            const float gs = sigma_softplus ? go[u].w * (1.f - expf(-o[u].w)) : (o[u].w > 0.f ? go[u].w : 0.f);
+            float d = g0 * w0;
+            d = fmaf(g1, w1, d);
+            d = fmaf(g2, w2, d);
+            d_src[(r0 + u) * 256 + j] = x[u] > 0.f ? d : 0.f;
+            a0 = fmaf(g0, x[u], a0); a1 = fmaf(g1, x[u], a1); a2 = fmaf(g2, x[u], a2);
+            s0 = fmaf(gs, h0[u], s0); s1 = fmaf(gs, h1[u], s1);
+            if (j == 0) { b0 += g0; b1 += g1; b2 += g2; bs += gs; g_sig_out[r0 + u] = gs; }
+        }
+    }
+    atomicAdd(d_rgb_w + j, a0); atomicAdd(d_rgb_w + 256 + j, a1); atomicAdd(d_rgb_w + 512 + j, a2);
+    atomicAdd(d_sigma_w + j, s0); atomicAdd(d_sigma_w + 256 + j, s1);
+    if (j == 0) { atomicAdd(d_rgb_b, b0); atomicAdd(d_rgb_b + 1, b1); atomicAdd(d_rgb_b + 2, b2); atomicAdd(d_sigma_b, bs); }
+}
+
 }  // namespace mnr
 
 using namespace mnr;
@@ -1247,12 +1295,22 @@ static int wide_fg_backward(mnr_step_plan *p, int c, int pass, int idx_is_float,
         if (r1_row) { g.r1_row = r1_row; g.r1_stride = 1; g.r1_col = r1_col; }
         return mnr_tgemm_run(&g, st);
     };
-    // ---- rgb head: sigmoid adjoint, weight / bias gradients, data gradient through rgb.weight, ReLU adjoint of the dir_a output ----
-    WIDE_OK(mnr_act_grad(g_rgb, 3, d_out, 4, out, 4, B, 3, 2, st));
-    WIDE_OK(mnr_gemm(G.rgb_w, H2, g_rgb, 1, 3, dact, 1, H2, 3, H2, B, 1, 0, st));
-    WIDE_OK(mnr_col_sum(G.rgb_b, g_rgb, 3, B, 3, st));
-    WIDE_OK(mnr_gemm(d_src, H2, g_rgb, 3, 1, d.rgb_w, 1, H2, B, H2, 3, 0, 1, st));
-    WIDE_OK(mnr_act_grad(d_src, H2, d_src, H2, dact, H2, B, H2, 1, st));
+    // ---- both heads in one pass over the rows: sigmoid / sigma-activation adjoints, their weight and bias gradients, the data gradient
+    // through rgb.weight with the ReLU adjoint of the dir_a output (k_wide_head_adjoint; MNR_WIDE_SEPARATE_HEADS=1: the eight launches
+    // of models/layerwise.py instead) ----
+    static const bool separate_heads = getenv("MNR_WIDE_SEPARATE_HEADS") != nullptr;
+    if (!separate_heads) {
+        const long nb = (B + 511) / 512;
+        hipLaunchKernelGGL(k_wide_head_adjoint, dim3((unsigned)(nb > 256 ? 256 : (nb < 1 ? 1 : nb))), dim3(256), 0, s, d_out, out, dact, hs[7], d.rgb_w, B,
+                           d.sigma_activation ? 1 : 0, d_src, g_sig, G.rgb_w, G.rgb_b, G.sigma_w, G.sigma_b);
+        WIDE_OK(check_launch("k_wide_head_adjoint"));
+    } else {
+        WIDE_OK(mnr_act_grad(g_rgb, 3, d_out, 4, out, 4, B, 3, 2, st));
+        WIDE_OK(mnr_gemm(G.rgb_w, H2, g_rgb, 1, 3, dact, 1, H2, 3, H2, B, 1, 0, st));
+        WIDE_OK(mnr_col_sum(G.rgb_b, g_rgb, 3, B, 3, st));
+        WIDE_OK(mnr_gemm(d_src, H2, g_rgb, 3, 1, d.rgb_w, 1, H2, B, H2, 3, 0, 1, st));
+        WIDE_OK(mnr_act_grad(d_src, H2, d_src, H2, dact, H2, B, H2, 1, st));
+    }
     // ---- dir_a layer ----
     {
         const Part parts[2] = {{fin, W, W, 0}, {side, Sp, ED + A, W}};
@@ -1266,9 +1324,11 @@ static int wide_fg_backward(mnr_step_plan *p, int c, int pass, int idx_is_float,
         const Part parts[1] = {{hs[7], W, W, 0}};
         WIDE_OK(wgrad(G.final_w, W, G.final_b, d_f, W, W, parts, 1));
     }
-    WIDE_OK(mnr_act_grad(g_sig, 1, d_out + 3, 4, out + 3, 4, B, 1, d.sigma_activation ? 3 : 1, st));
-    WIDE_OK(mnr_gemm(G.sigma_w, W, g_sig, 1, 1, hs[7], 1, W, 1, W, B, 1, 0, st));
-    WIDE_OK(mnr_col_sum(G.sigma_b, g_sig, 1, B, 1, st));
+    if (separate_heads) {
+        WIDE_OK(mnr_act_grad(g_sig, 1, d_out + 3, 4, out + 3, 4, B, 1, d.sigma_activation ? 3 : 1, st));
+        WIDE_OK(mnr_gemm(G.sigma_w, W, g_sig, 1, 1, hs[7], 1, W, 1, W, B, 1, 0, st));
+        WIDE_OK(mnr_col_sum(G.sigma_b, g_sig, 1, B, 1, st));
+    }
     float *d_h = F(L.w_dh[0]);
     WIDE_OK(dgrad_t(d_h, d_f, W, W, d.final_w, W, W, hs[7], g_sig, d.sigma_w));
     // ---- trunk, last layer first: d_h already carries the ReLU adjoint of layer i's output ----
