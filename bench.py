@@ -421,12 +421,15 @@ def calibrate(dev):
         return {'error': '%s: %s' % (type(e).__name__, e)}, {}
 
 
-def rank_devices(dev, dist, world):
-    """What each rank runs on (answers "did RCCL see N ranks on N GPUs" from the record)."""
+def rank_devices(dev, dist, world, cal=None):
+    """What each rank runs on (answers "did RCCL see N ranks on N GPUs" from the record) and, in short, what its GPU delivered right
+    before the timed regions."""
     pr = torch.cuda.get_device_properties(dev)
     me = {'rank': int(os.environ.get('RANK', 0)), 'device': dev.index, 'name': pr.name,
           'pci': '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', 0), getattr(pr, 'pci_device_id', 0)),
           'uuid': str(getattr(pr, 'uuid', '')), 'cus': pr.multi_processor_count}
+    if cal and 'error' not in cal:
+        me['cal'] = {k: cal.get(k) for k in ('mfma_f32_tflops', 'mfma_wg_ms_median', 'mfma_wg_ms_max', 'sclk_mhz_mfma_chain', 'chase_hbm_ns', 'hbm_read_gbps')}
     if dist is None:
         return {'world': 1, 'backend': None, 'ranks': [me]}
     got = [None] * world
@@ -810,7 +813,8 @@ def run_config(args, rank, world, dev, dist):
         step()
     torch.cuda.synchronize()
     diagnose = rank == 0 and not getattr(args, 'no_diag', False)
-    cal_before, dev_info = calibrate(dev) if diagnose else (None, {})
+    # (every rank calibrates its own GPU before the regions -- one slow device among N sets the max-over-ranks time --; rank 0 also after)
+    cal_before, dev_info = calibrate(dev) if not getattr(args, 'no_diag', False) else (None, {})
     # Clock-stabilised warm-up on top of the contract's `--warmup` steps: blocks of steps until two consecutive blocks agree to 1 % (cap
     # 1 s).  A fresh process starts the timed region on a chip that idled at 95 MHz a few milliseconds earlier.
     # kernel-level timing of the MLP / weight-gradient launches with HIP events recorded on the launch stream inside the timed regions: one
@@ -901,7 +905,9 @@ def run_config(args, rank, world, dev, dist):
     if blocked > 0:
         host_diag['host_blocked_ms_per_step'] = round(blocked, 3)     # (not part of host_enqueue_ms_per_step)
     n_bg = int(out[1]) if out[1] is not None else -1          # background rays in the (last cell's) batch
-    rank_info = rank_devices(dev, dist, world)
+    rank_info = rank_devices(dev, dist, world, cal_before)
+    if not diagnose:
+        cal_before = None
 
     # eval metric all-reduce (packed [sum_psnr, count]) -- the only collective of the path.  The targets of the
     # throughput batches are random colours, so this number only exercises the reduction; the PSNR that means something is

@@ -47,7 +47,7 @@ def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['steps'] == 3
     ranks = line['diag']['ranks']
     assert ranks['world'] == 2 and ranks['backend'] == 'gloo' and sorted(r_['rank'] for r_ in ranks['ranks']) == [0, 1]
-    assert all(r_['cus'] > 0 and r_['pci'] for r_ in ranks['ranks'])
+    assert all(r_['cus'] > 0 and r_['pci'] and r_['cal']['mfma_f32_tflops'] > 50 for r_ in ranks['ranks'])
     t = line['diag']['timing']
     assert len(t['regions_ms_per_step']) == 3 and t['min'] <= t['median'] <= t['max'] and abs(t['median'] - line['ms_per_step']) < 1e-3
 
