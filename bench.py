@@ -34,6 +34,11 @@ import time
 from pathlib import Path
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: required for RCCL across processes on this host driver
+# Kernel arguments in DEVICE memory (this ROCm's default; read by the HIP runtime when it initialises): with HIP_FORCE_DEV_KERNARG=0 every
+# wavefront's argument reads go to host memory -- measured here: the ray-stage kernels +4 ... +27 %, the step +0.8 % on a healthy box
+# (profiles/r06_kernarg_probe.txt), more where the host link is slow.  Pinned so that a stray setting of the launching shell cannot decide
+# the measurement; MNR_BENCH_KERNARG=0 measures the other placement.
+os.environ['HIP_FORCE_DEV_KERNARG'] = os.environ.get('MNR_BENCH_KERNARG', '1')
 
 import torch          # noqa: E402
 
@@ -1240,6 +1245,8 @@ def run_config(args, rank, world, dev, dist):
         if xcd is not None:
             diag['xcd_clocks_under_load'] = xcd
         diag['ranks'] = rank_info
+        # the runtime-relevant environment of this process (a setting of the launching shell that changes kernel behaviour shows here)
+        diag['env'] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(('HIP_', 'HSA_', 'ROCR_', 'GPU_', 'AMD_', 'ROC_', 'MNR_', 'NCCL_', 'RCCL_', 'PYTORCH_', 'OMP_NUM'))}
         line['diag'] = diag
         if roof is not None:
             # (the driver's record keeps `roofline` whole and only the tail of the rest of the line: the figures needed to tell a slow box
