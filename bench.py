@@ -336,37 +336,41 @@ def read_clocks(hw):
 
 
 class ClockSampler:
-    """Samples the hwmon files every `period` seconds on a host thread while a timed region runs (under load the files show what the
-    chip actually holds; an idle read shows 95 MHz)."""
+    """Samples the hwmon files every `period` seconds on a host thread (under load the files show what the chip actually holds; an idle
+    read shows 95 MHz).  Started BEFORE the stabilising warm-up: the thread's first reads cost the GPU ~0.7 % for a few hundred
+    milliseconds (measured: the first timed region 6.14 vs 6.09 ms when the sampler started with it); `summary(windows)` keeps the samples
+    that fall inside the timed regions."""
 
     def __init__(self, dev, period=0.04):
         import threading
-        self.hw, self.period, self.samples, self._stop = _hwmon_dir(dev), period, [], threading.Event()
+        self.hw = None if os.environ.get('MNR_BENCH_NO_SAMPLER') else _hwmon_dir(dev)
+        self.period, self.samples, self._stop = period, [], threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
             c = read_clocks(self.hw)
             if c:
-                self.samples.append(c)
+                self.samples.append((time.perf_counter(), c))
             self._stop.wait(self.period)
 
-    def __enter__(self):
+    def start(self):
         if self.hw is not None:
             self._t.start()
         return self
 
-    def __exit__(self, *a):
+    def stop(self):
         self._stop.set()
-        if self.hw is not None:
+        if self.hw is not None and self._t.is_alive():
             self._t.join()
 
-    def summary(self):
-        if not self.samples:
+    def summary(self, windows):
+        keep = [c for t, c in self.samples if any(a <= t <= b for a, b in windows)]
+        if not keep:
             return None
-        out = {'n': len(self.samples)}
-        for k in self.samples[0]:
-            v = [s_[k] for s_ in self.samples if k in s_]
+        out = {'n': len(keep)}
+        for k in keep[0]:
+            v = [s_[k] for s_ in keep if k in s_]
             out[k] = {'min': min(v), 'mean': round(sum(v) / len(v), 1), 'max': max(v)}
         return out
 
@@ -830,6 +834,7 @@ def run_config(args, rank, world, dev, dist):
     rendering.KERNEL_EVENTS = None
     if fused is not None:
         fused.profile(args.steps)
+    clocks = ClockSampler(dev).start()
     stab, t_stab0, blk = [], time.perf_counter(), max(2, min(10, args.steps))
     while True:
         t = time.perf_counter()
@@ -837,32 +842,33 @@ def run_config(args, rank, world, dev, dist):
             step()
         torch.cuda.synchronize()
         stab.append((time.perf_counter() - t) / blk * 1e3)
-        done = blk * len(stab) >= min(args.steps, 60) or fused is None          # (every profiling slot touched once)
+        done = (blk * len(stab) >= min(args.steps, 60) or fused is None) and time.perf_counter() - t_stab0 >= 0.3     # (every profiling slot touched once; the sampler's first reads behind us)
         if (done and len(stab) >= 2 and abs(stab[-1] - stab[-2]) <= 0.01 * stab[-1]) or time.perf_counter() - t_stab0 > 1.0 or len(stab) >= 50:
             break
     rendering.KERNEL_EVENTS = ev = []
     ms0 = torch.cuda.memory_stats(dev)
     wait0 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
-    region_s, enq_s, span_ms = [], [], {}
-    with ClockSampler(dev) as clocks:
-        for _r in range(REGIONS):
-            # EXACTLY `--steps` steps per region, a barrier + synchronize on both sides; three disjoint regions, `ms_per_step` = their median
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out = step()
-            enq_s.append(time.perf_counter() - t0)     # host time to ENQUEUE the timed steps (diagnostic: host-bound when ~ total)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            region_s.append(time.perf_counter() - t0)
-            if fused is not None:             # this region's kernel spans (the slots are re-used by the next region)
-                for i in range(args.steps):
-                    for k, v in fused.kernel_times(i).items():
-                        span_ms.setdefault(k, []).append(v)
+    region_s, enq_s, span_ms, windows = [], [], {}, []
+    for _r in range(REGIONS):
+        # EXACTLY `--steps` steps per region, a barrier + synchronize on both sides; three disjoint regions, `ms_per_step` = their median
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        enq_s.append(time.perf_counter() - t0)     # host time to ENQUEUE the timed steps (diagnostic: host-bound when ~ total)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        region_s.append(time.perf_counter() - t0)
+        windows.append((t0, time.perf_counter()))
+        if fused is not None:             # this region's kernel spans (the slots are re-used by the next region)
+            for i in range(args.steps):
+                for k, v in fused.kernel_times(i).items():
+                    span_ms.setdefault(k, []).append(v)
+    clocks.stop()
     wait1 = sum(getattr(t_, 'host_wait_s', 0.0) for t_ in trainers)
     cal_after = calibrate(dev)[0] if diagnose else None
     rendering.KERNEL_EVENTS = None
@@ -1239,7 +1245,7 @@ def run_config(args, rank, world, dev, dist):
                                    'nominal': {'mfma_f32_tflops': PEAK_F32_MFMA_TFLOPS, 'note': 'csrc/calibrate.hip; typical MI355X in this pool: mfma_f32_tflops ~145 '
                                                '(1 ms probe incl. clock ramp), sclk_mhz_mfma_chain 2400, dma_chunk_round_trip_us ~0.49, chase_l2 / mall / hbm ns, hbm GB/s: see '
                                                'profiles/r06_calibration_boxes.jsonl'}}
-        cl = clocks.summary()
+        cl = clocks.summary(windows)
         if cl is not None:
             diag['clocks_during_timed_regions'] = cl
         if xcd is not None:
