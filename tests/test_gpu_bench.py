@@ -140,3 +140,24 @@ def test_evaluation_renders_are_bit_reproducible():
         assert ln['renders'] == 200 and ln['renders_differing_from_the_first'] == 0 and ln['finite'], ln
     # ... and the TRAINING forward (tape-writing kernels, the feature-split tail): the same step without its optimiser, 200 times
     assert lines[4]['steps'] == 200 and lines[4]['steps_differing_from_the_first'] == 0 and lines[4]['finite'], lines[4]
+
+
+def test_device_calibration_probes():
+    """mnr_calibrate / mnr_calibrate_hog (csrc/calibrate.hip; bench.py's `diag.calibration`): every probe returns a plausible figure for an
+    MI355X, the memory hierarchy is told apart (L1 < L2 < memory-side), the per-workgroup MFMA times bracket their median, and the hog
+    (contention experiments, tools/probe_contention.py) runs to completion on a side stream."""
+    import torch
+    from mega_nerf import _native as N
+    dev = torch.device('cuda:0')
+    scr = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    N.calibrate(dev, scr)
+    c = N.calibrate(dev, scr)
+    assert c['cu_count'] >= 64 and 100 < c['mfma_f32_tflops'] < 160, c
+    assert 0 < c['mfma_wg_ms_min'] <= c['mfma_wg_ms_median'] <= c['mfma_wg_ms_max'] < 5 * c['mfma_wg_ms_median'], c
+    assert 0 < c['mfma_xcd_ms_fastest'] <= c['mfma_xcd_ms_slowest'], c
+    assert 10 < c['chase_l1_ns'] < c['chase_l2_ns'] < c['chase_mall_ns'] * 1.05 and c['chase_hbm_ns'] > c['chase_l2_ns'], c
+    assert c['dma_stream_gbps'] > 5000 and 0.05 < c['dma_chunk_round_trip_alone_us'] <= c['dma_chunk_round_trip_us'] < 20, c
+    assert c['hbm_read_gbps'] > 2000 and c['hbm_write_gbps'] > 1500 and 1500 < c['sclk_mhz_mfma_chain'] < 2700, c
+    side = torch.cuda.Stream(dev)
+    N.check(N.lib().mnr_calibrate_hog(scr.data_ptr(), 64 << 20, 8, 2, side.cuda_stream))
+    side.synchronize()
