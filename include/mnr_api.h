@@ -695,7 +695,9 @@ typedef struct mnr_side mnr_side;
 int mnr_side_create(mnr_side **out);
 void mnr_side_destroy(mnr_side *side);
 size_t mnr_render_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples);
-size_t mnr_render_route_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples, int n_cells);
+/* out_cols: columns the cells write per row -- 4, or rgb_dim + 1 for spherical-harmonics cells under a soft blend (the reference blends
+ * the RAW coefficients and evaluates eval_sh + sigmoid on the blend: mega_nerf.py:45-49, rendering.py:300-306) */
+size_t mnr_render_route_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples, int n_cells, int out_cols);
 int mnr_render_fwd(const mnr_render_io *io, void *stream);
 
 /* Kernel-level timing without a profiler (bench.py's roofline): after mnr_step_profile(plan, n) every step records HIP events on

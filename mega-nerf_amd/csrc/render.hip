@@ -865,16 +865,20 @@ __global__ void k_route_combine(float *__restrict__ out, long out_stride, const 
             for (int c = 0; c < n_cols; ++c) out[row * out_stride + c] = 0.f;
         return;
     }
-    float acc[32];
-    for (int c = 0; c < n_cols; ++c) acc[c] = 0.f;
-    for (int i = 0; i < n_sub; ++i) {
-        const int32_t p = pos[(long)i * B + row];
-        if (p < 0) continue;
-        const float w = weights ? weights[(long)i * B + row] : 1.f;
-        const float *src = sub + i * cell_stride + p * sub_stride;
-        for (int c = 0; c < n_cols; ++c) acc[c] = acc[c] + src[c] * w;
+    // (32 columns at a time: 49 = the raw outputs of an sh_deg 3 cell, blended on their coefficients)
+    for (int c0 = 0; c0 < n_cols; c0 += 32) {
+        const int nc = n_cols - c0 < 32 ? n_cols - c0 : 32;
+        float acc[32];
+        for (int c = 0; c < nc; ++c) acc[c] = 0.f;
+        for (int i = 0; i < n_sub; ++i) {
+            const int32_t p = pos[(long)i * B + row];
+            if (p < 0) continue;
+            const float w = weights ? weights[(long)i * B + row] : 1.f;
+            const float *src = sub + i * cell_stride + p * sub_stride + c0;
+            for (int c = 0; c < nc; ++c) acc[c] = acc[c] + src[c] * w;
+        }
+        for (int c = 0; c < nc; ++c) out[row * out_stride + c0 + c] = acc[c];
     }
-    for (int c = 0; c < n_cols; ++c) out[row * out_stride + c] = acc[c];
 }
 
 }  // namespace mnr
@@ -984,7 +988,7 @@ extern "C" int mnr_route_accumulate(float *out, int64_t out_stride, const float 
 extern "C" int mnr_route_combine_indexed(float *out, int64_t out_stride, const float *sub_all, int64_t cell_stride, int64_t sub_stride,
                                          int n_cols, const int32_t *inverse, const float *weights, int n_sub, int64_t B,
                                          const int32_t *n_dev, int rows_per_unit, void *stream) {
-    MNR_REQUIRE(out && sub_all && inverse && n_cols > 0 && n_cols <= 32 && B >= 0, "bad arguments to mnr_route_combine_indexed");
+    MNR_REQUIRE(out && sub_all && inverse && n_cols > 0 && n_cols <= 64 && B >= 0, "bad arguments to mnr_route_combine_indexed");
     MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "n_sub must be in 1..%d", ROUTE_MAX_SUB);
     if (B == 0) return MNR_OK;
     hipLaunchKernelGGL(k_route_combine, dim3(nblk(B, 256)), dim3(256), 0, as_stream(stream), out, (long)out_stride, sub_all, (long)cell_stride,

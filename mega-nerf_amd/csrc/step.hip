@@ -1711,28 +1711,32 @@ extern "C" int mnr_mlp_forward_multi_h2(const mnr_mlp_launch *segs, int n_segs, 
 // routing buffers of a routed render (mnr_render_io::route_workspace): per container the blend weights, row lists, inverse lists and the
 // cells' compact outputs of ONE pass (the coarse and the fine pass follow each other and share them), the row counts, the device cell table
 struct RouteWs {
-    struct Part { size_t weights, lists, inverse, sub_out, counts, table; long cap; } fg, bg;
+    struct Part { size_t weights, lists, inverse, sub_out, blend, counts, table; long cap; } fg, bg;
     size_t exit_pts, total;
 };
-static void route_layout(long N, long Nc, long Nf, int n_cells, RouteWs &L) {
+// ncol: columns the cells write per row (4; rgb_dim + 1 when spherical-harmonics cells are blended on their raw coefficients)
+static void route_layout(long N, long Nc, long Nf, int n_cells, int ncol, RouteWs &L) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     auto part = [&](RouteWs::Part &P, long cap) {
         P.cap = cap;
         P.weights = take((size_t)n_cells * cap * 4); P.lists = take((size_t)n_cells * cap * 4); P.inverse = take((size_t)n_cells * cap * 4);
-        P.sub_out = take((size_t)n_cells * cap * 16); P.counts = take(ROUTE_PREP_MAX * 4); P.table = take(ROUTE_PREP_MAX * sizeof(mnr_mlp_cell));
+        P.sub_out = take((size_t)n_cells * cap * ncol * 4); P.blend = take(ncol == 4 ? 0 : (size_t)cap * ncol * 4);
+        P.counts = take(ROUTE_PREP_MAX * 4); P.table = take(ROUTE_PREP_MAX * sizeof(mnr_mlp_cell));
     };
     part(L.fg, N * (Nc > Nf ? Nc : Nf));
     part(L.bg, N * ((Nc > Nf ? Nc : Nf) / 2));
     L.exit_pts = take((size_t)N * 12);
     L.total = off;
 }
-extern "C" size_t mnr_render_route_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples, int n_cells) {
-    if (render_dims_ok(n_rays, coarse_samples, fine_samples) != MNR_OK || n_cells < 1 || n_cells > ROUTE_PREP_MAX) return 0;
+extern "C" size_t mnr_render_route_workspace_bytes(int64_t n_rays, int coarse_samples, int fine_samples, int n_cells, int out_cols) {
+    if (render_dims_ok(n_rays, coarse_samples, fine_samples) != MNR_OK || n_cells < 1 || n_cells > ROUTE_PREP_MAX || out_cols < 4 || out_cols > 64) return 0;
     RouteWs L;
-    route_layout(n_rays, coarse_samples, fine_samples, n_cells, L);
+    route_layout(n_rays, coarse_samples, fine_samples, n_cells, out_cols, L);
     return L.total;
 }
+extern "C" int mnr_sh_apply(float *out_dev, int64_t ldo, const float *coef_dev, int64_t ldc, const float *dirs_dev, int64_t dir_stride,
+                            int64_t rows_per_ray, int deg, int64_t R, void *stream);
 extern "C" int mnr_mlp_forward_cells_multi(const mnr_mlp_cells_launch *segs, int n_segs, void *stream);
 
 // a side stream + fork / join events a caller may lend to mnr_render_fwd (mnr_render_io::side): the background branch then runs beside
@@ -1805,9 +1809,11 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         if ((rc = check_launch("k_step_samples"))) return rc;
     }
     RouteWs RL{};
+    // spherical-harmonics cells under a soft blend write their raw rgb_dim + 1 outputs: the blend runs on coefficients (as the reference's)
+    const int route_ncol = (n_cells > 0 && sh_deg >= 0 && r->boundary_margin > 1.f) ? r->fg->rgb_dim + 1 : 4;
     if (n_cells > 0) {
         MNR_REQUIRE(!r->split_precision, "routed render: fp32 kernels");
-        route_layout(N, Nc, Nf, n_cells, RL);
+        route_layout(N, Nc, Nf, n_cells, route_ncol, RL);
         MNR_REQUIRE(r->route_workspace_bytes >= RL.total, "routing workspace too small: %zu < %zu", r->route_workspace_bytes, RL.total);
         if ((rc = bg_exit_points_launch(F(L.rays_bg), r->n_bg, N, r->sphere_center, r->sphere_radius,
                                         reinterpret_cast<float *>(reinterpret_cast<char *>(r->route_workspace) + RL.exit_pts), s))) return rc;
@@ -1834,11 +1840,12 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
             auto RI = [&](size_t off) { return reinterpret_cast<int32_t *>(rw + off); };
             const long B[2] = {N * Sf, N * Sbb};
             const RouteWs::Part *P[2] = {&RL.fg, &RL.bg};
+            const int ncol = route_ncol;            // 4, or rgb_dim + 1: SH cells blended on their raw coefficients
             RoutePrep prep{};
             for (int q = 0; q < 2; ++q) {
                 RoutePrepSeg &g = prep.s[q];
                 g.table = reinterpret_cast<mnr_mlp_cell *>(rw + P[q]->table); g.lists = RI(P[q]->lists); g.counts = RI(P[q]->counts);
-                g.sub_out = RF(P[q]->sub_out); g.B = B[q]; g.n = n_cells; g.out_stride = 4;
+                g.sub_out = RF(P[q]->sub_out); g.B = B[q]; g.n = n_cells; g.out_stride = ncol;
                 for (int c = 0; c < n_cells; ++c) {
                     g.packed[c] = (q ? r->bg_cell_packed : r->fg_cell_packed)[c];
                     g.emb[c] = (q ? r->bg_cell_emb : r->fg_cell_emb)[c];
@@ -1854,7 +1861,8 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
             float *outs[2] = {io[0].out, io[1].out};
             mnr_mlp_cells_launch cl[2] = {};
             for (int q = 0; q < 2; ++q) {
-                io[q].n_rows = B[q]; io[q].out = nullptr; io[q].n_units_dev = nullptr;
+                io[q].n_rows = B[q]; io[q].out = nullptr; io[q].n_units_dev = nullptr; io[q].out_stride = ncol;
+                if (ncol != 4) io[q].apply_sh_deg = -1;
                 cl[q].desc = q ? r->bg : r->fg; cl[q].cells_dev = reinterpret_cast<const mnr_mlp_cell *>(rw + P[q]->table); cl[q].n_cells = n_cells; cl[q].io = &io[q];
             }
             // (the smaller segment -- the background's -- first: its workgroups start at once and the foreground's fill the chip behind them)
@@ -1864,8 +1872,15 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
                 for (int q = 0; q < 2 && (q == 0 || rc2 == MNR_OK); ++q) rc2 = mnr_mlp_forward_cells(ordered[q].desc, ordered[q].cells_dev, n_cells, ordered[q].io, st);
             if (rc2) return rc2;
             const float *wts[2] = {r->boundary_margin > 1.f ? RF(RL.fg.weights) : nullptr, r->boundary_margin > 1.f ? RF(RL.bg.weights) : nullptr};
-            if ((rc2 = mnr_route_combine_indexed(outs[0], 4, RF(RL.fg.sub_out), B[0] * 4, 4, 4, RI(RL.fg.inverse), wts[0], n_cells, B[0], nullptr, 0, st))) return rc2;
-            return mnr_route_combine_indexed(outs[1], 4, RF(RL.bg.sub_out), B[1] * 4, 4, 4, RI(RL.bg.inverse), wts[1], n_cells, B[1], r->n_bg, (int)Sbb, st);
+            float *dst[2] = {ncol == 4 ? outs[0] : RF(RL.fg.blend), ncol == 4 ? outs[1] : RF(RL.bg.blend)};
+            if ((rc2 = mnr_route_combine_indexed(dst[0], ncol, RF(RL.fg.sub_out), B[0] * ncol, ncol, ncol, RI(RL.fg.inverse), wts[0], n_cells, B[0], nullptr, 0, st))) return rc2;
+            if ((rc2 = mnr_route_combine_indexed(dst[1], ncol, RF(RL.bg.sub_out), B[1] * ncol, ncol, ncol, RI(RL.bg.inverse), wts[1], n_cells, B[1], r->n_bg, (int)Sbb, st))) return rc2;
+            if (ncol != 4) {
+                // eval_sh + sigmoid on the BLENDED coefficients (rendering.py:300-306 behind mega_nerf.py:45-49)
+                if ((rc2 = mnr_sh_apply(outs[0], 4, dst[0], ncol, io[0].dir, io[0].dir_stride, Sf, sh_deg, B[0], st))) return rc2;
+                if ((rc2 = mnr_sh_apply(outs[1], 4, dst[1], ncol, io[1].dir, io[1].dir_stride, Sbb, sh_deg, B[1], st))) return rc2;
+            }
+            return MNR_OK;
         }
         if (r->split_precision) return mnr_mlp_forward_multi_h2(seg + first, n, st);
         if (r->fg->layer_dim == 512 || r->bg->layer_dim == 512) {

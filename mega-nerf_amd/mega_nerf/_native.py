@@ -344,7 +344,7 @@ def lib() -> C.CDLL:
         _lib.mnr_render_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
         _lib.mnr_render_fwd.argtypes = [C.POINTER(RenderIO), C.c_void_p]
         _lib.mnr_render_route_workspace_bytes.restype = C.c_size_t
-        _lib.mnr_render_route_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int]
+        _lib.mnr_render_route_workspace_bytes.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.mnr_step_profile.argtypes = [C.c_void_p, C.c_int]
         _lib.mnr_step_kernel_times.argtypes = [C.c_void_p, C.c_int, c_float_p]
         _lib.mnr_train_step.argtypes = [C.c_void_p, C.POINTER(StepBatch), C.POINTER(StepRandoms), C.c_double, C.c_int64, C.c_uint64, C.c_int,

@@ -339,6 +339,19 @@ class MegaNeRF(nn.Module):
     def evaluate_routed(self, xyz: torch.Tensor, part, S: int, out: torch.Tensor, noise, sh_deg: int):
         """Render-path entry: xyz [n, S, 3] (fg) or [n, S, 7] = [xyz_real | sphere point | 1/r] (bg, quirk Q15);
         per-ray dirs / image indices in ``part``; ``out`` [n, S, 4]."""
+        if sh_deg >= 0 and self.boundary_margin > 1 and self.sub_modules[0].rgb_dim > 3:
+            # Spherical-harmonics cells under a soft blend: the reference blends the cells' RAW outputs -- the SH coefficients and sigma
+            # (mega_nerf.py:45-49) -- and evaluates eval_sh + sigmoid on the blend (rendering.py:300-306); a blend of the cells' colours
+            # AFTER their sigmoids is a different number wherever two cells meet (round 6: the fixture render_container_sh2_eval found
+            # the in-kernel colour epilogue being applied per cell).  So: cells write coefficients, the blend runs over rgb_dim + 1
+            # columns, one mnr_sh_apply turns the blended rows into colours.  (Hard routing has one cell per row: the epilogue stays fused.)
+            n = xyz.shape[0]
+            ncol = self.sub_modules[0].rgb_dim + 1
+            raw = torch.empty(n, S, ncol, device=out.device, dtype=torch.float32)
+            self._routed(*self._routed_args(xyz, part, S, raw, noise, -1))
+            N.check(N.lib().mnr_sh_apply(out.data_ptr(), out.shape[-1], raw.data_ptr(), ncol, part.dirs.data_ptr(), part.dirs.stride(0), S,
+                                         sh_deg, n * S, N.stream_ptr()))
+            return
         self._routed(*self._routed_args(xyz, part, S, out, noise, sh_deg))
 
     def forward(self, x: torch.Tensor, sigma_only: bool = False,

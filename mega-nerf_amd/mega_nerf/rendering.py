@@ -497,7 +497,8 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
         io.n_cells, io.fg_cell_packed, io.fg_cell_emb, io.bg_cell_packed, io.bg_cell_emb = nc, arrs[0], arrs[1], arrs[2], arrs[3]
         cent = nerf._centroids_host()
         io.centroids_host, io.boundary_margin = cent, float(nerf.boundary_margin)
-        rneed = lib.mnr_render_route_workspace_bytes(n, Nc, Nf, nc)
+        sh_blend = hparams.sh_deg is not None and hparams.pos_dir_dim == 0 and float(nerf.boundary_margin) > 1
+        rneed = lib.mnr_render_route_workspace_bytes(n, Nc, Nf, nc, nerf.sub_modules[0].rgb_dim + 1 if sh_blend else 4)
         rws = _route_ws.get(key)
         if rws is None or rws.numel() < rneed:
             rws = _route_ws[key] = torch.empty(rneed, dtype=torch.uint8, device=dev)

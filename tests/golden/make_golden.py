@@ -529,6 +529,8 @@ def main(only=None):
     # (every 1049th element of the 2048 x 2048 matrices: 3 999 samples per tensor)
     case('render_nerf_w2048_train', dict(base, use_cascade=True, appearance_dim=0), 8, 30, TR, bg=False, cascade=True, fg_train=True,
          with_grad=True, layer_dim=2048, gstride=1049)
+    # ... and configs[4] as the job evaluates it: a merged container of spherical-harmonics cells (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0)
+    case('render_container_sh2_eval', dict(base, container_path='dummy', sh_deg=2, pos_dir_dim=0), 32, 31, E, container=4)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

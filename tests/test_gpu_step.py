@@ -68,14 +68,14 @@ def test_fused_step_equals_the_stagewise_path_and_the_reference(name):
     check_gradients_against_reference(g, (('fg', nerf2), ('bg', bg2)), 'fused:' + name)
 
 
-def _cell(seed, n_rays, sh=False):
-    """A cell of the benchmark's kind: default fg + bg models (``sh``: their spherical-harmonics form of that degree; True = 2) with their
-    own weights, their own batch."""
+def _cell(seed, n_rays, sh=False, fg_width=256):
+    """A cell of the benchmark's kind: default fg + bg models (``sh``: their spherical-harmonics form of that degree; True = 2;
+    ``fg_width`` 512: the Building shape) with their own weights, their own batch."""
     from oracle import nerf_oracle as O
     from test_gpu_parity import native_nerf
     s = common.SCENE
     hp = O.make_hparams(coarse_samples=64, fine_samples=128, **(dict(sh_deg=2 if sh is True else int(sh), pos_dir_dim=0) if sh else {}))
-    fcfg, bcfg = common.model_cfg(hp, 3, 256), common.model_cfg(hp, 4, 256)
+    fcfg, bcfg = common.model_cfg(hp, 3, fg_width), common.model_cfg(hp, 4, 256)
     fg = native_nerf(fcfg, common.make_weights(fcfg, s['appearance_count'], seed)).train()
     bg = native_nerf(bcfg, common.make_weights(bcfg, s['appearance_count'], seed + 500)).train()
     d = O.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True)
@@ -85,7 +85,7 @@ def _cell(seed, n_rays, sh=False):
     return hp, fg, bg, (T(rays), T(idx.astype(np.int32)), T(tgt))
 
 
-@pytest.mark.parametrize('split,sh', [(False, False), (True, False), (False, True), (False, 3)], ids=['f32', 'split', 'f32-sh2', 'f32-sh3'])
+@pytest.mark.parametrize('split,sh', [(False, False), (True, False), (False, True), (False, 3), (False, 'wide')], ids=['f32', 'split', 'f32-sh2', 'f32-sh3', 'f32-w512'])
 def test_cells_sharing_a_step_are_independent(split, sh):
     """Three cells (own weights, own batches, own optimiser moments) stepped by ONE plan -- their rows side by side in every MLP
     launch -- against the same cells stepped one plan each (cell c of a plan draws its random numbers with key seed + c, so a
@@ -93,14 +93,18 @@ def test_cells_sharing_a_step_are_independent(split, sh):
     colours exactly, gradients to the summation order of the atomics and of the weight-gradient partials -- and so do the weights
     after three Adam steps (parscripts/run_8.txt: independent trainers).  ``split``: the same through the split-precision kernels
     (per-cell exponent words of the weight-gradient scaling, device tables of the h2 images; the lone plans run their background
-    branch on a side stream, the shared plan does not)."""
+    branch on a side stream, the shared plan does not).  ``f32-w512``: 512-wide foreground cells (configs[3]: a rank's Building cells in
+    one plan) -- the per-cell offsets of the tiled backward (csrc/step.hip wide_fg_backward) and of the padded weight copies."""
     from mega_nerf.training import FusedTrainStep
     s = common.SCENE
     sc, sr = T(s['sphere_center']), T(s['sphere_radius'])
     n_rays, seeds = 128, (11, 12, 13)
+    wide = sh == 'wide'
+    if wide:
+        sh = False
 
     def run(groups):
-        cells = [_cell(sd, n_rays, sh) for sd in seeds]
+        cells = [_cell(sd, n_rays, sh, 512 if wide else 256) for sd in seeds]
         hpn = Namespace(**vars(cells[0][0]))
         first = {}
         for grp in groups:
@@ -196,7 +200,7 @@ def test_generated_random_numbers_are_uniform_and_keyed():
                                         ('render_w512_eval', False),
                                         # merged containers: route -> all cells in one launch -> blend inside the same call (mega_nerf.py:19-61)
                                         ('render_container_eval', False), ('render_container8_eval', False), ('render_container25_eval', False),
-                                        ('render_container_w512_eval', False)])
+                                        ('render_container_w512_eval', False), ('render_container_sh2_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches; routed containers: seventeen) against the stage-by-stage render -- identical outputs, bit for bit, for
     the fp32 kernels -- and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
