@@ -531,6 +531,8 @@ def main(only=None):
          with_grad=True, layer_dim=2048, gstride=1049)
     # ... and configs[4] as the job evaluates it: a merged container of spherical-harmonics cells (configs/mega-nerf-sh-3: sh_deg 2, pos_dir_dim 0)
     case('render_container_sh2_eval', dict(base, container_path='dummy', sh_deg=2, pos_dir_dim=0), 32, 31, E, container=4)
+    # ... and a merged container at the reference's default 256 + 512 samples per ray (the other instantiation of the ray-stage kernels, routed)
+    case('render_container_default_samples_eval', dict(container_path='dummy'), 6, 32, E, container=4)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

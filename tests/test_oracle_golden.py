@@ -122,7 +122,7 @@ def test_mlp_forward(name):
 #    render_fgbg_eval, 3 of 13 background rays; never in training mode (random u).  Counted, not bounded: at most one per ray.
 #  * anything else is a u that straddles a cdf entry by an ulp: measured 0 in every 64 + 128 fixture, 1 of 4 096 at 256 + 512 samples
 #    (cdf steps of 1e-3 instead of 1e-2).  Bound: INDEX_OTHER_MAX (<= 2 x measured, 0 where 0 was measured).
-INDEX_OTHER_MAX = {'render_default_samples_eval': 2, 'render_default_samples_train': 2}
+INDEX_OTHER_MAX = {'render_default_samples_eval': 2, 'render_default_samples_train': 2, 'render_container_default_samples_eval': 2}
 INDEX_LOG = []
 
 
@@ -172,6 +172,7 @@ RENDER_CASES = {
                                   seed=15, bg=False, cascade=True, fg_train=True),
     # BASELINE configs[0] at its real width: configs/nerf/*.yaml (use_cascade, layer_dim 2048, appearance_dim 0, no_bg_nerf), 8 rays
     'render_nerf_w2048_train': dict(hp=dict(use_cascade=True, appearance_dim=0, layer_dim=2048), seed=30, bg=False, cascade=True, fg_train=True),
+    'render_container_default_samples_eval': dict(hp=dict(container_path='dummy', coarse_samples=256, fine_samples=512), seed=32, container=4),
     'render_container_sh2_eval': dict(hp=dict(container_path='dummy', sh_deg=2, pos_dir_dim=0), seed=31, container=4),
     # cluster_2d (Quad configs): distances over dims 1:3, background routed per sample on the true far-away point
     'render_container_2d_eval': dict(hp=dict(container_path='dummy'), seed=28, container=4, cluster_2d=True),
