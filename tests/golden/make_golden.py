@@ -533,6 +533,12 @@ def main(only=None):
     case('render_container_sh2_eval', dict(base, container_path='dummy', sh_deg=2, pos_dir_dim=0), 32, 31, E, container=4)
     # ... and a merged container at the reference's default 256 + 512 samples per ray (the other instantiation of the ray-stage kernels, routed)
     case('render_container_default_samples_eval', dict(container_path='dummy'), 6, 32, E, container=4)
+    # ... the sh_deg 3 head in a container (49 raw columns per row through the blend), cascade + background in evaluation mode, and
+    # jointly trained (--train_mega_nerf, hard routing) spherical-harmonics cells with the reference's gradients
+    case('render_container_sh3_eval', dict(base, container_path='dummy', sh_deg=3, pos_dir_dim=0), 24, 33, E, container=4)
+    case('render_cascade_bg_eval', dict(base, use_cascade=True), 32, 34, E, cascade=True, layer_dim=64, bg_layer_dim=64)
+    case('render_joint_sh2_train', dict(base, train_mega_nerf='dummy', sh_deg=2, pos_dir_dim=0), 128, 36, TR, container=4, joint=True, fg_train=True,
+         bg_train=True, with_grad=True, layer_dim=64, bg_layer_dim=64)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

@@ -201,7 +201,7 @@ def test_generated_random_numbers_are_uniform_and_keyed():
                                         # merged containers: route -> all cells in one launch -> blend inside the same call (mega_nerf.py:19-61)
                                         ('render_container_eval', False), ('render_container8_eval', False), ('render_container25_eval', False),
                                         ('render_container_w512_eval', False), ('render_container_sh2_eval', False),
-                                        ('render_container_default_samples_eval', False)])
+                                        ('render_container_default_samples_eval', False), ('render_container_sh3_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches; routed containers: seventeen) against the stage-by-stage render -- identical outputs, bit for bit, for
     the fp32 kernels -- and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
