@@ -75,8 +75,10 @@ def _hparams(data, exp, extra):
                          '--ray_altitude_range', '-0.5', '0.2', '--val_scale_factor', '1', '--batch_size', '384'] + extra)
 
 
-def test_runner_train_runs_the_fused_step_and_resumes(tmp_path, monkeypatch):
-    """train.py's loop (Runner.train, reference runner.py:244-277) on the default architecture must run the ONE-CALL training step
+@pytest.mark.parametrize('width', [256, 512])
+def test_runner_train_runs_the_fused_step_and_resumes(tmp_path, monkeypatch, width):
+    """(``width`` 512: the Building shape -- the same through the 512-wide foreground's path inside mnr_train_step.)
+    train.py's loop (Runner.train, reference runner.py:244-277) on the default architecture must run the ONE-CALL training step
     (mnr_train_step through training.CellTrainer) -- the thing bench.py times -- and stay a drop-in:
       * same trained weights as the stage-by-stage autograd loop (MNR_RUNNER_AUTOGRAD=1) from the same seed, on deterministic
         renders (models pinned to eval mode: the two paths draw their random numbers from different generators);
@@ -95,7 +97,7 @@ def test_runner_train_runs_the_fused_step_and_resumes(tmp_path, monkeypatch):
             monkeypatch.setenv('MNR_RUNNER_AUTOGRAD', '1')
         else:
             monkeypatch.delenv('MNR_RUNNER_AUTOGRAD', raising=False)
-        r = Runner(_hparams(data, tmp_path / tag, ['--train_iterations', '40', '--ckpt_interval', '20'] + extra))
+        r = Runner(_hparams(data, tmp_path / tag, ['--train_iterations', '40', '--ckpt_interval', '20', '--layer_dim', str(width)] + extra))
         w0 = {k: v.detach().clone() for k, v in list(r.nerf.state_dict().items()) + [('bg.' + k, v) for k, v in r.bg_nerf.state_dict().items()]}
         r.train()
         w = {k: v.detach().clone() for k, v in list(r.nerf.state_dict().items()) + [('bg.' + k, v) for k, v in r.bg_nerf.state_dict().items()]}
