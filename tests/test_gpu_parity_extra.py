@@ -572,3 +572,31 @@ def test_pair_kernel_equals_the_one_wavefront_kernel_and_fp64(xyz_dim, monkeypat
     ref = torch.cat([rgb, sigma], -1).numpy()
     err = np.abs(outs['pair'][0] - ref).max(0) / np.maximum(np.abs(ref).max(0), 1e-12)
     assert err.max() < 1e-5, err
+
+
+@pytest.mark.parametrize('name', ['render_container8_eval', 'render_container_sh2_eval', 'render_container_w512_eval'])
+def test_one_call_routed_render_equals_the_stage_by_stage_render_at_ragged_sizes(name):
+    """mnr_render_fwd with merged containers (route -> all cells in one launch -> blend inside the call) against the stage-by-stage
+    sequencing of the same kernels at ray counts that leave ragged last workgroups / row blocks everywhere (1, 7, 33, 100, 257 rays of
+    the benchmark camera, some with a background segment): every output bit-identical."""
+    from mega_nerf import rendering as R
+    from oracle import nerf_oracle as O
+    hp, nerf, bg_nerf = native_models(name)
+    hpn = Namespace(**vars(hp))
+    s = common.SCENE
+    d = O.get_ray_directions(s['W'], s['H'], s['fx'], s['fy'], s['cx'], s['cy'], True)
+    rays_all = O.get_rays(d, s['c2w'], s['near'], s['far'], s['ray_altitude_range']).reshape(-1, 8)
+    for n in (1, 7, 33, 100, 257):
+        rays, idx = common.pick_rays(rays_all, n, 1000 + n)
+        args = (nerf, bg_nerf, T(rays), T(idx.astype(f32)), hpn, T(s['sphere_center']), T(s['sphere_radius']), True, False, True)
+        try:
+            with torch.no_grad():
+                assert R._fused_render_ok(nerf, bg_nerf, hpn, args[3], args[6], False, {})
+                fused, p1 = R.render_rays(*args)
+                R.FUSED_RENDER = False
+                stage, p2 = R.render_rays(*args)
+        finally:
+            R.FUSED_RENDER = True
+        assert p1 == p2 and sorted(fused) == sorted(stage)
+        for k in fused:
+            np.testing.assert_array_equal(fused[k].cpu().numpy(), stage[k].cpu().numpy(), err_msg='%s n=%d %s' % (name, n, k))
