@@ -531,6 +531,7 @@ def main():
             line['strong_scaling_n1'] = {'flags': '--submodules 8', 'submodules': 8, 'ms_per_step_of_the_set': set8['ms_per_step'],
                                          'rays_per_sec': set8['rays_per_sec'], 'frac_of_f32_mfma_peak': set8['frac'], 'steps': set8['steps']}
         line['runner_loop'] = runner_loop(args, dev, line['value'])
+        line['joint_cells_loop'] = joint_cells_loop(args, dev)
         line['baseline_configs']['_seconds'] = round(time.perf_counter() - t0, 1)
     if rank == 0:
         if 'diag' in line:
@@ -651,6 +652,81 @@ def config0_line(args, dev, mode):
             'frac_of': 'whole step (k_tgemm / k_wgrad2 jobs + render stages), wall clock', 'peak_tflops': PEAK_F32_MFMA_TFLOPS,
             'achieved_tflops': round(fl / dt / 1e12, 2), 'algorithmic_gflop_per_step': round(fl / 1e9, 1),
             'workload': 'cascade of two 8x2048 NeRFs, %d rays x (%d coarse + %d fine-model) rows, fg only' % (args.rays, Nc, Nc + Nf)}
+
+
+def joint_cells_loop(args, dev, n_cells=4):
+    """Rays/s of a rank that owns several cells, trained the way tools/train_cells.py trains them: every cell its own, unchanged
+    Runner.train() loop on a host thread, the cells' iterations meeting in ONE mnr_train_step per iteration (training.JointCells) -- against
+    the bare multi-cell step on the last batches (what `--submodules N` times).  Same synthetic dataset for every cell (throughput does not
+    depend on the pixels); timed from iteration 20 of cell 0 to its last one."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import numpy as np
+    import synthetic_scene as S
+    from PIL import Image
+    from mega_nerf.opts import get_opts_base
+    from mega_nerf.runner import Runner
+    from mega_nerf.training import JointCells
+    tmp = Path(tempfile.mkdtemp(prefix='mnr_bench_joint_'))
+    try:
+        data, sc = tmp / 'data', S.SCENE
+        rng = np.random.default_rng(7)
+        torch.save({'origin_drb': torch.zeros(3), 'pose_scale_factor': 1.0}, _mkdir(data) / 'coordinates.pt')
+        for i, split in enumerate(('train', 'train', 'val')):
+            c2w = torch.from_numpy(sc['c2w'].copy())
+            c2w[:, 3] += torch.tensor([0.0, 0.01 * i, -0.01 * i])
+            Image.fromarray(rng.integers(0, 256, (sc['H'], sc['W'], 3), dtype=np.uint8)).save(_mkdir(data / split / 'rgbs') / ('%06d.png' % i))
+            torch.save({'W': sc['W'], 'H': sc['H'], 'intrinsics': torch.tensor([sc['fx'], sc['fy'], sc['cx'], sc['cy']]), 'c2w': c2w},
+                       _mkdir(data / split / 'metadata') / ('%06d.pt' % i))
+        p = get_opts_base()
+        p.add_argument('--exp_name', type=str, required=True)
+        p.add_argument('--dataset_path', type=str, required=True)
+        iters, first = 20 + args.steps, 20
+        runners, marks = [], {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            joint = JointCells(n_cells)
+            for c in range(n_cells):
+                hp = p.parse_args(['--dataset_path', str(data), '--exp_name', str(tmp / ('exp%d' % c)), '--coarse_samples', '64', '--fine_samples', '128',
+                                   '--near', str(sc['near']), '--ray_altitude_range'] + [str(v) for v in sc['ray_altitude_range']] +
+                                  ['--val_scale_factor', '8', '--batch_size', str(args.rays), '--train_iterations', str(iters), '--random_seed', str(42 + c)])
+                r = Runner(hp)
+                r.sphere_center = torch.from_numpy(sc['sphere_center']).to(dev)
+                r.sphere_radius = torch.from_numpy(sc['sphere_radius']).to(dev)
+                r.trainer_factory = joint.member(c)
+                r._write_final_metrics = lambda *a, **k: None          # (no validation render behind the loops: this times training)
+                r._run_validation = lambda *a, **k: {'val/psnr': 0.0, 'val/ssim': 0.0}
+                runners.append(r)
+
+            def hook(it):
+                if it in (first, iters):
+                    torch.cuda.synchronize()
+                    marks[it] = time.perf_counter()
+            runners[0].iteration_hook = hook
+            joint.run([r.train for r in runners])
+        dt = (marks[iters] - marks[first]) / (iters - first)
+        bare = None
+        if joint.plan is not None:
+            fs, batches = joint.plan, list(joint.plan._keep[:n_cells])
+            for _ in range(3):
+                fs(batches)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(iters - first):
+                fs(batches)
+            torch.cuda.synchronize()
+            bare = (time.perf_counter() - t1) / (iters - first)
+        return {'cells': n_cells, 'rays_per_sec': round(n_cells * args.rays / dt, 1), 'ms_per_joint_iteration': round(dt * 1e3, 4),
+                'joint_steps': joint.joint_steps, 'cell_by_cell_iterations': joint.separate_steps,
+                'bare_multi_cell_step_on_its_last_batches_ms': round(bare * 1e3, 4) if bare else None,
+                'fraction_of_bare_step': round(bare / dt, 4) if bare else None,
+                'what': 'training.JointCells: %d cells, each its own Runner.train() loop on a host thread, one mnr_train_step per iteration for all of them '
+                        '(tools/train_cells.py on a rank that owns several cells)' % n_cells}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def runner_loop(args, dev, value):
