@@ -119,6 +119,9 @@ def test_default_line_carries_every_baseline_config():
         assert 100 < c['mfma_f32_tflops'] < 160 and 1500 < c['sclk_mhz_mfma_chain'] < 2600, c
         assert 0 < c['chase_l2_ns'] <= c['chase_hbm_ns'] * 1.2 and c['hbm_read_gbps'] > 1000 and c['dma_stream_gbps'] > 1000, c
         assert line['roofline']['box'][when]['mfma_f32_tflops'] == c['mfma_f32_tflops']
+    jl = line['joint_cells_loop']
+    assert 'error' not in jl, jl
+    assert jl['cells'] == 4 and jl['cell_by_cell_iterations'] == 0 and jl['joint_steps'] >= 20 and jl['fraction_of_bare_step'] > 0.85, jl
     rl = line['runner_loop']
     assert 'error' not in rl, rl
     assert rl['one_call_step'] is True and rl['fraction_of_value'] > 0.9, rl
