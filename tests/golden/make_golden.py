@@ -539,6 +539,9 @@ def main(only=None):
     case('render_cascade_bg_eval', dict(base, use_cascade=True), 32, 34, E, cascade=True, layer_dim=64, bg_layer_dim=64)
     case('render_joint_sh2_train', dict(base, train_mega_nerf='dummy', sh_deg=2, pos_dir_dim=0), 128, 36, TR, container=4, joint=True, fg_train=True,
          bg_train=True, with_grad=True, layer_dim=64, bg_layer_dim=64)
+    # ... --affine_appearance (nerf.py:87-89,156-158: a 3 x 4 colour transform per appearance index instead of the appearance input), training
+    case('render_affine_train', dict(base, affine_appearance=True), 64, 37, TR, fg_train=True, bg_train=True, with_grad=True,
+         layer_dim=64, bg_layer_dim=64)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

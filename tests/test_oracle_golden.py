@@ -177,6 +177,7 @@ RENDER_CASES = {
     'render_cascade_bg_eval': dict(hp=dict(use_cascade=True, layer_dim=64, bg_layer_dim=64), seed=34, cascade=True),
     'render_joint_sh2_train': dict(hp=dict(train_mega_nerf='dummy', sh_deg=2, pos_dir_dim=0, layer_dim=64, bg_layer_dim=64), seed=36, container=4,
                                    joint=True, fg_train=True, bg_train=True),
+    'render_affine_train': dict(hp=dict(affine_appearance=True, layer_dim=64, bg_layer_dim=64), seed=37, fg_train=True, bg_train=True),
     'render_container_sh2_eval': dict(hp=dict(container_path='dummy', sh_deg=2, pos_dir_dim=0), seed=31, container=4),
     # cluster_2d (Quad configs): distances over dims 1:3, background routed per sample on the true far-away point
     'render_container_2d_eval': dict(hp=dict(container_path='dummy'), seed=28, container=4, cluster_2d=True),
