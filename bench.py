@@ -1320,7 +1320,28 @@ def run_config(args, rank, world, dev, dist):
             diag['calibration'] = {'before': cal_before, 'after': cal_after, 'device': dev_info,
                                    'nominal': {'mfma_f32_tflops': PEAK_F32_MFMA_TFLOPS, 'note': 'csrc/calibrate.hip; typical MI355X in this pool: mfma_f32_tflops ~145 '
                                                '(1 ms probe incl. clock ramp), sclk_mhz_mfma_chain 2400, dma_chunk_round_trip_us ~0.49, chase_l2 / mall / hbm ns, hbm GB/s: see '
-                                               'profiles/r06_calibration_boxes.jsonl'}}
+                                               'profiles/r06_calibration_healthy_box.jsonl'}}
+        if cal_before is not None and 'error' not in cal_before:
+            # a one-line reading of the calibration against what healthy boxes of this pool deliver (profiles/r06_calibration_healthy_box.jsonl)
+            flags = []
+            for when, c in (('before', cal_before), ('after', cal_after or {})):
+                if not c or 'error' in c:
+                    continue
+                if c.get('mfma_f32_tflops', 1e9) < 135:
+                    flags.append('%s: fp32-MFMA probe %.0f TFLOP/s (healthy 142-147)' % (when, c['mfma_f32_tflops']))
+                if c.get('mfma_wg_ms_median') and c['mfma_wg_ms_max'] > 1.10 * c['mfma_wg_ms_median']:
+                    flags.append('%s: slowest workgroup %.2fx the median (healthy <= 1.03): a CU / XCD runs behind' % (when, c['mfma_wg_ms_max'] / c['mfma_wg_ms_median']))
+                if c.get('mfma_xcd_ms_fastest') and c['mfma_xcd_ms_slowest'] > 1.06 * c['mfma_xcd_ms_fastest']:
+                    flags.append('%s: slowest XCD %.2fx the fastest (healthy <= 1.03)' % (when, c['mfma_xcd_ms_slowest'] / c['mfma_xcd_ms_fastest']))
+                if c.get('sclk_mhz_mfma_chain', 1e9) < 2250:
+                    flags.append('%s: one wavefront sees %.0f MHz (healthy 2395-2415)' % (when, c['sclk_mhz_mfma_chain']))
+                if c.get('dma_chunk_round_trip_us', 0) > 0.7:
+                    flags.append('%s: 32 KiB L2 -> LDS chunk round trip %.2f us (healthy 0.48-0.49)' % (when, c['dma_chunk_round_trip_us']))
+                if c.get('chase_l2_ns', 0) > 280 or c.get('chase_hbm_ns', 0) > 450:
+                    flags.append('%s: load latency L2 %.0f / HBM %.0f ns (healthy 218 / 335-350)' % (when, c.get('chase_l2_ns', 0), c.get('chase_hbm_ns', 0)))
+                if c.get('hbm_read_gbps', 1e9) < 6000:
+                    flags.append('%s: HBM stream read %.0f GB/s (healthy 6900-7050)' % (when, c['hbm_read_gbps']))
+            diag['box_verdict'] = 'calibration within the healthy range of this pool' if not flags else 'BOX BELOW NOMINAL -- ' + '; '.join(flags)
         cl = clocks.summary(windows)
         if cl is not None:
             diag['clocks_during_timed_regions'] = cl
@@ -1339,7 +1360,8 @@ def run_config(args, rank, world, dev, dist):
             if cal_before is not None:
                 keys = ('mfma_f32_tflops', 'sclk_mhz_mfma_chain', 'dma_stream_gbps', 'dma_chunk_round_trip_us', 'chase_l2_ns', 'chase_mall_ns', 'chase_hbm_ns',
                         'hbm_read_gbps', 'hbm_write_gbps')
-                roof['box'] = {'before': {k: cal_before.get(k) for k in keys}, 'after': {k: (cal_after or {}).get(k) for k in keys}}
+                roof['box'] = {'before': {k: cal_before.get(k) for k in keys}, 'after': {k: (cal_after or {}).get(k) for k in keys},
+                               'verdict': diag.get('box_verdict')}
                 if cl is not None:
                     roof['box']['sclk_mhz_during'] = next((v for k, v in cl.items() if k.startswith('sclk')), None)
                     roof['box']['power_w_during'] = cl.get('power_w')
