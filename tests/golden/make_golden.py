@@ -278,7 +278,7 @@ def run_render(name, hp_kw, N, seed, flags, *, bg=True, fg_train=False, bg_train
                 bg_nerf = MegaNeRF(bsubs, cent_t, 1, True, cluster_2d, True)
             else:
                 nerf = MegaNeRF(subs, cent_t, hp.boundary_margin, False, cluster_2d)
-                bg_nerf = MegaNeRF(bsubs, cent_t, hp.boundary_margin, True, cluster_2d)
+                bg_nerf = MegaNeRF(bsubs, cent_t, hp.boundary_margin, True, cluster_2d) if bg else None        # (--no_bg_nerf: model_utils.py:19-20)
         elif cascade:
             nerf = Cascade(ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000), A),
                            ref_model(hp, fcfg, common.make_weights(fcfg, A, seed * 1000 + 1), A))
@@ -542,6 +542,11 @@ def main(only=None):
     # ... --affine_appearance (nerf.py:87-89,156-158: a 3 x 4 colour transform per appearance index instead of the appearance input), training
     case('render_affine_train', dict(base, affine_appearance=True), 64, 37, TR, fg_train=True, bg_train=True, with_grad=True,
          layer_dim=64, bg_layer_dim=64)
+    # ... quirk Q13 through a container (the background container left in training mode at evaluation: noise + random fine samples through
+    # the router), a container without a background model (--no_bg_nerf), the default foreground trained alone
+    case('render_container_q13_eval', dict(base, container_path='dummy'), 40, 38, E, container=4, bg_train=True)
+    case('render_container_fgonly_eval', dict(base, container_path='dummy'), 40, 39, E, container=4, bg=False)
+    case('render_fgonly_train', base, 48, 40, TR, bg=False, fg_train=True, with_grad=True)
     if only is None or 'render_overfit_eval' in only:
         run_overfit('render_overfit_eval', all_rays)
     if only is None or 'render_overfit_hip_eval' in only:

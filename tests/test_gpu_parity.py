@@ -311,7 +311,8 @@ def test_mlp_large_batch_against_oracle():
 SUPPORTED_RENDER = ['render_fgbg_eval', 'render_fgonly_eval', 'render_q13_eval', 'render_default_samples_eval',
                     'render_sh2_eval', 'render_container_eval', 'render_cascade_eval', 'render_coarse_only_eval',
                     'render_relu_noapp_eval', 'render_w512_eval', 'render_container_sh2_eval',
-                    'render_container_default_samples_eval', 'render_container_sh3_eval', 'render_cascade_bg_eval']
+                    'render_container_default_samples_eval', 'render_container_sh3_eval', 'render_cascade_bg_eval',
+                    'render_container_q13_eval', 'render_container_fgonly_eval']
 
 
 def native_models(name):

@@ -151,7 +151,7 @@ def test_nerf_forward_autograd_matches_fp64():
 
 TRAIN_CASES = ['render_fgbg_train', 'render_w512_train', 'render_cascade_bg_train', 'render_sh2_train', 'render_sh2_256_train', 'render_sh3_256_train', 'render_default_samples_train', 'render_noapp_train',
                'render_noapp256_train',
-               'render_nerf_cfg_train', 'render_nerf_w2048_train', 'render_joint_train', 'render_joint_2d_train', 'render_joint_sh2_train', 'render_affine_train']
+               'render_nerf_cfg_train', 'render_nerf_w2048_train', 'render_joint_train', 'render_joint_2d_train', 'render_joint_sh2_train', 'render_affine_train', 'render_fgonly_train']
 
 
 @pytest.mark.parametrize('name', TRAIN_CASES)

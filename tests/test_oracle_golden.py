@@ -122,7 +122,7 @@ def test_mlp_forward(name):
 #    render_fgbg_eval, 3 of 13 background rays; never in training mode (random u).  Counted, not bounded: at most one per ray.
 #  * anything else is a u that straddles a cdf entry by an ulp: measured 0 in every 64 + 128 fixture, 1 of 4 096 at 256 + 512 samples
 #    (cdf steps of 1e-3 instead of 1e-2).  Bound: INDEX_OTHER_MAX (<= 2 x measured, 0 where 0 was measured).
-INDEX_OTHER_MAX = {'render_default_samples_eval': 2, 'render_default_samples_train': 2, 'render_container_default_samples_eval': 2}
+INDEX_OTHER_MAX = {'render_default_samples_eval': 2, 'render_default_samples_train': 2, 'render_container_default_samples_eval': 2, 'render_container_fgonly_eval': 2}
 INDEX_LOG = []
 
 
@@ -178,6 +178,9 @@ RENDER_CASES = {
     'render_joint_sh2_train': dict(hp=dict(train_mega_nerf='dummy', sh_deg=2, pos_dir_dim=0, layer_dim=64, bg_layer_dim=64), seed=36, container=4,
                                    joint=True, fg_train=True, bg_train=True),
     'render_affine_train': dict(hp=dict(affine_appearance=True, layer_dim=64, bg_layer_dim=64), seed=37, fg_train=True, bg_train=True),
+    'render_container_q13_eval': dict(hp=dict(container_path='dummy'), seed=38, container=4, bg_train=True),
+    'render_container_fgonly_eval': dict(hp=dict(container_path='dummy'), seed=39, container=4, bg=False),
+    'render_fgonly_train': dict(hp=dict(), seed=40, bg=False, fg_train=True),
     'render_container_sh2_eval': dict(hp=dict(container_path='dummy', sh_deg=2, pos_dir_dim=0), seed=31, container=4),
     # cluster_2d (Quad configs): distances over dims 1:3, background routed per sample on the true far-away point
     'render_container_2d_eval': dict(hp=dict(container_path='dummy'), seed=28, container=4, cluster_2d=True),
@@ -206,7 +209,7 @@ def build_case(name):
         nerf = O.Model(fcfg, subs=[common.make_weights(fcfg, A, seed * 1000 + i) for i in range(n)], centroids=cent,
                        boundary_margin=margin, xyz_real=False, cluster_2d=c.get('cluster_2d', False), training=ft)
         bg_nerf = O.Model(bcfg, subs=[common.make_weights(bcfg, A, seed * 1000 + 500 + i) for i in range(n)],
-                          centroids=cent, boundary_margin=margin, xyz_real=True, cluster_2d=c.get('cluster_2d', False), training=bt)
+                          centroids=cent, boundary_margin=margin, xyz_real=True, cluster_2d=c.get('cluster_2d', False), training=bt) if bg else None
     elif c.get('cascade'):
         nerf = O.Model(fcfg, cascade=(common.make_weights(fcfg, A, seed * 1000),
                                       common.make_weights(fcfg, A, seed * 1000 + 1)), training=ft)
