@@ -3,6 +3,7 @@
 // instantiations), mlp_fwd_multi.hip (two-model launches) -- so that the instantiations compile in parallel (one unit took
 // 7.5 minutes).  Design notes: mlp_fwd.hip.
 #pragma once
+#include <stdlib.h>
 #include "mlp_device.h"
 #include "sh_device.h"
 
@@ -20,6 +21,7 @@ struct MlpFwdArgs {
     int32_t sigma_act, app_count;
     const mnr_mlp_cell *cells;   // batched routed evaluation: per-cell weights / row lists / outputs (device array), else NULL
     int n_cells;
+    int xcd_order;               // routed evaluation: every XCD takes a CONTIGUOUS eighth of the cell-after-cell workgroup sequence (see xcd_contiguous)
     long aux_byte_off;           // offset of the aux block inside a packed image (same for all cells of one architecture)
     const MlpCellSeg *dcells;    // several cells' rows side by side in one segment (device table), else NULL
     long cell_rows;              // ... rows per cell (capacity; a multiple of the rows per workgroup)
@@ -164,6 +166,20 @@ __device__ __forceinline__ void init_acc_lds(AccT (&acc)[NOB], unsigned addr) { 
     });
 }
 
+// Routed evaluation, workgroup order.  The hardware deals workgroups to the 8 XCDs round-robin (flat id % 8), so with the cells laid out one
+// after another every XCD's L2 sees the weight streams of ALL the cells in flight (2-5 of them: 2.4 MB each at 256 channels, 9.3 MB at 512, against
+// 4 MB of L2).  Here XCD x takes logical workgroups [x * ceil(T / 8), (x + 1) * ceil(T / 8)) of the T the device-side counts add up to, in
+// order: one cell's stream per L2 at a time, as in a single-cell launch.  `blk` = index inside the segment (whose first workgroup is
+// blockIdx.x - blk); returns the logical index, or -1 for a surplus workgroup.  (The grid is the worst case rounded up to 8 plus 8, so
+// every residue has at least ceil(T / 8) workgroups.)
+__device__ __forceinline__ long xcd_contiguous(long blk, long T) {
+    const int x = blockIdx.x & 7;
+    const int o = (int)(((long)blockIdx.x - blk) & 7);
+    const long j = (blk - ((x - o) & 7)) >> 3;
+    const long per = (T + 7) >> 3;
+    return j < per ? x * per + j : -1;
+}
+
 // NW = wavefronts per workgroup sharing one weight stream (4: two workgroups per CU; 8: one -- half the stream traffic and barriers per CU)
 template <class C, bool TRAIN, int NW = 4>
 __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int cidx = 0) {
@@ -180,6 +196,12 @@ __device__ __forceinline__ void mlp_fwd_body(const MlpFwdArgs &a, long blk, int 
     if (a.cells) {
         // One launch for all cells of a routed evaluation: workgroups are laid out cell after cell, ceil(count_c / rows
         // per workgroup) each; everything below is uniform per workgroup, so the per-cell pointers stay in SGPRs.
+        if (a.xcd_order) {
+            long T = 0;
+            for (int c = 0; c < a.n_cells; ++c) T += ((long)*a.cells[c].count + ROWS_WG - 1) / ROWS_WG;
+            blk = xcd_contiguous(blk, T);
+            if (blk < 0) return;
+        }
         int c = 0;
         n_rows = 0;
         for (; c < a.n_cells; ++c) {
@@ -491,6 +513,9 @@ static inline int allow_lds(const void *fn, size_t bytes) {
     return MNR_OK;
 }
 
+// grid of a routed segment with `worst` workgroups in the worst case (xcd_contiguous: every residue of 8 needs its share)
+static inline long routed_grid(long worst) { return (worst + 7) / 8 * 8 + 8; }
+
 template <class C>
 static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed, const mnr_model_desc *d, const mnr_mlp_io *io,
                          float *tape, long tape_rows, long tape_row0, const mnr_mlp_cell *cells, int n_cells) {
@@ -505,6 +530,7 @@ static int fill_fwd_args(MlpFwdArgs &a, const ModelLayout &m, const void *packed
     a.emb_a = d->embedding_a;
     a.cells = cells;
     a.n_cells = n_cells;
+    a.xcd_order = cells && !getenv("MNR_NO_XCD_ORDER");
     a.dcells = nullptr;
     a.cell_rows = 0;
     a.aux_byte_off = (long)m.total_chunks * CHUNK_BYTES;
@@ -531,8 +557,9 @@ static int launch_fwd(const ModelLayout &m, const void *packed, const mnr_model_
     const int rc = fill_fwd_args<C>(a, m, packed, d, io, tape, tape_rows, tape_row0, cells, n_cells);
     if (rc != MNR_OK) return rc;
     // cells: the worst case (every row routed to every cell); workgroups past the device-side counts exit at once
-    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
+    long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
+    if (cells) nwg = routed_grid(nwg);
     if (nwg > 0x7fffffffL) return set_err(MNR_E_INVALID, "too many rows for one MLP launch");
     constexpr size_t LDS = fwd_lds_bytes<C, 4>();
     const int lrc = allow_lds(reinterpret_cast<const void *>(k_mlp_fwd<C, TRAIN>), LDS);

@@ -80,7 +80,7 @@ static int mlp_forward_multi_pair(const mnr_mlp_launch *segs, int n_segs, const 
             wg += cells[i].cell_rows / rows_wg;
         } else
         // (routed: the worst case -- every row routed to every cell; workgroups past the device-side counts exit at once)
-        wg += (L.io->n_rows + rows_wg - 1) / rows_wg * (routed ? routed[i].n_cells : 1);
+        wg += routed ? routed_grid((L.io->n_rows + rows_wg - 1) / rows_wg * routed[i].n_cells) : (L.io->n_rows + rows_wg - 1) / rows_wg;
         MNR_REQUIRE(wg <= 0x7fffffffL, "too many rows for one MLP launch");
     }
     for (int i = n_segs; i <= MLP_MAX_SEGS; ++i) mm.wg0[i] = (int32_t)wg;

@@ -187,6 +187,12 @@ __device__ __forceinline__ void pair_body(const MlpFwdArgs &a) {
     float *outp = io.out;
     long n_rows, blk = blockIdx.x;
     if (a.cells) {          // routed evaluation: workgroups laid out cell after cell (see mlp_fwd_body)
+        if (a.xcd_order) {
+            long T = 0;
+            for (int c = 0; c < a.n_cells; ++c) T += ((long)*a.cells[c].count + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG;
+            blk = xcd_contiguous(blk, T);
+            if (blk < 0) return;
+        }
         int c = 0;
         n_rows = 0;
         for (; c < a.n_cells; ++c) {
@@ -417,8 +423,9 @@ static int launch_fwd_pair(const ModelLayout &m, const void *packed, const mnr_m
     MlpFwdArgs a;
     const int rc = fill_fwd_args<C>(a, m, packed, d, io, tape, tape_rows, tape_row0, cells, n_cells);
     if (rc != MNR_OK) return rc;
-    const long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
+    long nwg = (io->n_rows + C::ROWS_PER_WG - 1) / C::ROWS_PER_WG * (cells ? n_cells : 1);
     if (nwg <= 0) return MNR_OK;
+    if (cells) nwg = routed_grid(nwg);
     if (nwg > 0x7fffffffL) return set_err(MNR_E_INVALID, "too many rows for one MLP launch");
     static bool lds_enabled_dev[MAX_DEVICES] = {};
     bool &lds_enabled = lds_enabled_dev[device_slot()];

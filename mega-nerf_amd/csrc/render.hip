@@ -737,15 +737,16 @@ struct Centroids {
 // writes the row ids.  `inverse` (optional) [n_sub][B]: the position of `row` in cell i's list, -1 where it was not routed there -- what
 // k_route_combine needs (round 4 built it with a fill + an inversion launch per evaluation).
 constexpr int ROUTE_BLOCK = 1024;
-__global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__ pos, long pos_stride, long B,
-                                                       const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
-                                                       float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
-                                                       int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows) {
+// (a device function taking the block index: k_route runs one routing problem per launch, k_route2 two side by side)
+__device__ __forceinline__ void route_block(const float *__restrict__ pos, long pos_stride, long B,
+                                            const int32_t *__restrict__ n_dev, int rows_per_unit, const Centroids &cen, int d0,
+                                            float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
+                                            int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows, long blk) {
     __shared__ int wcnt[ROUTE_MAX_SUB][ROUTE_BLOCK / 64];
     __shared__ int base[ROUTE_MAX_SUB];
     __shared__ float4 sc[ROUTE_MAX_SUB];                                   // (c_x, c_y, c_z, |c|^2 over the clustered axes)
     const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
-    if ((long)blockIdx.x * ROUTE_BLOCK >= n) return;                       // (uniform: the whole block is past the device-side count)
+    if (blk * ROUTE_BLOCK >= n) return;                                    // (uniform: the whole block is past the device-side count)
     // The centroids go through LDS once: read from the kernel-argument block inside the three loops below, every cell cost a chain of
     // dependent scalar loads -- ~15 us per launch whatever the row count (round 5 trace: 20 us for 4 416 rows and for 65 536).
     if ((int)threadIdx.x < cen.n) {
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__
         sc[i] = make_float4(cen.c[i][0], cen.c[i][1], cen.c[i][2], cn);
     }
     __syncthreads();
-    const long row = (long)blockIdx.x * ROUTE_BLOCK + threadIdx.x;
+    const long row = blk * ROUTE_BLOCK + threadIdx.x;
     const bool valid = row < n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float p[3] = {0.f, 0.f, 0.f};
@@ -836,6 +837,21 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__
         if (inverse && valid) inverse[(long)i * B + row] = routed ? slot : -1;
     }
 }
+__global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__ pos, long pos_stride, long B,
+                                                       const int32_t *__restrict__ n_dev, int rows_per_unit, Centroids cen, int d0,
+                                                       float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
+                                                       int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows) {
+    route_block(pos, pos_stride, B, n_dev, rows_per_unit, cen, d0, margin, weights, lists, counts, inverse, pos_rows, (long)blockIdx.x);
+}
+// two routing problems over the same centroids in one launch (the foreground and the background container of a render pass): blocks
+// [0, nb_a) belong to the first
+__global__ __launch_bounds__(ROUTE_BLOCK) void k_route2(RouteProblem a, RouteProblem b, Centroids cen, int d0, float margin, int nb_a) {
+    if ((int)blockIdx.x < nb_a)
+        route_block(a.pos, a.pos_stride, a.B, a.n_dev, a.rows_per_unit, cen, d0, margin, a.weights, a.lists, a.counts, a.inverse, a.pos_rows, (long)blockIdx.x);
+    else
+        route_block(b.pos, b.pos_stride, b.B, b.n_dev, b.rows_per_unit, cen, d0, margin, b.weights, b.lists, b.counts, b.inverse, b.pos_rows,
+                    (long)blockIdx.x - nb_a);
+}
 
 __global__ void k_route_accumulate(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long sub_stride,
                                    int n_cols, const int32_t *__restrict__ list, const int32_t *__restrict__ count,
@@ -855,11 +871,10 @@ __global__ void k_route_accumulate(float *__restrict__ out, long out_stride, con
 // pos[i][row] = index of `row` in cell i's compact list (or -1): k_route's inverse map
 // out[row] = sum over the cells in index order of w_i[row] * sub_i[pos_i[row]]  (same order and roundings as applying
 // k_route_accumulate cell after cell to a zeroed output: mega_nerf.py:43-49)
-__global__ void k_route_combine(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long cell_stride,
-                                long sub_stride, int n_cols, const int32_t *__restrict__ pos, const float *__restrict__ weights,
-                                int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit, int zero_rest) {
+__device__ __forceinline__ void combine_row(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long cell_stride,
+                                            long sub_stride, int n_cols, const int32_t *__restrict__ pos, const float *__restrict__ weights,
+                                            int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit, int zero_rest, long row) {
     const long n = n_dev ? (long)(*n_dev) * rows_per_unit : B;
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) {
         if (zero_rest && row < B)
             for (int c = 0; c < n_cols; ++c) out[row * out_stride + c] = 0.f;
@@ -879,6 +894,21 @@ __global__ void k_route_combine(float *__restrict__ out, long out_stride, const 
         }
         for (int c = 0; c < nc; ++c) out[row * out_stride + c0 + c] = acc[c];
     }
+}
+__global__ void k_route_combine(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long cell_stride,
+                                long sub_stride, int n_cols, const int32_t *__restrict__ pos, const float *__restrict__ weights,
+                                int n_sub, long B, const int32_t *__restrict__ n_dev, int rows_per_unit, int zero_rest) {
+    combine_row(out, out_stride, sub, cell_stride, sub_stride, n_cols, pos, weights, n_sub, B, n_dev, rows_per_unit, zero_rest,
+                (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// the blends of two containers in one launch: blocks [0, nb_a) belong to the first
+__global__ void k_route_combine2(CombineProblem a, CombineProblem b, int n_cols, int n_sub, int nb_a) {
+    if ((int)blockIdx.x < nb_a)
+        combine_row(a.out, a.out_stride, a.sub, a.cell_stride, a.sub_stride, n_cols, a.pos, a.weights, n_sub, a.B, a.n_dev, a.rows_per_unit, 1,
+                    (long)blockIdx.x * blockDim.x + threadIdx.x);
+    else
+        combine_row(b.out, b.out_stride, b.sub, b.cell_stride, b.sub_stride, n_cols, b.pos, b.weights, n_sub, b.B, b.n_dev, b.rows_per_unit, 1,
+                    (long)(blockIdx.x - nb_a) * blockDim.x + threadIdx.x);
 }
 
 }  // namespace mnr
@@ -955,6 +985,24 @@ __global__ void k_route_prepare(RoutePrep a) {
 int route_prepare_launch(const RoutePrep &a, hipStream_t s) {
     hipLaunchKernelGGL(k_route_prepare, dim3(1), dim3(64), 0, s, a);
     return check_launch("k_route_prepare");
+}
+int route2_launch(const RouteProblem &a, const RouteProblem &b, const float *centroids_host, int n_sub, int d0, float margin, hipStream_t s) {
+    MNR_REQUIRE(n_sub >= 1 && n_sub <= ROUTE_MAX_SUB && (d0 == 0 || d0 == 1) && margin >= 1.f, "bad arguments to route2_launch");
+    Centroids cen;
+    cen.n = n_sub;
+    for (int i = 0; i < n_sub; ++i)
+        for (int k = 0; k < 3; ++k) cen.c[i][k] = centroids_host[3 * i + k];
+    const int nb_a = (int)nblk(a.B, ROUTE_BLOCK), nb_b = (int)nblk(b.B, ROUTE_BLOCK);
+    if (nb_a + nb_b == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_route2, dim3(nb_a + nb_b), dim3(ROUTE_BLOCK), 0, s, a, b, cen, d0, margin, nb_a);
+    return check_launch("k_route2");
+}
+int combine2_launch(const CombineProblem &a, const CombineProblem &b, int n_cols, int n_sub, hipStream_t s) {
+    MNR_REQUIRE(n_cols > 0 && n_cols <= 64 && n_sub >= 1 && n_sub <= ROUTE_MAX_SUB, "bad arguments to combine2_launch");
+    const int nb_a = (int)nblk(a.B, 256), nb_b = (int)nblk(b.B, 256);
+    if (nb_a + nb_b == 0) return MNR_OK;
+    hipLaunchKernelGGL(k_route_combine2, dim3(nb_a + nb_b), dim3(256), 0, s, a, b, n_cols, n_sub, nb_a);
+    return check_launch("k_route_combine2");
 }
 int route_launch(const float *pos, long pos_stride, int pos_rows, long B, const int32_t *n_dev, int rows_per_unit, const float *centroids_host, int n_sub,
                  int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, hipStream_t s) {

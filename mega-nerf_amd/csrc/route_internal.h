@@ -16,6 +16,17 @@ struct RoutePrepSeg {
 };
 struct RoutePrep { RoutePrepSeg s[2]; };
 int route_prepare_launch(const RoutePrep &a, hipStream_t s);
+// two routing problems / two blends over the same centroids in ONE launch each (the two containers of a render pass)
+struct RouteProblem {
+    const float *pos; long pos_stride, B; const int32_t *n_dev; int rows_per_unit; int pos_rows;
+    float *weights; int32_t *lists, *counts, *inverse;
+};
+struct CombineProblem {
+    float *out; long out_stride; const float *sub; long cell_stride, sub_stride; const int32_t *pos; const float *weights; long B;
+    const int32_t *n_dev; int rows_per_unit;
+};
+int route2_launch(const RouteProblem &a, const RouteProblem &b, const float *centroids_host, int n_sub, int d0, float margin, hipStream_t s);
+int combine2_launch(const CombineProblem &a, const CombineProblem &b, int n_cols, int n_sub, hipStream_t s);
 int route_launch(const float *pos, long pos_stride, int pos_rows, long B, const int32_t *n_dev, int rows_per_unit, const float *centroids_host, int n_sub,
                  int d0, float margin, float *weights, int32_t *lists, int32_t *counts, int32_t *inverse, hipStream_t s);
 int bg_exit_points_launch(const float *rays_bg, const int32_t *n_bg, long N_max, const float *center, const float *radius, float *out, hipStream_t s);
