@@ -1300,8 +1300,9 @@ static int wide_fg_backward(mnr_step_plan *p, int c, int pass, int idx_is_float,
     // of models/layerwise.py instead) ----
     static const bool separate_heads = getenv("MNR_WIDE_SEPARATE_HEADS") != nullptr;
     if (!separate_heads) {
-        const long nb = (B + 511) / 512;
-        hipLaunchKernelGGL(k_wide_head_adjoint, dim3((unsigned)(nb > 256 ? 256 : (nb < 1 ? 1 : nb))), dim3(256), 0, s, d_out, out, dact, hs[7], d.rgb_w, B,
+        static const long cap = getenv("MNR_WIDE_HEAD_BLOCKS") ? atol(getenv("MNR_WIDE_HEAD_BLOCKS")) : 1024;
+        const long nb = (B + 127) / 128;
+        hipLaunchKernelGGL(k_wide_head_adjoint, dim3((unsigned)(nb > cap ? cap : (nb < 1 ? 1 : nb))), dim3(256), 0, s, d_out, out, dact, hs[7], d.rgb_w, B,
                            d.sigma_activation ? 1 : 0, d_src, g_sig, G.rgb_w, G.rgb_b, G.sigma_w, G.sigma_b);
         WIDE_OK(check_launch("k_wide_head_adjoint"));
     } else {
