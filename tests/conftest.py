@@ -32,3 +32,20 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def free_port() -> str:
+    """A TCP port nothing listens on right now (rendezvous of the multi-process tests: a fixed port can still be held by the previous
+    test's agent for a moment)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return str(so.getsockname()[1])
+
+
+def loopback_env(env: dict) -> dict:
+    """gloo picks its interface from the host name, which need not resolve in a container: pin it to the loopback device when there is one."""
+    import os
+    if os.path.isdir('/sys/class/net/lo'):
+        env.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+    return env

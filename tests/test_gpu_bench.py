@@ -7,6 +7,7 @@ import sys
 from pathlib import Path
 
 import pytest
+from conftest import free_port, loopback_env
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -21,8 +22,8 @@ def _last_json(text):
 def test_two_ranks_step_the_fixed_eight_cell_set():
     """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --submodules 8`: the 8 Rubble cells dealt 4 + 4 to two ranks, every rank
     steps its cells with one mnr_train_step call per iteration, ONE JSON line from rank 0, strong scaling, max-over-ranks timing."""
-    env = dict(os.environ, MNR_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29533',
+    env = loopback_env(dict(os.environ, MNR_BENCH_SHARE_GPU='1', MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', free_port(),
            str(ROOT / 'bench.py'), '--gpus', '2', '--submodules', '8', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras']
     r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -37,7 +38,7 @@ def test_two_ranks_step_the_fixed_eight_cell_set():
 def test_plain_python_launch_with_gpus_2_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command): bench.py starts the two ranks itself
     (torch.distributed.run on 127.0.0.1) and the line says which ranks ran where."""
-    env = dict(os.environ, MNR_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = loopback_env(dict(os.environ, MNR_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0'))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras'],
@@ -77,10 +78,10 @@ def test_rccl_runs_the_paths_collectives_with_one_rank():
     fp32 all_gather and the barrier with ONE rank, then bench.py's own RCCL branch under torch.distributed.run (MNR_BENCH_FORCE_DIST)."""
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     run = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1']
-    r = subprocess.run(run + ['--master-port', '29537', '--no-python', sys.executable, '-c', _RCCL_ONE_RANK], cwd=str(ROOT), env=env,
+    r = subprocess.run(run + ['--master-port', free_port(), '--no-python', sys.executable, '-c', _RCCL_ONE_RANK], cwd=str(ROOT), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'RCCL_OK [1.5, 2.0, 7.0] 3.25 True nccl' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-    r = subprocess.run(run + ['--master-port', '29539', str(ROOT / 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+    r = subprocess.run(run + ['--master-port', free_port(), str(ROOT / 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
                               '--no-extras', '--no-config-sweep'], cwd=str(ROOT), env=dict(env, MNR_BENCH_FORCE_DIST='1'),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
