@@ -48,6 +48,9 @@ timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace_sh2" -o t --output-f
 # routed 8-cell container through the one-call render (route -> all cells in one launch -> blend)
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace_container8" -o t --output-format csv -- \
     python "$B" --mode eval --container 8 --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-diag > "$OUT/bench_container8_under_rocprof.json" 2> "$OUT/trace_container8.err" < /dev/null
+# routed 25-cell container of 512-wide cells (k_mlp_fwd_pair in gather mode, XCD-contiguous workgroup order)
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace_container25" -o t --output-format csv -- \
+    python "$B" --mode eval --layer-dim 512 --container 25 --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-diag > "$OUT/bench_container25_under_rocprof.json" 2> "$OUT/trace_container25.err" < /dev/null
 # keep the merge small: only the csv / json / err files travel back
 find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
 ls "$OUT"

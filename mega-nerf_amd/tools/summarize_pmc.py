@@ -67,7 +67,7 @@ def med(xs):
 def main():
     src, dst, rnd = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
     dst.mkdir(exist_ok=True)
-    for mode in ('train', 'eval', 'w512', 'split', 'sh2', 'container8'):
+    for mode in ('train', 'eval', 'w512', 'split', 'sh2', 'container8', 'container25'):
         for f in glob.glob(str(src / ('trace_' + mode) / '**' / '*kernel_stats.csv'), recursive=True):
             shutil.copy(f, dst / ('%s_%s_kernel_stats.csv' % (rnd, mode)))
         j = src / ('bench_%s_under_rocprof.json' % mode)
