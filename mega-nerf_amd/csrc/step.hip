@@ -882,20 +882,22 @@ __global__ __launch_bounds__(256) void k_step_pack(const PackJob *__restrict__ j
 //   d_src[r][j]  = dact[r][j] > 0 ? sum_c g_rgb[c] W_rgb[c][j] : 0        (data gradient through the rgb layer + ReLU adjoint of dir_a)
 //   dW_rgb[c][j] += g_rgb[c] dact[r][j],  db_rgb[c] += g_rgb[c],  dW_sigma[k] += g_sig hs7[r][k],  db_sigma += g_sig
 // (what k_act_grad x 3, k_gemm x 3 and k_col_sum x 2 did in eight launches, each re-reading a [rows][256 | 512] plane: 0.45 ms per fine
-// pass; here dact and hs7 are read once and d_src written once).  256 threads: thread j owns column j of dact / d_src and columns j,
-// j + 256 of hs7; few long blocks, one set of atomics per block (as k_head_grads).
+// pass; here dact and hs7 are read once and d_src written once).  Thread (g, j) of a block's four row groups owns column j of dact / d_src and
+// columns j, j + 256 of hs7 for the rows of group g; few long blocks, the groups' sums meet in LDS: one set of atomics per block (as k_head_grads).
 constexpr int WH_U = 4;              // rows in flight per iteration
-__global__ __launch_bounds__(256) void k_wide_head_adjoint(const float *__restrict__ d_out, const float *__restrict__ out, const float *__restrict__ dact,
+constexpr int WH_G = 4;              // row groups per block (256 threads each): one set of atomics per block for four times the wavefronts
+__global__ __launch_bounds__(256 * WH_G) void k_wide_head_adjoint(const float *__restrict__ d_out, const float *__restrict__ out, const float *__restrict__ dact,
                                                            const float *__restrict__ hs7, const float *__restrict__ rgb_w, long B, int sigma_softplus,
                                                            float *__restrict__ d_src, float *__restrict__ g_sig_out, float *__restrict__ d_rgb_w,
                                                            float *__restrict__ d_rgb_b, float *__restrict__ d_sigma_w, float *__restrict__ d_sigma_b) {
-    const int j = threadIdx.x;
-    const long per = ((B + gridDim.x - 1) / gridDim.x + WH_U - 1) / WH_U * WH_U;
+    __shared__ float red[WH_G - 1][5][256];
+    __shared__ float redb[WH_G - 1][4];
+    const int j = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const long per = ((B + gridDim.x - 1) / gridDim.x + WH_U * WH_G - 1) / (WH_U * WH_G) * (WH_U * WH_G);
     const long rb = (long)blockIdx.x * per, re = min(B, rb + per);
-    if (rb >= re) return;
     const float w0 = rgb_w[j], w1 = rgb_w[256 + j], w2 = rgb_w[512 + j];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, bs = 0.f;
-    for (long r0 = rb; r0 < re; r0 += WH_U) {
+    for (long r0 = rb + g * WH_U; r0 < re; r0 += WH_U * WH_G) {
         float4 go[WH_U], o[WH_U];
         float x[WH_U], h0[WH_U], h1[WH_U];
 #pragma unroll
@@ -918,6 +920,18 @@ __global__ __launch_bounds__(256) void k_wide_head_adjoint(const float *__restri
             s0 = fmaf(gs, h0[u], s0); s1 = fmaf(gs, h1[u], s1);
             if (j == 0) { b0 += g0; b1 += g1; b2 += g2; bs += gs; g_sig_out[r0 + u] = gs; }
         }
+    }
+    // the block's row groups meet in LDS; group 0 adds the block's sums with one set of atomics
+    if (g > 0) {
+        red[g - 1][0][j] = a0; red[g - 1][1][j] = a1; red[g - 1][2][j] = a2; red[g - 1][3][j] = s0; red[g - 1][4][j] = s1;
+        if (j == 0) { redb[g - 1][0] = b0; redb[g - 1][1] = b1; redb[g - 1][2] = b2; redb[g - 1][3] = bs; }
+    }
+    __syncthreads();
+    if (g > 0 || rb >= re) return;
+#pragma unroll
+    for (int q = 0; q < WH_G - 1; ++q) {
+        a0 += red[q][0][j]; a1 += red[q][1][j]; a2 += red[q][2][j]; s0 += red[q][3][j]; s1 += red[q][4][j];
+        if (j == 0) { b0 += redb[q][0]; b1 += redb[q][1]; b2 += redb[q][2]; bs += redb[q][3]; }
     }
     atomicAdd(d_rgb_w + j, a0); atomicAdd(d_rgb_w + 256 + j, a1); atomicAdd(d_rgb_w + 512 + j, a2);
     atomicAdd(d_sigma_w + j, s0); atomicAdd(d_sigma_w + 256 + j, s1);
@@ -1300,9 +1314,9 @@ static int wide_fg_backward(mnr_step_plan *p, int c, int pass, int idx_is_float,
     // of models/layerwise.py instead) ----
     static const bool separate_heads = getenv("MNR_WIDE_SEPARATE_HEADS") != nullptr;
     if (!separate_heads) {
-        static const long cap = getenv("MNR_WIDE_HEAD_BLOCKS") ? atol(getenv("MNR_WIDE_HEAD_BLOCKS")) : 1024;
-        const long nb = (B + 127) / 128;
-        hipLaunchKernelGGL(k_wide_head_adjoint, dim3((unsigned)(nb > cap ? cap : (nb < 1 ? 1 : nb))), dim3(256), 0, s, d_out, out, dact, hs[7], d.rgb_w, B,
+        static const long cap = getenv("MNR_WIDE_HEAD_BLOCKS") ? atol(getenv("MNR_WIDE_HEAD_BLOCKS")) : 512;
+        const long nb = (B + 255) / 256;
+        hipLaunchKernelGGL(k_wide_head_adjoint, dim3((unsigned)(nb > cap ? cap : (nb < 1 ? 1 : nb))), dim3(256 * WH_G), 0, s, d_out, out, dact, hs[7], d.rgb_w, B,
                            d.sigma_activation ? 1 : 0, d_src, g_sig, G.rgb_w, G.rgb_b, G.sigma_w, G.sigma_b);
         WIDE_OK(check_launch("k_wide_head_adjoint"));
     } else {
