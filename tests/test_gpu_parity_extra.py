@@ -600,3 +600,36 @@ def test_one_call_routed_render_equals_the_stage_by_stage_render_at_ragged_sizes
         assert p1 == p2 and sorted(fused) == sorted(stage)
         for k in fused:
             np.testing.assert_array_equal(fused[k].cpu().numpy(), stage[k].cpu().numpy(), err_msg='%s n=%d %s' % (name, n, k))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('width', [256, 512])
+def test_routed_launch_workgroup_order_does_not_change_a_bit(width, monkeypatch):
+    """Gather-mode launches of a merged container hand every XCD a contiguous run of the cells' workgroups (csrc/mlp_fwd_kernels.h
+    ``xcd_contiguous``; ``MNR_NO_XCD_ORDER=1``: the hardware's round-robin).  Same tiles on other CUs: MegaNeRF.forward
+    (mega_nerf.py:19-61) must return the same bits either way -- 3 / 25 / 64 cells (64 = the router's maximum), row counts from one row to
+    several rounds of workgroups, most cells empty at the small ones, hard and blended routing."""
+    from mega_nerf.models.mega_nerf import MegaNeRF
+    hp = O.make_hparams(coarse_samples=64, fine_samples=128, layer_dim=width, bg_layer_dim=width)
+    cfg = common.model_cfg(hp, 3, width)
+    A = common.SCENE['appearance_count']
+    rng = np.random.default_rng(91)
+    base = [common.make_weights(cfg, A, 9100 + i, sharpen=False) for i in range(3)]
+    for n_cells, rows in ((3, (1, 63, 65, 4097)), (25, (7, 640, 20011)), (64, (129, 9000))):
+        g = int(np.ceil(np.sqrt(n_cells)))
+        cent = np.array([[0.0, -.7 + 1.4 * (i // g) / max(1, g - 1), -.7 + 1.4 * (i % g) / max(1, g - 1)] for i in range(n_cells)], f32)
+        subs = [native_nerf(cfg, base[i % 3]) for i in range(n_cells)]
+        for margin in (1.0, 1.15):
+            m = MegaNeRF(subs, torch.from_numpy(cent), margin, False, False).to(DEV).eval()
+            for B in rows:
+                x = np.concatenate([rng.uniform(-.8, .8, (B, 3)), rng.standard_normal((B, 3)), rng.integers(0, A, (B, 1))], 1).astype(f32)
+                out = {}
+                for order in ('xcd', 'round_robin'):
+                    if order == 'xcd':
+                        monkeypatch.delenv('MNR_NO_XCD_ORDER', raising=False)
+                    else:
+                        monkeypatch.setenv('MNR_NO_XCD_ORDER', '1')
+                    with torch.no_grad():
+                        out[order] = m(T(x)).cpu().numpy()
+                assert np.isfinite(out['xcd']).all()
+                np.testing.assert_array_equal(out['xcd'], out['round_robin'], err_msg='%d cells, margin %.2f, %d rows' % (n_cells, margin, B))
