@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_step_begin(BeginArgs ba, long N, SSphe
     const mnr_step_batch &b = ba.b[cell];
     const long base = (long)cell * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
+    if (threadIdx.x == 0) { base_s = 0; err_o[cell] = 0; }          // (the cell's error flag belongs to this block: cleared here, no memset launch in front)
     __syncthreads();
     for (long start = 0; start < N; start += 1024) {
         const long i = start + threadIdx.x;
@@ -1805,7 +1805,6 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
     const SSphere sp{r->sphere_center[0], r->sphere_center[1], r->sphere_center[2], r->sphere_radius[0], r->sphere_radius[1], r->sphere_radius[2]};
-    if (hipMemsetAsync(r->err, 0, 4, s) != hipSuccess) return set_err(MNR_E_LAUNCH, "hipMemsetAsync(render)");
     {
         BeginArgs ba{};
         ba.b[0].rays = r->rays; ba.b[0].idx = r->idx; ba.b[0].idx_is_float = r->idx_is_float; ba.b[0].target = nullptr;
