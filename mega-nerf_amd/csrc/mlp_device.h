@@ -74,7 +74,16 @@ __device__ __forceinline__ void gstore4(const float *uniform_base, unsigned byte
     mnr_gchar *b = (mnr_gchar *)uniform_ptr(reinterpret_cast<const char *>(uniform_base));
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) f4v gf4v;
+    // NON-TEMPORAL: the tapes (1.1 - 2 GB per launch) are read back launches later, by kernels that stream them once; written through, they
+    // leave no dirty lines behind in the eight L2s for the next kernel to work around.  Measured (same box, alternated twice; -DMNR_PLAIN_TAPE_STORES
+    // builds the other form): benchmark step 6.12 -> 6.06 ms (the launch behind the data-gradient chain, k_head_grads, 0.120 -> 0.080 ms),
+    // 512-wide step 22.94 -> 22.75, split-precision step 3.10 -> 3.01 (its forward's fine launch 0.578 -> 0.519); inference unchanged.
+    // (k_tgemm's output tiles are the next launch's operand: there non-temporal stores cost 18 %, csrc/tgemm.hip.)
+#ifdef MNR_PLAIN_TAPE_STORES
     *(gf4v *)(b + byte_off + IMM) = f4v{v.x, v.y, v.z, v.w};
+#else
+    __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, (gf4v *)(b + byte_off + IMM));
+#endif
 }
 
 // ---- weight stream: global -> LDS (async LDS-DMA, issued one chunk ahead) ------------------------

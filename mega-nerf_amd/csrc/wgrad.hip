@@ -28,6 +28,9 @@
 #include "lds_asm.h"
 #include "step_internal.h"
 
+#ifndef MNR_WGRAD_LOAD_AUX
+#define MNR_WGRAD_LOAD_AUX 0          // cache policy of the operand stream (2 = non-temporal: comparison builds)
+#endif
 namespace mnr {
 
 int layout_from_desc(const mnr_model_desc *d, ModelLayout &m);
@@ -263,7 +266,7 @@ __device__ __forceinline__ void wgrad_episode(const WArgs &a, int j, int item, f
                 if constexpr (S::NSEG == 3) src = t >= F2 ? q.i[2] + (t - F2) * 4 : src;
             }
             float *dst = stage0 + stage * S::STAGE_FLOATS + (lo + wave * 64) * 4;   // wave-uniform; HW adds lane*16
-            __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, MNR_WGRAD_LOAD_AUX);
         }
     };
 
