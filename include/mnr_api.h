@@ -677,10 +677,11 @@ typedef struct mnr_render_io {
     void *workspace;  size_t workspace_bytes;
     void *side;                        /* optional side handle of mnr_side_create: the background branch runs on its stream beside the foreground's passes; NULL = one stream */
     /* Merged containers (mega_nerf.py:19-61 behind rendering.py:275-331, model_utils.py:22-29): with n_cells > 0 BOTH models are MegaNeRF
-     * routers over the same n_cells centroids (3-D clustering: cluster_2d containers take the stage-by-stage path).  fg / bg then describe
+     * routers over the same n_cells centroids.  fg / bg then describe
      * the cells' shared architectures, fg_packed / bg_packed are ignored, and every MLP pass becomes: route the pass's rows (k_route:
      * blend weights, per-cell row lists, on the device) -> ONE gather-mode launch of all cells of both containers -> blend in cell order
-     * (k_route_combine).  The background's routing position is its ray's sphere-exit point (rendering.py:463-464). */
+     * (k_route_combine).  The background's routing position is its ray's sphere-exit point (rendering.py:463-464), or the sample's own
+     * far-away position under cluster_2d. */
     int32_t n_cells;                   /* 0 = plain models; 1 .. 64 */
     const void *const *fg_cell_packed; /* HOST arrays [n_cells]: device pointers of the cells' mnr_pack_model images ... */
     const void *const *bg_cell_packed;
@@ -688,6 +689,7 @@ typedef struct mnr_render_io {
     const float *const *bg_cell_emb;
     const float *centroids_host;       /* [n_cells][3] */
     float boundary_margin;             /* >= 1 (1 = hard routing) */
+    int32_t cluster_2d;                /* container.cluster_2d (mega_nerf.py:16): distances over y, z; a background row then routes on o + d * depth_real (rendering.py:458-461) */
     void *route_workspace;  size_t route_workspace_bytes;    /* mnr_render_route_workspace_bytes() */
 } mnr_render_io;
 /* A side stream + fork / join events a caller may lend to mnr_render_fwd (host objects; create once per device / thread, destroy at exit). */

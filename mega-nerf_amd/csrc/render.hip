@@ -741,7 +741,8 @@ constexpr int ROUTE_BLOCK = 1024;
 __device__ __forceinline__ void route_block(const float *__restrict__ pos, long pos_stride, long B,
                                             const int32_t *__restrict__ n_dev, int rows_per_unit, const Centroids &cen, int d0,
                                             float margin, float *__restrict__ weights, int32_t *__restrict__ lists,
-                                            int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows, long blk) {
+                                            int32_t *__restrict__ counts, int32_t *__restrict__ inverse, int pos_rows, long blk,
+                                            const float *__restrict__ ray_depth = nullptr, int depth_flip = 0) {
     __shared__ int wcnt[ROUTE_MAX_SUB][ROUTE_BLOCK / 64];
     __shared__ int base[ROUTE_MAX_SUB];
     __shared__ float4 sc[ROUTE_MAX_SUB];                                   // (c_x, c_y, c_z, |c|^2 over the clustered axes)
@@ -763,7 +764,16 @@ __device__ __forceinline__ void route_block(const float *__restrict__ pos, long 
     // (pos_rows > 1: one position per pos_rows consecutive rows -- the background rows of a ray under 3-D clustering all carry the ray's
     // sphere-exit point, rendering.py:463-464)
     const long prow = pos_rows > 1 ? row / pos_rows : row;
-    if (valid) { p[0] = pos[prow * pos_stride]; p[1] = pos[prow * pos_stride + 1]; p[2] = pos[prow * pos_stride + 2]; }
+    if (valid) {
+        p[0] = pos[prow * pos_stride]; p[1] = pos[prow * pos_stride + 1]; p[2] = pos[prow * pos_stride + 2];
+        if (ray_depth) {
+            // `cluster_2d` background rows: `pos` holds rays (origin, direction), the routing point is the sample's true position
+            // o + d * depth_real (rendering.py:458-461; the same separately rounded product and sum as k_bg_samples' 7-column form)
+            // (depth_flip: the coarse background rows reach the MLP in the flipped order of rendering.py:271-273, their depth_real is stored ascending)
+            const float m = ray_depth[depth_flip ? prow * pos_rows + (pos_rows - 1 - (row - prow * pos_rows)) : row];
+            p[0] = p[0] + pos[prow * pos_stride + 3] * m; p[1] = p[1] + pos[prow * pos_stride + 4] * m; p[2] = p[2] + pos[prow * pos_stride + 5] * m;
+        }
+    }
     // distances: torch.cdist(x[:, d0:3], centroids[:, d0:]) (mega_nerf.py:22,31).  ATen takes its MATMUL formulation whenever either side
     // has more than 25 rows (cdist mode "use_mm_for_euclid_dist_if_necessary"; _euclidean_dist): [-2x, |x|^2, 1] . [c, 1, |c|^2] as one
     // sgemm -- an fma chain in column order (checked against torch / MKL: oracle/nerf_oracle.py cdist_mm) --, clamp_min(0), sqrt.  The two
@@ -847,10 +857,11 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void k_route(const float *__restrict__
 // [0, nb_a) belong to the first
 __global__ __launch_bounds__(ROUTE_BLOCK) void k_route2(RouteProblem a, RouteProblem b, Centroids cen, int d0, float margin, int nb_a) {
     if ((int)blockIdx.x < nb_a)
-        route_block(a.pos, a.pos_stride, a.B, a.n_dev, a.rows_per_unit, cen, d0, margin, a.weights, a.lists, a.counts, a.inverse, a.pos_rows, (long)blockIdx.x);
+        route_block(a.pos, a.pos_stride, a.B, a.n_dev, a.rows_per_unit, cen, d0, margin, a.weights, a.lists, a.counts, a.inverse, a.pos_rows, (long)blockIdx.x,
+                    a.ray_depth, a.depth_flip);
     else
         route_block(b.pos, b.pos_stride, b.B, b.n_dev, b.rows_per_unit, cen, d0, margin, b.weights, b.lists, b.counts, b.inverse, b.pos_rows,
-                    (long)blockIdx.x - nb_a);
+                    (long)blockIdx.x - nb_a, b.ray_depth, b.depth_flip);
 }
 
 __global__ void k_route_accumulate(float *__restrict__ out, long out_stride, const float *__restrict__ sub, long sub_stride,

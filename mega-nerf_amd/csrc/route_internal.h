@@ -20,6 +20,8 @@ int route_prepare_launch(const RoutePrep &a, hipStream_t s);
 struct RouteProblem {
     const float *pos; long pos_stride, B; const int32_t *n_dev; int rows_per_unit; int pos_rows;
     float *weights; int32_t *lists, *counts, *inverse;
+    const float *ray_depth;      // NULL, or per-row depths: `pos` then holds RAYS (stride pos_stride, one per pos_rows rows) and a row routes on o + d * ray_depth[row]
+    int depth_flip;              // ... ray_depth is stored in the opposite sample order of the rows (coarse background pass)
 };
 struct CombineProblem {
     float *out; long out_stride; const float *sub; long cell_stride, sub_stride; const int32_t *pos; const float *weights; long B;

@@ -1829,6 +1829,7 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
         MNR_REQUIRE(!r->split_precision, "routed render: fp32 kernels");
         route_layout(N, Nc, Nf, n_cells, route_ncol, RL);
         MNR_REQUIRE(r->route_workspace_bytes >= RL.total, "routing workspace too small: %zu < %zu", r->route_workspace_bytes, RL.total);
+        if (!r->cluster_2d)            // (cluster_2d: the background routes per sample on o + d * depth_real, see fwd_pass)
         if ((rc = bg_exit_points_launch(F(L.rays_bg), r->n_bg, N, r->sphere_center, r->sphere_radius,
                                         reinterpret_cast<float *>(reinterpret_cast<char *>(r->route_workspace) + RL.exit_pts), s))) return rc;
     }
@@ -1869,9 +1870,15 @@ extern "C" int mnr_render_fwd(const mnr_render_io *r, void *stream) {
             if (rc2) return rc2;
             // foreground rows route on their own position; a background ray's rows all on its sphere-exit point -- both in one launch
             {
-                RouteProblem pa{io[0].xyz, 3, B[0], nullptr, 0, 1, RF(RL.fg.weights), RI(RL.fg.lists), RI(RL.fg.counts), RI(RL.fg.inverse)};
-                RouteProblem pb{RF(RL.exit_pts), 3, B[1], r->n_bg, (int)Sbb, (int)Sbb, RF(RL.bg.weights), RI(RL.bg.lists), RI(RL.bg.counts), RI(RL.bg.inverse)};
-                if ((rc2 = route2_launch(pa, pb, r->centroids_host, n_cells, 0, r->boundary_margin, st))) return rc2;
+                RouteProblem pa{io[0].xyz, 3, B[0], nullptr, 0, 1, RF(RL.fg.weights), RI(RL.fg.lists), RI(RL.fg.counts), RI(RL.fg.inverse), nullptr, 0};
+                RouteProblem pb{RF(RL.exit_pts), 3, B[1], r->n_bg, (int)Sbb, (int)Sbb, RF(RL.bg.weights), RI(RL.bg.lists), RI(RL.bg.counts), RI(RL.bg.inverse), nullptr, 0};
+                if (r->cluster_2d) {
+                    // `cluster_2d` containers (mega_nerf.py:16,22: distances over y, z only): a background row routes on its sample's TRUE position
+                    // o + d * depth_real (rendering.py:458-461), not on the ray's sphere-exit point
+                    pb.pos = F(L.rays_bg); pb.pos_stride = 8;
+                    pb.ray_depth = F(pass ? L.dr_f : L.dr_c); pb.depth_flip = pass ? 0 : 1;
+                }
+                if ((rc2 = route2_launch(pa, pb, r->centroids_host, n_cells, r->cluster_2d ? 1 : 0, r->boundary_margin, st))) return rc2;
             }
             float *outs[2] = {io[0].out, io[1].out};
             mnr_mlp_cells_launch cl[2] = {};

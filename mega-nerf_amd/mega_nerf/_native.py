@@ -183,7 +183,7 @@ class RenderIO(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('side', C.c_void_p),
                 ('n_cells', C.c_int32), ('fg_cell_packed', C.POINTER(C.c_void_p)), ('bg_cell_packed', C.POINTER(C.c_void_p)),
                 ('fg_cell_emb', C.POINTER(C.c_void_p)), ('bg_cell_emb', C.POINTER(C.c_void_p)), ('centroids_host', c_float_p),
-                ('boundary_margin', C.c_float), ('route_workspace', C.c_void_p), ('route_workspace_bytes', C.c_size_t)]
+                ('boundary_margin', C.c_float), ('cluster_2d', C.c_int32), ('route_workspace', C.c_void_p), ('route_workspace_bytes', C.c_size_t)]
 
 
 class Calibration(C.Structure):

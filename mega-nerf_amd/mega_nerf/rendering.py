@@ -410,12 +410,15 @@ def release_render_workspaces(*models) -> None:
 
 
 def _routed_pair(nerf, bg_nerf) -> bool:
-    """Both models are merged containers (MegaNeRF routers) the one-call render covers: the same centroids and margin, 3-D clustering, the
-    foreground routed on its points and the background on its rays' sphere-exit points (mega_nerf.py:19-61)."""
+    """Both models are merged containers (MegaNeRF routers) the one-call render covers: the same centroids, margin and clustering (3-D, or
+    `cluster_2d`), the foreground routed on its points and the background on its rays' sphere-exit points -- under `cluster_2d` on every
+    sample's own far-away position (mega_nerf.py:19-61, rendering.py:458-464)."""
     from mega_nerf.models.mega_nerf import MegaNeRF
     if not (isinstance(nerf, MegaNeRF) and isinstance(bg_nerf, MegaNeRF)):
         return False
-    if nerf.cluster_dim_start or bg_nerf.cluster_dim_start or nerf.xyz_real or not bg_nerf.xyz_real or nerf.joint_training or bg_nerf.joint_training:
+    if nerf.cluster_dim_start != bg_nerf.cluster_dim_start or nerf.xyz_real or not bg_nerf.xyz_real or nerf.joint_training or bg_nerf.joint_training:
+        return False
+    if nerf.cluster_dim_start and os.environ.get('MNR_NO_FUSED_2D_ROUTED_RENDER'):
         return False
     if len(nerf.sub_modules) != len(bg_nerf.sub_modules) or not 1 <= len(nerf.sub_modules) <= 64:
         return False
@@ -496,7 +499,7 @@ def _fused_render(nerf, bg_nerf, rays, image_indices, hparams, sphere_center, sp
         io.fg, io.bg = C.pointer(fd), C.pointer(bd)
         io.n_cells, io.fg_cell_packed, io.fg_cell_emb, io.bg_cell_packed, io.bg_cell_emb = nc, arrs[0], arrs[1], arrs[2], arrs[3]
         cent = nerf._centroids_host()
-        io.centroids_host, io.boundary_margin = cent, float(nerf.boundary_margin)
+        io.centroids_host, io.boundary_margin, io.cluster_2d = cent, float(nerf.boundary_margin), int(nerf.cluster_dim_start == 1)
         sh_blend = hparams.sh_deg is not None and hparams.pos_dir_dim == 0 and float(nerf.boundary_margin) > 1
         rneed = lib.mnr_render_route_workspace_bytes(n, Nc, Nf, nc, nerf.sub_modules[0].rgb_dim + 1 if sh_blend else 4)
         rws = _route_ws.get(key)

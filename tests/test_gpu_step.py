@@ -201,7 +201,9 @@ def test_generated_random_numbers_are_uniform_and_keyed():
                                         # merged containers: route -> all cells in one launch -> blend inside the same call (mega_nerf.py:19-61)
                                         ('render_container_eval', False), ('render_container8_eval', False), ('render_container25_eval', False),
                                         ('render_container_w512_eval', False), ('render_container_sh2_eval', False),
-                                        ('render_container_default_samples_eval', False), ('render_container_sh3_eval', False)])
+                                        ('render_container_default_samples_eval', False), ('render_container_sh3_eval', False),
+                                        # cluster_2d: distances over y, z; the background routed per sample on o + d * depth_real (rendering.py:458-461)
+                                        ('render_container_2d_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
     """mnr_render_fwd (six launches; routed containers: seventeen) against the stage-by-stage render -- identical outputs, bit for bit, for
     the fp32 kernels -- and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
@@ -227,14 +229,17 @@ def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
         np.testing.assert_array_equal(a, stage[k].cpu().numpy(), err_msg=k)
 
 
-def test_cluster_2d_containers_stay_on_the_stage_by_stage_path():
-    """Under cluster_2d the background is routed per SAMPLE on the true far-away point (rendering.py:459-461): not what the one-call
-    render's per-ray routing position covers, so it must decline (and the stage-by-stage render serves the fixture)."""
+def test_cluster_2d_containers_can_be_kept_on_the_stage_by_stage_path(monkeypatch):
+    """`cluster_2d` containers go through the one-call render like the others (the case above); MNR_NO_FUSED_2D_ROUTED_RENDER=1 keeps them
+    on the stage-by-stage path (comparison runs)."""
     from mega_nerf import rendering as R
     name = 'render_container_2d_eval'
     g = load(name)
     hp, nerf, bg_nerf = native_models(name)
     hpn = Namespace(**vars(hp))
+    assert nerf.cluster_dim_start == 1
+    assert R._fused_render_ok(nerf, bg_nerf, hpn, T(g['idx'].astype(f32)), T(common.SCENE['sphere_radius']), False, {})
+    monkeypatch.setenv('MNR_NO_FUSED_2D_ROUTED_RENDER', '1')
     assert not R._fused_render_ok(nerf, bg_nerf, hpn, T(g['idx'].astype(f32)), T(common.SCENE['sphere_radius']), False, {})
 
 
