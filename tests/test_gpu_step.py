@@ -205,7 +205,7 @@ def test_generated_random_numbers_are_uniform_and_keyed():
                                         # cluster_2d: distances over y, z; the background routed per sample on o + d * depth_real (rendering.py:458-461)
                                         ('render_container_2d_eval', False)])
 def test_fused_render_equals_the_stagewise_path_and_the_reference(name, split):
-    """mnr_render_fwd (six launches; routed containers: seventeen) against the stage-by-stage render -- identical outputs, bit for bit, for
+    """mnr_render_fwd (six launches; routed containers: thirteen) against the stage-by-stage render -- identical outputs, bit for bit, for
     the fp32 kernels -- and against the reference's outputs at the north-star tolerance; also on the split-precision MLP kernel."""
     from mega_nerf import rendering as R
     g = load(name)
