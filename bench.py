@@ -1362,6 +1362,11 @@ def run_config(args, rank, world, dev, dist):
                         'hbm_read_gbps', 'hbm_write_gbps')
                 roof['box'] = {'before': {k: cal_before.get(k) for k in keys}, 'after': {k: (cal_after or {}).get(k) for k in keys},
                                'verdict': diag.get('box_verdict')}
+                # the same achieved rate against what THIS box delivered on a pure fp32-MFMA loop chip-wide (clocks under that load
+                # are power-limited below the 2.4 GHz the 157.3 TFLOP/s peak is priced at): context, not a second roofline
+                rates = [c.get('mfma_f32_tflops') for c in (cal_before, cal_after or {}) if c.get('mfma_f32_tflops')]
+                if rates and roof.get('achieved'):
+                    roof['box']['achieved_over_calibrated_mfma_rate'] = round(roof['achieved'] / (sum(rates) / len(rates)), 4)
                 if cl is not None:
                     roof['box']['sclk_mhz_during'] = next((v for k, v in cl.items() if k.startswith('sclk')), None)
                     roof['box']['power_w_during'] = cl.get('power_w')
