@@ -260,6 +260,13 @@ __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[N
     static_assert(NB >= 4 * NG, "B register array too small");
     static_assert(!PUB_END || seg_weaves<TILE, NOB, NG, GPC, G0>(), "only the woven pipeline publishes ahead");
     static_assert(TILE == 16 || (NOBF == NOB && OB0 == 0), "feature split: 16-row tiles only");
+    // A wavefront inside a K segment (the MFMA stream) outranks the SIMD's other wavefront while that one is between segments (layer boundary:
+    // bias / ReLU / encodings, tape stores): the issue arbiter is oldest-first otherwise.  Measured, same box, six alternations
+    // (-DMNR_NO_SETPRIO builds the other form): render 1.922 -> 1.905 ms (every pair), benchmark step 6.034 -> 6.019 (mean of four), 8-cell container 3.450 -> 3.447.
+#ifndef MNR_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(2);
+    struct PrioGuard { __device__ ~PrioGuard() { __builtin_amdgcn_s_setprio(0); } } prio_guard;
+#endif
     if constexpr (TILE == 32) {
         static_for<0, NG>([&](auto gi) {
             constexpr int g = G0 + decltype(gi)::value;
