@@ -67,6 +67,10 @@ __device__ __forceinline__ void run_segment_half(floatx4 (&acc)[NOBH], const flo
                                                  unsigned bst = 0) {
     static_assert(BSTASH || NB >= 4 * NG, "B register array too small");
     static_assert(NOBH % 8 == 0, "blocks per half: whole pairs of four-block batches");
+#ifdef MNR_PAIR_SETPRIO                // comparison builds (mlp_device.h::run_segment has it by default)
+    __builtin_amdgcn_s_setprio(2);
+    struct PrioGuard { __device__ ~PrioGuard() { __builtin_amdgcn_s_setprio(0); } } prio_guard;
+#endif
     // ONE two-deep pipeline over the segment's batches (mlp_device.h: SegSched, frag_load, frag_mfmas -- the accumulator pins behind every
     // batch keep the MFMAs above the reads that follow them).  A chunk boundary does not restart it: when batch t + 2 opens a new weight
     // chunk, the barrier is taken at the START of batch t, as soon as the reads of the old chunk (batches t, t + 1) have landed; the
