@@ -137,7 +137,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         zero_acc(accd);
         st.next_chunk();
         gtape_store<P>(dd, a.gtape + a.tl.dact_off * cap, (unsigned)((trow * (W / 2) + 4 * part) * 4), valid);
-        run_segment<TILE, NOBD, H2 / 4, GPCD, 0>(accd, dd, st, lane);
+        run_segment<TILE, NOBD, H2 / 4, GPCD, 0, false, NOBD, 0, true>(accd, dd, st, lane);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
@@ -186,7 +186,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         st.next_chunk();
         gtape_store<P>(g, a.gtape + a.tl.fin_off * cap, (unsigned)((trow * W + 4 * part) * 4), valid);
         // (woven pipeline: every W x W layer publishes its successor's first chunk two batches before its own end -- run_segment PUB_END)
-        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && C::NL > 1)>(acc, g, st, lane);
+        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && C::NL > 1), NOB, 0, true>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
     }
@@ -198,7 +198,7 @@ __device__ __forceinline__ void mlp_bwd_body(const MlpBwdArgs &a, long blk, int 
         const MaskBits<H> bits = mask_load<H>(a.tape + a.tl.mask_off[l - 1] * cap, trow, a.tl.mask_w, part);
         if constexpr (!PUBT) st.next_chunk();
         gtape_store<P>(g, a.gtape + a.tl.act_off[l] * cap, (unsigned)((trow * W + 4 * part) * 4), valid);       // dZ_l (deferred, see gtape_store)
-        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && l > 1)>(acc, g, st, lane);
+        run_segment<TILE, NOB, H / 4, C::GPC, 0, (PUBT && l > 1), NOB, 0, true>(acc, g, st, lane);
         acc_to_regs<NOB, RPB, false>(g, acc);
         mask_apply(g, bits);
     });

@@ -255,17 +255,19 @@ constexpr bool seg_weaves() {
 // batches before the end, exactly like a chunk boundary inside the segment; the caller then skips the next layer's next_chunk().
 // NOBF / OB0 (feature-split workgroups, mlp_fwd_split_body): the layer has NOBF output blocks per group in the weight stream and this
 // wavefront computes the NOB blocks OB0 .. OB0 + NOB of them.
-template <int TILE, int NOB, int NG, int GPC, int G0, bool PUB_END = false, int NOBF = NOB, int OB0 = 0, class AccT, int NB, class Stream>
+template <int TILE, int NOB, int NG, int GPC, int G0, bool PUB_END = false, int NOBF = NOB, int OB0 = 0, bool BOUNDARY_FIRST = false, class AccT, int NB, class Stream>
 __device__ __forceinline__ void run_segment(AccT (&acc)[NOB], const float (&b)[NB], Stream &st, int lane) {
     static_assert(NB >= 4 * NG, "B register array too small");
     static_assert(!PUB_END || seg_weaves<TILE, NOB, NG, GPC, G0>(), "only the woven pipeline publishes ahead");
     static_assert(TILE == 16 || (NOBF == NOB && OB0 == 0), "feature split: 16-row tiles only");
-    // A wavefront inside a K segment (the MFMA stream) outranks the SIMD's other wavefront while that one is between segments (layer boundary:
-    // bias / ReLU / encodings, tape stores): the issue arbiter is oldest-first otherwise.  Measured, same box, six alternations
-    // (-DMNR_NO_SETPRIO builds the other form): render 1.922 -> 1.905 ms (every pair), benchmark step 6.034 -> 6.019 (mean of four), 8-cell container 3.450 -> 3.447.
+    // Issue priority (the arbiter is oldest-first otherwise).  Forward kernels: a wavefront inside a K segment (the MFMA stream) outranks the SIMD's
+    // other wavefront while that one is between segments (bias / ReLU / encodings, tape stores) -- render 1.922 -> 1.905 ms in every one of six
+    // alternations, benchmark step 6.034 -> 6.019.  BOUNDARY_FIRST (the data-gradient chain, whose boundaries carry the mask arithmetic and the
+    // gradient-tape stores): the other way round, the boundary outranks the stream -- chain 1.819 -> 1.800 ms (three alternations), while the
+    // forward launches lose 1 % that way.  (-DMNR_NO_SETPRIO: neither.)
 #ifndef MNR_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(2);
-    struct PrioGuard { __device__ ~PrioGuard() { __builtin_amdgcn_s_setprio(0); } } prio_guard;
+    struct PrioGuard { __device__ ~PrioGuard() { __builtin_amdgcn_s_setprio(BOUNDARY_FIRST ? 3 : 0); } } prio_guard;
+    __builtin_amdgcn_s_setprio(BOUNDARY_FIRST ? 1 : 2);
 #endif
     if constexpr (TILE == 32) {
         static_for<0, NG>([&](auto gi) {
